@@ -1,0 +1,232 @@
+"""oracle/torch_ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU (fp32, plain torch ops) restatement of the reference's per-frame hot path, function by function.
+It exists because /root/reference cannot travel to the GPU box; tests/test_oracle_vs_reference.py
+pins every function here against the real reference imported through oracle/reference_loader.py
+(in the build container), and tests/golden/*.npz hold outputs of the real reference.
+
+The conv / instance-norm / grid_sample / interpolate arithmetic itself is PyTorch's (the reference
+calls torch for it: networks/generator.py:13-17,80-133,307,313; pinned de facto to torch 2.10 CPU,
+SURVEY.md section 8c).  grid_sample therefore follows torch>=1.3's default align_corners=False (hazard H1).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import raster as _raster
+
+EYE_Z = -(1.0 / math.tan(math.radians(30.0)) + 1.0)  # utils/nmr.py:177 (viewing_angle=30)
+
+
+# --------------------------------------------------------------------------- geometry (a3-a9)
+def look_at(vertices, eye, at=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
+    """neural_renderer/look_at.py:6-62 for the general case (used only by the KAT test)."""
+    bs = vertices.shape[0]
+    eye = torch.as_tensor(eye, dtype=torch.float32).reshape(1, 3).repeat(bs, 1)
+    at = torch.as_tensor(at, dtype=torch.float32).reshape(1, 3).repeat(bs, 1)
+    up = torch.as_tensor(up, dtype=torch.float32).reshape(1, 3).repeat(bs, 1)
+    z = F.normalize(at - eye, eps=1e-5)
+    x = F.normalize(torch.cross(up, z, dim=1), eps=1e-5)
+    y = F.normalize(torch.cross(z, x, dim=1), eps=1e-5)
+    r = torch.stack((x, y, z), dim=1)
+    return torch.matmul(vertices - eye[:, None, :], r.transpose(1, 2))
+
+
+def project_vertices(verts, cam):
+    """utils/nmr.py:10-28 (orthographic_proj_withz_idrot) + nmr.py:271 (y flip) + look_at with the
+    renderer's fixed eye (nmr.py:177,273): rotation is the identity, z is shifted by -eye_z."""
+    scale = cam[:, 0].reshape(-1, 1, 1)
+    trans = cam[:, 1:3].reshape(cam.shape[0], 1, 2)
+    xy = scale * (verts[:, :, :2] + trans)
+    out = torch.cat((xy, verts[:, :, 2:3]), 2)
+    out[:, :, 1] *= -1
+    eye = torch.tensor([0.0, 0.0, EYE_Z], dtype=torch.float32)
+    return out - eye[None, None, :]
+
+
+def vertices_to_faces(vertices, faces_idx):
+    """neural_renderer/vertices_to_faces.py:4-22.  faces_idx: (nf,3) or (bs,nf,3) int."""
+    bs = vertices.shape[0]
+    if faces_idx.dim() == 2:
+        faces_idx = faces_idx[None].expand(bs, -1, -1)
+    idx = faces_idx.long()
+    return torch.stack([vertices[b][idx[b]] for b in range(bs)], 0)
+
+
+def render_fim_wim(cam, verts, faces_idx, image_size=256):
+    """utils/nmr.py:263-278.  Returns (f2verts, fim, wim); near/far are the rasteriser defaults
+    0.1/100 (rasterize.py:8-13) because nmr.py:277 passes only three arguments."""
+    f2verts = vertices_to_faces(project_vertices(verts, cam), faces_idx)
+    fim, wim, _ = _raster.rasterize_fim_wim(f2verts.numpy(), image_size, 0.1, 100.0)
+    return f2verts, torch.from_numpy(fim), torch.from_numpy(wim)
+
+
+def encode_fim(fim, map_fn, transpose=True):
+    """utils/nmr.py:328-341: table lookup; fim == -1 wraps to the last (background) row."""
+    enc = map_fn[fim.long()]
+    return enc.permute(0, 3, 1, 2) if transpose else enc
+
+
+def cal_bc_transform(src_f2pts, dst_fims, dst_wims):
+    """utils/nmr.py:617-659.  src_f2pts (bs|1, nf, 3, 2); a single source is shared by every frame
+    of a batch (the reference runs batch 1; batching target frames over one source is this
+    build's only extension)."""
+    bs, h, w = dst_fims.shape
+    T = -2 * torch.ones((bs, h * w, 2), dtype=torch.float32)
+    for i in range(bs):
+        pts = src_f2pts[i if src_f2pts.shape[0] > 1 else 0]
+        fi = dst_fims[i].long().reshape(-1)
+        wi = dst_wims[i].reshape(-1, 3)
+        m = fi != -1
+        T[i, m] = (pts[fi[m]] * wi[m][:, :, None]).sum(dim=1)
+    return T.view(bs, h, w, 2)
+
+
+def grid_sample(x, grid, align_corners=False):
+    """F.grid_sample as called at models/imitator.py:259 and networks/generator.py:313."""
+    return F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=align_corners)
+
+
+def resize_trans(T, h, w):
+    """networks/generator.py:303-310."""
+    t = F.interpolate(T.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True)
+    return t.permute(0, 2, 3, 1)
+
+
+def morph(mask, ks, mode="erode"):
+    """utils/util.py:73-89."""
+    pad = ks // 2
+    kernel = torch.ones(1, 1, ks, ks)
+    if mode == "erode":
+        out = F.conv2d(F.pad(mask, [pad] * 4, value=1.0), kernel)
+        return (out == ks * ks).float()
+    out = F.conv2d(F.pad(mask, [pad] * 4, value=0.0), kernel)
+    return (out >= 1).float()
+
+
+# --------------------------------------------------------------------------- generator (a12-a15)
+def _in_relu(x, sd, prefix, relu=True):
+    x = F.instance_norm(x, weight=sd[prefix + ".weight"], bias=sd[prefix + ".bias"], eps=1e-5)
+    return F.relu(x) if relu else x
+
+
+def _encoder(x, sd, p, i):
+    """ResUnetGenerator.encoders[i]: conv -> IN -> ReLU (networks/generator.py:79-92)."""
+    if i == 0:
+        x = F.conv2d(x, sd["%s.encoders.0.0.weight" % p], padding=3)
+    else:
+        x = F.conv2d(x, sd["%s.encoders.%d.0.weight" % (p, i)], stride=2, padding=1)
+    return _in_relu(x, sd, "%s.encoders.%d.1" % (p, i))
+
+
+def _resblock(x, sd, p, i):
+    """ResidualBlock (networks/generator.py:8-20)."""
+    q = "%s.resnets.%d.main" % (p, i)
+    y = F.conv2d(x, sd[q + ".0.weight"], padding=1)
+    y = _in_relu(y, sd, q + ".1")
+    y = F.conv2d(y, sd[q + ".3.weight"], padding=1)
+    y = _in_relu(y, sd, q + ".4", relu=False)
+    return x + y
+
+
+def _decode(x, enc_outs, sd, p, n_down=3):
+    """ResUnetGenerator.decode (networks/generator.py:173-181)."""
+    d = x
+    for i in range(n_down):
+        d = F.conv_transpose2d(d, sd["%s.decoders.%d.0.weight" % (p, i)], stride=2, padding=1, output_padding=1)
+        d = _in_relu(d, sd, "%s.decoders.%d.1" % (p, i))
+        d = torch.cat([enc_outs[n_down - 1 - i], d], dim=1)
+        d = F.conv2d(d, sd["%s.skippers.%d.0.weight" % (p, i)], padding=1)
+        d = _in_relu(d, sd, "%s.skippers.%d.1" % (p, i))
+    return d
+
+
+def _regress(x, sd, p):
+    """ResUnetGenerator.regress (networks/generator.py:183-184); 'attetion_reg' is the reference's spelling."""
+    img = torch.tanh(F.conv2d(x, sd["%s.img_reg.0.weight" % p], padding=3))
+    mask = torch.sigmoid(F.conv2d(x, sd["%s.attetion_reg.0.weight" % p], padding=3))
+    return img, mask
+
+
+def encode_src(sd, src_inputs, n_down=3, repeat_num=6):
+    """ImpersonatorGenerator.encode_src -> ResUnetGenerator.inference (generator.py:213-214,136-147)."""
+    x = src_inputs
+    enc = []
+    for i in range(n_down + 1):
+        x = _encoder(x, sd, "src_model", i)
+        enc.append(x)
+    res = []
+    for i in range(repeat_num):
+        x = _resblock(x, sd, "src_model", i)
+        res.append(x)
+    return enc, res
+
+
+def generator_inference(sd, src_enc, src_res, tsf_inputs, T, n_down=3, repeat_num=6, align_corners=False):
+    """ImpersonatorGenerator.inference (networks/generator.py:277-301) with the Liquid Warping Block
+    transform/stn/resize_trans (generator.py:303-320)."""
+    def lwb(feat, Tfull):
+        h, w = feat.shape[2:]
+        if feat.shape[0] != Tfull.shape[0]:
+            feat = feat.expand(Tfull.shape[0], -1, -1, -1)
+        return grid_sample(feat, resize_trans(Tfull, h, w), align_corners)
+
+    x = _encoder(tsf_inputs, sd, "tsf_model", 0)
+    enc = [x]
+    for i in range(1, n_down + 1):
+        x = _encoder(x, sd, "tsf_model", i) + lwb(src_enc[i], T)
+        enc.append(x)
+    for i in range(repeat_num):
+        x = _resblock(x, sd, "tsf_model", i) + lwb(src_res[i], T)
+    return _regress(_decode(x, enc, sd, "tsf_model", n_down), sd, "tsf_model")
+
+
+def generator_swap(sd, tsf_inputs, enc12, enc21, res12, res21, T12, T21, n_down=3, repeat_num=6,
+                   align_corners=False):
+    """ImpersonatorGenerator.swap (networks/generator.py:245-275): two warps per level."""
+    def lwb(feat, Tfull):
+        h, w = feat.shape[2:]
+        if feat.shape[0] != Tfull.shape[0]:
+            feat = feat.expand(Tfull.shape[0], -1, -1, -1)
+        return grid_sample(feat, resize_trans(Tfull, h, w), align_corners)
+
+    x = _encoder(tsf_inputs, sd, "tsf_model", 0)
+    enc = [x]
+    for i in range(1, n_down + 1):
+        x = _encoder(x, sd, "tsf_model", i) + lwb(enc12[i], T12) + lwb(enc21[i], T21)
+        enc.append(x)
+    for i in range(repeat_num):
+        x = _resblock(x, sd, "tsf_model", i) + lwb(res12[i], T12) + lwb(res21[i], T21)
+    return _regress(_decode(x, enc, sd, "tsf_model", n_down), sd, "tsf_model")
+
+
+def imitator_forward(sd, src_enc, src_res, bg_img, tsf_inputs, T, align_corners=False):
+    """Imitator.forward (models/imitator.py:326-336) without front_warp."""
+    color, mask = generator_inference(sd, src_enc, src_res, tsf_inputs, T, align_corners=align_corners)
+    return mask * bg_img + (1 - mask) * color, color, mask
+
+
+def transfer_frame(src_img, src_p2verts, cam, verts, faces_idx, map_fn, image_size=256, align_corners=False):
+    """models/imitator.py:250-260 given posed vertices: render -> cond -> T -> warped source -> tsf_inputs."""
+    f2verts, fim, wim = render_fim_wim(cam, verts, faces_idx, image_size)
+    cond = encode_fim(fim, map_fn)
+    T = cal_bc_transform(src_p2verts, fim, wim)
+    img = src_img if src_img.shape[0] == T.shape[0] else src_img.expand(T.shape[0], -1, -1, -1)
+    tsf_img = grid_sample(img, T, align_corners)
+    return dict(f2verts=f2verts, fim=fim, wim=wim, cond=cond, T=T, tsf_img=tsf_img,
+                tsf_inputs=torch.cat([tsf_img, cond], dim=1))
+
+
+def source_p2verts(f2verts):
+    """models/imitator.py:105-107 (hazard H9): xy of the source face vertices with y negated."""
+    p = f2verts[:, :, :, 0:2].clone()
+    p[:, :, :, 1] *= -1
+    return p
+
+
+def state_dict_from_numpy(sd_np):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
