@@ -1,0 +1,101 @@
+"""ctypes binding of liblwg.so (include/lwg.h).  Fails loudly: no library, no product path."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_C", "liblwg.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lwg.h")
+
+LWG_OK = 0
+ERR_NAMES = {-1: "LWG_ERR_INVALID_ARG", -2: "LWG_ERR_UNSUPPORTED", -3: "LWG_ERR_WORKSPACE", -4: "LWG_ERR_HIP",
+             -5: "LWG_ERR_STATE"}
+
+
+class LwgError(RuntimeError):
+    """A liblwg entry point returned a negative status (the reference raised RuntimeError via AT_CHECK)."""
+
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "LWG_ERR"), code, message))
+        self.code = code
+
+
+_c = ctypes
+_vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+_PROTOS = {
+    "lwg_version": (_i, []),
+    "lwg_last_error": (_c.c_char_p, []),
+    "lwg_device_info": (_i, [_c.POINTER(_i), _c.POINTER(_sz), _c.c_char_p, _sz]),
+    "lwg_project_faces": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "lwg_rasterize_workspace_bytes": (_sz, [_i, _i, _i]),
+    "lwg_rasterize_fim_wim": (_i, [_vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lwg_encode_fim": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lwg_cal_bc_transform": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "lwg_grid_sample": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lwg_resize_flow": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lwg_transfer_workspace_bytes": (_sz, [_i, _i, _i]),
+    "lwg_transfer_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lwg_pack_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lwg_unpack_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lwg_generator_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
+    "lwg_generator_destroy": (None, [_vp]),
+    "lwg_generator_load_weight": (_i, [_vp, _c.c_char_p, _vp, _c.POINTER(_c.c_int64), _i]),
+    "lwg_generator_missing_weights": (_i, [_vp]),
+    "lwg_generator_num_src_features": (_i, [_vp]),
+    "lwg_generator_src_feature_shape": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
+    "lwg_generator_encode_src": (_i, [_vp, _vp, _c.POINTER(_vp), _vp]),
+    "lwg_generator_inference": (_i, [_vp, _vp, _i, _vp, _i, _c.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "lwg_generator_swap": (_i, [_vp, _vp, _i, _vp, _vp, _i, _c.POINTER(_vp), _c.POINTER(_vp), _i, _vp, _vp, _vp]),
+    "lwg_generator_peek": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "lwg_generator_profile": (_i, [_vp, _i]),
+    "lwg_generator_profile_read": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Every entry point include/lwg.h declares (used by the ABI test)."""
+    with open(HEADER_PATH) as fh:
+        text = fh.read()
+    return sorted(set(re.findall(r"LWG_API[^;]*?\b(lwg_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "liblwg.so is missing (%s). Build it with `python -m impersonator_amd.build` (needs hipcc); "
+            "there is no CPU fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != LWG_OK:
+        raise LwgError(rc, load().lwg_last_error().decode(errors="replace"))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,78 @@
+"""Builds liblwg.so (the C-ABI HIP library) in-tree for gfx950 with hipcc.
+
+    python -m impersonator_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+The .so lands in impersonator_amd/_C/ (git-ignored, but shipped to the GPU box by gpurun).
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "_C")
+LIB = os.path.join(OUT_DIR, "liblwg.so")
+ARCH = "gfx950"
+
+# (source, extra flags).  raster/warp keep the reference's float expression order: no fused multiply-add.
+SOURCES = [
+    ("capi.hip", []),
+    ("raster.hip", ["-ffp-contract=off"]),
+    ("warp.hip", ["-ffp-contract=off"]),
+    ("conv.hip", []),
+    ("generator.hip", []),
+]
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: liblwg cannot be built")
+
+
+def _digest():
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in sorted(os.listdir(root)):
+            with open(os.path.join(root, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(COMMON).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    stamp = os.path.join(OUT_DIR, "liblwg.sha256")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src, extra in SOURCES:
+        obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(dig + "\n")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,426 @@
+// conv.hip -- the generator's device kernels for gfx950 (MI355X, CDNA4).
+//
+// Replaces what PyTorch/cuDNN executes for the reference's ResUnetGenerator (networks/generator.py:8-20,
+// 68-184): Conv2d 7x7/3x3 (stride 1/2), ConvTranspose2d 3x3 s2, InstanceNorm2d(affine), ReLU, the residual
+// add, the Liquid Warping Block add (generator.py:283-295,303-320), torch.cat and the tanh/sigmoid heads.
+//
+// Layout: activations NHWC fp32 (channel-contiguous => the im2col row of a tap is one contiguous run).
+//
+// conv_igemm_f32: implicit GEMM on the exact-fp32 matrix cores, v_mfma_f32_32x32x2_f32
+//   (64 FLOP/clk/SIMD, 157.3 TFLOP/s chip peak; results are an fp32 fmaf chain, no reduced precision).
+//   Workgroup tile 128 pixels x BN channels x 32 reduction, 4 waves, each wave a 32*WM x 32*WN block of
+//   32x32 MFMA tiles.  Both operands are staged in LDS row-major with a 36-float row pitch and read with
+//   ds_read_b128: lanes 0-31 fetch k..k+3 and lanes 32-63 fetch k+4..k+7 of their row, which feeds four
+//   back-to-back MFMAs (k-pairs {k+j, k+4+j}); pitch 36 makes the 16-lane b128 groups hit 16 distinct
+//   16-byte slots (bank-conflict free).  Global->register prefetch of stage t+1 is issued before the MFMAs
+//   of stage t and written to the other LDS buffer afterwards: one barrier per stage.
+//   Epilogue: raw output store + per-tile InstanceNorm statistics (mean, M2 over the tile's 128 pixels,
+//   Chan-combinable, deterministic -- no atomics).
+// in_finalize : combines tile statistics per (image, channel) -> scale/shift.
+// apply       : y = act(x*scale+shift) (+ residual) (+ bilinear-warped source features), float4 over
+//               channels, writes straight into channel slices of the decoder's concat buffers (torch.cat is free).
+// heads       : direct 7x7 conv 64->3+1 on the vector ALU (N=4 outputs cannot feed a 32-wide MFMA tile),
+//               InstanceNorm+ReLU of its input folded into the halo load, tanh/sigmoid/blend fused.
+#include "conv.h"
+#include "sample.h"
+
+namespace lwg {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = kConvBM;
+constexpr int BK = kConvBK;
+constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B alignment, spreads banks)
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
+{
+    constexpr int WAVES_N = BN / (32 * WN);
+    constexpr int WAVES_M = BM / (32 * WM);
+    static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
+    constexpr int B_ROWS = BN / 32;  // float4 loads per thread for the weight tile
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                  // [2][BM][LDK]
+    float *Bs = smem + 2 * BM * LDK;   // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+
+    const ConvPhase ph = a.ph[blockIdx.z];
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int hw_m = a.Hm * a.Wm;
+    const int img = m0 / hw_m;         // a tile never straddles two images (hw_m % BM == 0)
+    const int rem0 = m0 - img * hw_m;
+
+    // ---- loader geometry: thread -> (row = tid/8 + 32*j, 16-byte column kq = tid%8)
+    const int lrow = tid >> 3, kq = tid & 7;
+    int hi0[4], wi0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rem = rem0 + lrow + 32 * j;
+        const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
+        hi0[j] = hm * a.stride - a.pad;
+        wi0[j] = wm * a.stride - a.pad;
+    }
+    const float *xin = a.x + (size_t)img * a.H * a.W * a.ldx;
+    const float *wt = a.w + ph.w_off + (size_t)(n0 + lrow) * ph.Kpad + kq * 4;
+    const int cin_mask = a.Cin - 1;
+
+    float4 ra[4], rb[B_ROWS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < B_ROWS; ++j) rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_stage = [&](int kt) {
+        const int kg = kt * BK + kq * 4;
+        const int tap = kg >> a.cin_log2;
+        const int ci = kg & cin_mask;
+        const int kh = tap / ph.KW, kw = tap - kh * ph.KW;
+        const bool tap_ok = tap < ph.ntaps;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = tap_ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            ra[j] = ok ? *reinterpret_cast<const float4 *>(xin + (size_t)(hi * a.W + wi) * a.ldx + ci)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < B_ROWS; ++j)
+            rb[j] = *reinterpret_cast<const float4 *>(wt + (size_t)(32 * j) * ph.Kpad + kt * BK);
+    };
+    auto store_stage = [&](int buf) {
+        float *ad = As + buf * BM * LDK + lrow * LDK + kq * 4;
+        float *bd = Bs + buf * BN * LDK + lrow * LDK + kq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(ad + 32 * j * LDK) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_ROWS; ++j) *reinterpret_cast<float4 *>(bd + 32 * j * LDK) = rb[j];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag = (lane & 31) * LDK + 4 * (lane >> 5);
+    const int a_frag = (wave_m * 32 * WM) * LDK + frag;
+    const int b_frag = (wave_n * 32 * WN) * LDK + frag;
+
+    // software pipeline with a single call site per stage function (kt = -1 is the prologue fill)
+    const int nk = ph.Kpad / BK;
+    for (int kt = -1; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_stage(kt + 1);
+        if (kt >= 0) {
+            const float *Ab = As + buf * BM * LDK + a_frag;
+            const float *Bb = Bs + buf * BN * LDK + b_frag;
+#pragma unroll
+            for (int k8 = 0; k8 < BK / 8; ++k8) {
+                float4 af[WM], bf[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4 *>(Ab + i * 32 * LDK + k8 * 8);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const float4 *>(Bb + j * 32 * LDK + k8 * 8);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (kt + 1 < nk) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+            const int rem = rem0 + row;
+            const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
+            const size_t opix = ((size_t)img * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
+            float *yo = a.y + opix * a.ldy + n0 + wave_n * 32 * WN + col;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) yo[j * 32] = acc[i][j][r];
+        }
+
+    // ---- epilogue 2: per-tile InstanceNorm statistics (mean, M2) per channel over the tile's 128 pixels
+    if (a.partials) {
+        float2 *red = reinterpret_cast<float2 *>(smem);  // [WAVES_M][BN], LDS is free again after the last barrier
+        constexpr float kInvRows = 1.f / (32 * WM);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+            s += __shfl_xor(s, 32);
+            const float mu = s * kInvRows;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[i][j][r] - mu;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 32);
+            if (lane < 32) red[wave_m * BN + wave_n * 32 * WN + j * 32 + col] = make_float2(mu, q);
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float mean = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) mean += red[w * BN + tid].x;
+            mean *= 1.f / WAVES_M;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) {
+                const float2 p = red[w * BN + tid];
+                const float d = p.x - mean;
+                m2 += p.y + (32 * WM) * d * d;
+            }
+            a.partials[((size_t)blockIdx.z * a.mtiles + blockIdx.x) * a.Cout + n0 + tid] = make_float2(mean, m2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid (C/64, N), 256 threads = 4 tile slices x 64 channels
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float2 *__restrict__ partials, int nphase, int mtiles,
+                                                          int tiles_per_img, int C, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps,
+                                                          float2 *__restrict__ scale_shift)
+{
+    __shared__ double sh[3][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    const int n = blockIdx.y;
+    double sm = 0., sq = 0., m2 = 0.;
+    if (c < C) {
+        for (int p = 0; p < nphase; ++p)
+            for (int t = slice; t < tiles_per_img; t += 4) {
+                const float2 v = partials[((size_t)p * mtiles + (size_t)n * tiles_per_img + t) * C + c];
+                sm += v.x;
+                sq += (double)v.x * v.x;
+                m2 += v.y;
+            }
+    }
+    sh[0][slice][threadIdx.x & 63] = sm;
+    sh[1][slice][threadIdx.x & 63] = sq;
+    sh[2][slice][threadIdx.x & 63] = m2;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        const int l = threadIdx.x;
+        const double cnt = (double)nphase * tiles_per_img;
+        sm = sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l];
+        sq = sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l];
+        m2 = sh[2][0][l] + sh[2][1][l] + sh[2][2][l] + sh[2][3][l];
+        const double mean = sm / cnt;
+        // Chan et al.: M2_total = sum M2_i + n_i * sum (mean_i - mean)^2, every tile holds BM samples
+        double between = sq - cnt * mean * mean;
+        if (between < 0.) between = 0.;
+        const double var = (m2 + BM * between) / (cnt * BM);  // biased, as InstanceNorm2d uses
+        const double inv = 1.0 / sqrt(var + (double)eps);
+        const float sc = (float)(gamma[c] * inv);
+        scale_shift[(size_t)n * C + c] = make_float2(sc, (float)(beta[c] - mean * gamma[c] * inv));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void fma4(float4 &acc, const float4 v, float w)
+{
+    acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+}
+
+__global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a)
+{
+    const int c4n = a.C >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.N * a.H * a.W * c4n;
+    if (i >= total) return;
+    const long pix = i / c4n;
+    const int c = (int)(i - pix * c4n) * 4;
+    const int hw = a.H * a.W;
+    const int n = (int)(pix / hw);
+    const int pn = (int)(pix - (long)n * hw);
+
+    const float4 v = ld4(a.raw + pix * a.C + c);
+    const float4 s01 = ld4(reinterpret_cast<const float *>(a.scale_shift + (size_t)n * a.C + c));
+    const float4 s23 = ld4(reinterpret_cast<const float *>(a.scale_shift + (size_t)n * a.C + c + 2));
+    float4 y;
+    y.x = v.x * s01.x + s01.y;
+    y.y = v.y * s01.z + s01.w;
+    y.z = v.z * s23.x + s23.y;
+    y.w = v.w * s23.z + s23.w;
+    if (a.relu) {
+        y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+    }
+    if (a.res) {
+        const float4 r = ld4(a.res + pix * a.ld_res + c);
+        y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+    }
+    for (int k = 0; k < a.nwarp; ++k) {
+        const float2 g = *reinterpret_cast<const float2 *>(a.warp_T[k] + pix * 2);
+        const GridTaps t = grid_taps(g.x, g.y, a.W, a.H, a.align_corners);
+        const float *src = a.warp_src[k] + (size_t)(a.warp_n[k] > 1 ? n : 0) * hw * a.C + c;
+        float4 wsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t.vnw) fma4(wsum, ld4(src + (size_t)(t.y0 * a.W + t.x0) * a.C), t.wnw);
+        if (t.vne) fma4(wsum, ld4(src + (size_t)(t.y0 * a.W + t.x0 + 1) * a.C), t.wne);
+        if (t.vsw) fma4(wsum, ld4(src + (size_t)((t.y0 + 1) * a.W + t.x0) * a.C), t.wsw);
+        if (t.vse) fma4(wsum, ld4(src + (size_t)((t.y0 + 1) * a.W + t.x0 + 1) * a.C), t.wse);
+        y.x += wsum.x; y.y += wsum.y; y.z += wsum.z; y.w += wsum.w;
+    }
+    (void)pn;
+    *reinterpret_cast<float4 *>(a.dst + pix * a.ld_dst + c) = y;
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int HT_ROWS = 8, HT_COLS = 32;                // output tile per workgroup
+constexpr int HH = HT_ROWS + 6, HWD = HT_COLS + 6;      // halo tile
+constexpr int HPITCH = 20;                              // floats per halo pixel (16 channels + pad: conflict-free b128)
+
+__global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float halo[HH * HWD * HPITCH];
+    const int tid = threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
+    const int n = blockIdx.z;
+    const int y0 = blockIdx.y * HT_ROWS, x0 = blockIdx.x * HT_COLS;
+    const float *xin = a.x + (size_t)n * a.H * a.W * 64;
+    const float2 *ss = a.scale_shift + (size_t)n * 64;
+
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int chunk = 0; chunk < 4; ++chunk) {
+        __syncthreads();
+        for (int i = tid; i < HH * HWD * 4; i += 256) {
+            const int pix = i >> 2, q = i & 3;
+            const int hy = pix / HWD, hx = pix - hy * HWD;
+            const int gy = y0 - 3 + hy, gx = x0 - 3 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+                const int c = chunk * 16 + q * 4;
+                v = ld4(xin + ((size_t)gy * a.W + gx) * 64 + c);
+                const float4 s01 = ld4(reinterpret_cast<const float *>(ss + c));
+                const float4 s23 = ld4(reinterpret_cast<const float *>(ss + c + 2));
+                v.x = fmaxf(v.x * s01.x + s01.y, 0.f);
+                v.y = fmaxf(v.y * s01.z + s01.w, 0.f);
+                v.z = fmaxf(v.z * s23.x + s23.y, 0.f);
+                v.w = fmaxf(v.w * s23.z + s23.w, 0.f);
+            }
+            *reinterpret_cast<float4 *>(halo + pix * HPITCH + q * 4) = v;
+        }
+        __syncthreads();
+        for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const float *lp = halo + ((ty + ky) * HWD + tx + kx) * HPITCH;
+                const float *wp = a.wh + ((size_t)(ky * 7 + kx) * 64 + chunk * 16) * 4;  // wave-uniform: scalar loads
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = ld4(lp + q * 4);
+                    const float *w = wp + q * 16;
+                    acc0 += v.x * w[0];  acc1 += v.x * w[1];  acc2 += v.x * w[2];  acc3 += v.x * w[3];
+                    acc0 += v.y * w[4];  acc1 += v.y * w[5];  acc2 += v.y * w[6];  acc3 += v.y * w[7];
+                    acc0 += v.z * w[8];  acc1 += v.z * w[9];  acc2 += v.z * w[10]; acc3 += v.z * w[11];
+                    acc0 += v.w * w[12]; acc1 += v.w * w[13]; acc2 += v.w * w[14]; acc3 += v.w * w[15];
+                }
+            }
+        }
+    }
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy >= a.H || ox >= a.W) return;
+    const size_t hw = (size_t)a.H * a.W, p = (size_t)oy * a.W + ox;
+    const float col[3] = {tanhf(acc0), tanhf(acc1), tanhf(acc2)};
+    const float m = 1.f / (1.f + expf(-acc3));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (a.color) a.color[((size_t)n * 3 + c) * hw + p] = col[c];
+        if (a.pred) {
+            const float b = a.bg[((size_t)(a.bg_bs > 1 ? n : 0) * 3 + c) * hw + p];
+            a.pred[((size_t)n * 3 + c) * hw + p] = m * b + (1.f - m) * col[c];
+        }
+    }
+    if (a.mask) a.mask[(size_t)n * hw + p] = m;
+}
+
+}  // namespace
+
+int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st)
+{
+    if (a.Cout % bn != 0 || (bn != 64 && bn != 128))
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cout=%d not a multiple of the %d-channel tile", a.Cout, bn);
+    if ((a.Hm * a.Wm) % BM != 0 || a.mtiles * BM != a.N * a.Hm * a.Wm)
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: %dx%d output grid per image is not a multiple of %d pixels", a.Hm, a.Wm, BM);
+    if ((1 << a.cin_log2) != a.Cin || a.Cin < 4 || (a.ldx & 3))
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d must be a power of two >= 4 with a 16-byte aligned pixel stride", a.Cin);
+    for (int p = 0; p < a.nphase; ++p)
+        if (a.ph[p].Kpad % BK != 0 || a.ph[p].Kpad < a.ph[p].ntaps * a.Cin)
+            LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: bad padded K=%d for %d taps x %d channels", a.ph[p].Kpad, a.ph[p].ntaps, a.Cin);
+    const dim3 grid(a.mtiles, a.Cout / bn, a.nphase);
+    const size_t lds = (size_t)2 * (BM + bn) * LDK * sizeof(float);
+    // the 128-channel tile needs 72 KiB of LDS: above the 64 KiB default, well inside gfx950's 160 KiB per CU
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + 64) * LDK * (int)sizeof(float)));
+        LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<128, 2, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + 128) * LDK * (int)sizeof(float)));
+        lds_opt_in = true;
+    }
+    if (bn == 64) {
+        conv_igemm_f32<64, 1, 2><<<grid, 256, lds, st>>>(a);
+    } else {
+        conv_igemm_f32<128, 2, 2><<<grid, 256, lds, st>>>(a);
+    }
+    LWG_LAUNCH_CHECK("conv_igemm_f32");
+    return LWG_OK;
+}
+
+int launch_in_finalize(const float2 *partials, int nphase, int mtiles, int N, int C, const float *gamma,
+                       const float *beta, float eps, float2 *scale_shift, hipStream_t st)
+{
+    if (mtiles % N != 0) LWG_FAIL(LWG_ERR_UNSUPPORTED, "in_finalize: %d tiles do not split over %d images", mtiles, N);
+    const dim3 grid(ceil_div(C, 64), N);
+    in_finalize_kernel<<<grid, 256, 0, st>>>(partials, nphase, mtiles, mtiles / N, C, gamma, beta, eps, scale_shift);
+    LWG_LAUNCH_CHECK("in_finalize_kernel");
+    return LWG_OK;
+}
+
+int launch_apply(const ApplyArgs &a, hipStream_t st)
+{
+    if ((a.C & 3) || (a.ld_dst & 3) || (a.res && (a.ld_res & 3)))
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "apply: channel counts/strides must be multiples of 4 (C=%d)", a.C);
+    const long total = (long)a.N * a.H * a.W * (a.C >> 2);
+    apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(a);
+    LWG_LAUNCH_CHECK("apply_kernel");
+    return LWG_OK;
+}
+
+int launch_heads(const HeadsArgs &a, hipStream_t st)
+{
+    if (a.pred && !a.bg) LWG_FAIL(LWG_ERR_INVALID_ARG, "heads: pred requested without a background image");
+    const dim3 grid(ceil_div(a.W, HT_COLS), ceil_div(a.H, HT_ROWS), a.N);
+    heads_kernel<<<grid, 256, 0, st>>>(a);
+    LWG_LAUNCH_CHECK("heads_kernel");
+    return LWG_OK;
+}
+
+}  // namespace lwg

@@ -1,0 +1,753 @@
+// generator.hip -- host side of the lwg_generator handle: weight re-layout, scratch, layer schedule.
+//
+// Mirrors the data flow of the reference's ImpersonatorGenerator (networks/generator.py:187-320):
+//   encode_src : src_model encoders + residual blocks, every level kept      (generator.py:136-147,213-214)
+//   inference  : tsf_model with the Liquid Warping Block add per level        (generator.py:277-301)
+//   swap       : the two-source variant                                       (generator.py:245-275)
+// Every layer is  conv_igemm (raw output + tile statistics) -> in_finalize -> apply  (see conv.hip).
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "conv.h"
+
+namespace lwg {
+namespace {
+
+constexpr int kNDown = 3;
+constexpr float kInEps = 1e-5f;  // nn.InstanceNorm2d default
+
+int ilog2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+struct Layer {
+    // geometry
+    int cin = 0, cin_pad = 0, cout = 0, k = 0, stride = 1, pad = 0;
+    bool transposed = false, has_norm = true;
+    // device weights: conv [cout][kpad]; transposed: four phase matrices back to back
+    float *w = nullptr;
+    ConvPhase ph[4];
+    int nphase = 1;
+    float *gamma = nullptr, *beta = nullptr;
+    bool got_w = false, got_g = false, got_b = false;
+    size_t w_floats = 0;
+};
+
+struct StreamNet {
+    Layer enc[kNDown + 1];
+    std::vector<Layer> res;  // 2 per block
+    Layer dec[kNDown], skip[kNDown];
+    float *heads_w = nullptr;  // [49][64][4]
+    bool got_img = false, got_att = false;
+};
+
+}  // namespace
+}  // namespace lwg
+
+using namespace lwg;
+
+struct lwg_generator {
+    int src_dim, tsf_dim, cd, repeat, is, max_batch;
+    StreamNet src, tsf;
+    int ignored_keys = 0;
+
+    // scratch (sized for max_batch)
+    float *x0 = nullptr;              // (bs,is,is,8) packed input
+    float *raw = nullptr;             // largest raw conv output
+    float *cat[kNDown] = {};          // cat[l]: (bs, is>>l, is>>l, 2*cd<<l): [skip | decoder]
+    float *trunk[3] = {};             // (bs, is/8, is/8, 8cd) ping/pong/mid
+    float *sk[kNDown] = {};           // skipper outputs sk[i] at level (2-i): sk[0] 64^2x4cd ... (last one stays raw)
+    float *tscale[2][kNDown] = {};    // resized flows per level (two sets for swap)
+    float2 *partials = nullptr;
+    float2 *ss = nullptr;             // scale/shift [max_batch][8cd]
+    int trunk_out = 0;                // which trunk buffer holds the residual trunk's output
+
+    // profiling of the implicit-GEMM kernel
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_flops = 0.0;
+    int prof_launches = 0;
+};
+
+namespace lwg {
+namespace {
+
+int dev_alloc(float **p, size_t floats)
+{
+    LWG_HIP(hipMalloc(reinterpret_cast<void **>(p), floats * sizeof(float)));
+    return LWG_OK;
+}
+
+void init_conv(Layer &L, int cin, int cout, int k, int stride, int pad)
+{
+    L.cin = cin;
+    L.cin_pad = cin < 8 ? 8 : cin;
+    L.cout = cout;
+    L.k = k;
+    L.stride = stride;
+    L.pad = pad;
+    L.transposed = false;
+    L.nphase = 1;
+    ConvPhase &p = L.ph[0];
+    p.KH = p.KW = k;
+    p.ntaps = k * k;
+    p.Kpad = (int)align_up((size_t)p.ntaps * L.cin_pad, kConvBK);
+    p.w_off = 0;
+    p.oy0 = p.ox0 = 0;
+    L.w_floats = (size_t)cout * p.Kpad;
+}
+
+// ConvTranspose2d(k=3, s=2, p=1, output_padding=1): out(2i+py, 2j+px) only sees taps whose parity matches;
+// phase (py,px) is a stride-1 correlation with (1+py) x (1+px) taps reading in(i+ty, j+tx).
+void init_convT(Layer &L, int cin, int cout)
+{
+    L.cin = L.cin_pad = cin;
+    L.cout = cout;
+    L.k = 3;
+    L.stride = 1;
+    L.pad = 0;
+    L.transposed = true;
+    L.nphase = 4;
+    long off = 0;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            ConvPhase &p = L.ph[py * 2 + px];
+            p.KH = 1 + py;
+            p.KW = 1 + px;
+            p.ntaps = p.KH * p.KW;
+            p.Kpad = (int)align_up((size_t)p.ntaps * cin, kConvBK);
+            p.w_off = off;
+            p.oy0 = py;
+            p.ox0 = px;
+            off += (long)cout * p.Kpad;
+        }
+    L.w_floats = (size_t)off;
+}
+
+int alloc_layer(Layer &L)
+{
+    int rc = dev_alloc(&L.w, L.w_floats);
+    if (rc != LWG_OK) return rc;
+    LWG_HIP(hipMemset(L.w, 0, L.w_floats * sizeof(float)));
+    if (L.has_norm) {
+        if ((rc = dev_alloc(&L.gamma, L.cout)) != LWG_OK) return rc;
+        if ((rc = dev_alloc(&L.beta, L.cout)) != LWG_OK) return rc;
+    }
+    return LWG_OK;
+}
+
+void free_layer(Layer &L)
+{
+    if (L.w) (void)hipFree(L.w);
+    if (L.gamma) (void)hipFree(L.gamma);
+    if (L.beta) (void)hipFree(L.beta);
+    L.w = L.gamma = L.beta = nullptr;
+}
+
+int build_stream(StreamNet &s, int in_dim, int cd, int repeat, bool with_decoder)
+{
+    init_conv(s.enc[0], in_dim, cd, 7, 1, 3);
+    for (int i = 1; i <= kNDown; ++i) init_conv(s.enc[i], cd << (i - 1), cd << i, 3, 2, 1);
+    const int ct = cd << kNDown;
+    s.res.resize(2 * repeat);
+    for (auto &L : s.res) init_conv(L, ct, ct, 3, 1, 1);
+    int rc;
+    for (int i = 0; i <= kNDown; ++i)
+        if ((rc = alloc_layer(s.enc[i])) != LWG_OK) return rc;
+    for (auto &L : s.res)
+        if ((rc = alloc_layer(L)) != LWG_OK) return rc;
+    if (with_decoder) {
+        int cur = ct;
+        for (int i = 0; i < kNDown; ++i) {
+            init_convT(s.dec[i], cur, cur / 2);
+            init_conv(s.skip[i], cur, cur / 2, 3, 1, 1);
+            if ((rc = alloc_layer(s.dec[i])) != LWG_OK) return rc;
+            if ((rc = alloc_layer(s.skip[i])) != LWG_OK) return rc;
+            cur /= 2;
+        }
+        if ((rc = dev_alloc(&s.heads_w, 49 * 64 * 4)) != LWG_OK) return rc;
+        LWG_HIP(hipMemset(s.heads_w, 0, 49 * 64 * 4 * sizeof(float)));
+    }
+    return LWG_OK;
+}
+
+void free_stream(StreamNet &s)
+{
+    for (auto &L : s.enc) free_layer(L);
+    for (auto &L : s.res) free_layer(L);
+    for (auto &L : s.dec) free_layer(L);
+    for (auto &L : s.skip) free_layer(L);
+    if (s.heads_w) (void)hipFree(s.heads_w);
+    s.heads_w = nullptr;
+}
+
+// PyTorch Conv2d weight (cout, cin, k, k) -> [cout][(kh*k+kw)*cin_pad + ci], zero padded to Kpad
+int upload_conv(Layer &L, const float *w, const int64_t *shape, int ndim, const char *key)
+{
+    if (ndim != 4 || shape[0] != L.cout || shape[1] != L.cin || shape[2] != L.k || shape[3] != L.k)
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "%s: expected shape (%d,%d,%d,%d)", key, L.cout, L.cin, L.k, L.k);
+    const ConvPhase &p = L.ph[0];
+    std::vector<float> h((size_t)L.cout * p.Kpad, 0.f);
+    for (int co = 0; co < L.cout; ++co)
+        for (int ci = 0; ci < L.cin; ++ci)
+            for (int t = 0; t < L.k * L.k; ++t)
+                h[(size_t)co * p.Kpad + (size_t)t * L.cin_pad + ci] = w[((size_t)co * L.cin + ci) * L.k * L.k + t];
+    LWG_HIP(hipMemcpy(L.w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    L.got_w = true;
+    return LWG_OK;
+}
+
+// PyTorch ConvTranspose2d weight (cin, cout, 3, 3); out(oy) = sum in(iy) w[ky] with oy = 2*iy - 1 + ky.
+// Phase parity 0 uses ky = 1 (iy = i); parity 1 uses ky = 2 (iy = i, tap offset 0) and ky = 0 (iy = i+1, offset 1).
+int upload_convT(Layer &L, const float *w, const int64_t *shape, int ndim, const char *key)
+{
+    if (ndim != 4 || shape[0] != L.cin || shape[1] != L.cout || shape[2] != 3 || shape[3] != 3)
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "%s: expected shape (%d,%d,3,3)", key, L.cin, L.cout);
+    std::vector<float> h(L.w_floats, 0.f);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const ConvPhase &p = L.ph[py * 2 + px];
+            for (int ty = 0; ty < p.KH; ++ty)
+                for (int tx = 0; tx < p.KW; ++tx) {
+                    const int ky = py == 0 ? 1 : (ty == 0 ? 2 : 0);
+                    const int kx = px == 0 ? 1 : (tx == 0 ? 2 : 0);
+                    const int t = ty * p.KW + tx;
+                    for (int co = 0; co < L.cout; ++co)
+                        for (int ci = 0; ci < L.cin; ++ci)
+                            h[(size_t)p.w_off + (size_t)co * p.Kpad + (size_t)t * L.cin + ci] =
+                                w[(((size_t)ci * L.cout + co) * 3 + ky) * 3 + kx];
+                }
+        }
+    LWG_HIP(hipMemcpy(L.w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    L.got_w = true;
+    return LWG_OK;
+}
+
+int upload_vec(float *dst, int n, bool *flag, const float *src, const int64_t *shape, int ndim, const char *key)
+{
+    if (ndim != 1 || shape[0] != n) LWG_FAIL(LWG_ERR_INVALID_ARG, "%s: expected shape (%d,)", key, n);
+    LWG_HIP(hipMemcpy(dst, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    *flag = true;
+    return LWG_OK;
+}
+
+// heads: img_reg (3,64,7,7) -> channels 0..2, attetion_reg (1,64,7,7) -> channel 3 of [49][64][4]
+int upload_head(StreamNet &s, const float *w, const int64_t *shape, int ndim, int c0, int nc, int cd, const char *key)
+{
+    if (ndim != 4 || shape[0] != nc || shape[1] != cd || shape[2] != 7 || shape[3] != 7)
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "%s: expected shape (%d,%d,7,7)", key, nc, cd);
+    std::vector<float> h(49 * 64 * 4);
+    LWG_HIP(hipMemcpy(h.data(), s.heads_w, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int c = 0; c < nc; ++c)
+        for (int ci = 0; ci < cd; ++ci)
+            for (int t = 0; t < 49; ++t) h[((size_t)t * 64 + ci) * 4 + c0 + c] = w[((size_t)c * cd + ci) * 49 + t];
+    LWG_HIP(hipMemcpy(s.heads_w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return LWG_OK;
+}
+
+int missing_in(const StreamNet &s, bool with_decoder)
+{
+    int m = 0;
+    auto need = [&](const Layer &L) { m += !L.got_w + (L.has_norm ? (!L.got_g + !L.got_b) : 0); };
+    for (auto &L : s.enc) need(L);
+    for (auto &L : s.res) need(L);
+    if (with_decoder) {
+        for (auto &L : s.dec) need(L);
+        for (auto &L : s.skip) need(L);
+        m += !s.got_img + !s.got_att;
+    }
+    return m;
+}
+
+// ---- profiling helpers
+int prof_begin(lwg_generator *g, hipStream_t st, hipEvent_t *e1)
+{
+    if (g->ev_used + 2 > g->ev_pool.size()) {
+        for (int i = 0; i < 64; ++i) {
+            hipEvent_t e;
+            LWG_HIP(hipEventCreate(&e));
+            g->ev_pool.push_back(e);
+        }
+    }
+    LWG_HIP(hipEventRecord(g->ev_pool[g->ev_used], st));
+    *e1 = g->ev_pool[g->ev_used + 1];
+    g->ev_used += 2;
+    return LWG_OK;
+}
+
+// one normalised conv layer: conv -> statistics -> (caller applies)
+int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, int H, int W, float *raw,
+             hipStream_t st)
+{
+    ConvArgs a = {};
+    a.x = x;
+    a.ldx = ldx;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.Cin = L.cin_pad;
+    a.cin_log2 = ilog2(L.cin_pad);
+    a.w = L.w;
+    a.y = raw;
+    a.ldy = L.cout;
+    a.Cout = L.cout;
+    a.nphase = L.nphase;
+    for (int p = 0; p < L.nphase; ++p) a.ph[p] = L.ph[p];
+    if (L.transposed) {
+        a.Hm = H; a.Wm = W; a.stride = 1; a.pad = 0; a.os = 2; a.Ho = 2 * H; a.Wo = 2 * W;
+    } else {
+        a.Hm = (H + 2 * L.pad - L.k) / L.stride + 1;
+        a.Wm = (W + 2 * L.pad - L.k) / L.stride + 1;
+        a.stride = L.stride; a.pad = L.pad; a.os = 1; a.Ho = a.Hm; a.Wo = a.Wm;
+    }
+    a.mtiles = N * a.Hm * a.Wm / kConvBM;
+    a.partials = L.has_norm ? g->partials : nullptr;
+    // tile width: 64 channels keeps >= 2 workgroups per CU on the 32x32 trunk (batch 8: 512 tiles on 256 CUs)
+    const long tiles128 = (long)a.mtiles * (L.cout / 128 > 0 ? L.cout / 128 : 1) * L.nphase;
+    const int bn = (L.cout % 128 == 0 && tiles128 >= 2 * 256) ? 128 : 64;
+
+    hipEvent_t e1 = nullptr;
+    if (g->profile) {
+        const int rc = prof_begin(g, st, &e1);
+        if (rc != LWG_OK) return rc;
+    }
+    int rc = launch_conv_igemm(a, bn, st);
+    if (rc != LWG_OK) return rc;
+    if (g->profile) {
+        LWG_HIP(hipEventRecord(e1, st));
+        double k_alg = 0;
+        for (int p = 0; p < L.nphase; ++p) k_alg += (double)L.ph[p].ntaps * L.cin;
+        g->prof_flops += 2.0 * N * a.Hm * a.Wm * (double)L.cout * k_alg;
+        g->prof_launches += 1;
+    }
+    if (L.has_norm) {
+        rc = launch_in_finalize(g->partials, L.nphase, a.mtiles, N, L.cout, L.gamma, L.beta, kInEps, g->ss, st);
+        if (rc != LWG_OK) return rc;
+    }
+    return LWG_OK;
+}
+
+struct Warp {
+    const float *src = nullptr;  // NHWC (1,H,W,C)
+    const float *T = nullptr;    // resized flow (N,H,W,2)
+};
+
+int run_apply(lwg_generator *g, int N, int H, int W, int C, bool relu, float *dst, int ld_dst, const float *res,
+              int ld_res, const Warp *warps, int nwarp, int align, hipStream_t st)
+{
+    ApplyArgs a = {};
+    a.raw = g->raw;
+    a.C = C;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.scale_shift = g->ss;
+    a.relu = relu;
+    a.dst = dst;
+    a.ld_dst = ld_dst;
+    a.res = res;
+    a.ld_res = ld_res;
+    a.nwarp = nwarp;
+    for (int k = 0; k < nwarp; ++k) {
+        a.warp_src[k] = warps[k].src;
+        a.warp_n[k] = 1;
+        a.warp_T[k] = warps[k].T;
+    }
+    a.align_corners = align;
+    return launch_apply(a, st);
+}
+
+int pack_input(lwg_generator *g, const float *x, int layout, int N, int C, hipStream_t st, const float **out)
+{
+    if (layout == 1) {
+        *out = x;
+        return LWG_OK;
+    }
+    if (layout != 0) LWG_FAIL(LWG_ERR_INVALID_ARG, "layout must be 0 (NCHW) or 1 (NHWC8)");
+    const int rc = lwg_pack_nhwc(x, N, C, g->is, g->is, 8, g->x0, st);
+    *out = g->x0;
+    return rc;
+}
+
+// encoder level `lvl` of one stream; dst/ld_dst is where the activated output goes
+int run_encoder(lwg_generator *g, const StreamNet &s, int lvl, const float *x, int ldx, int N, float *dst, int ld_dst,
+                const Warp *warps, int nwarp, int align, hipStream_t st)
+{
+    const Layer &L = s.enc[lvl];
+    const int Hin = lvl == 0 ? g->is : g->is >> (lvl - 1);
+    int rc = run_conv(g, L, x, ldx, N, Hin, Hin, g->raw, st);
+    if (rc != LWG_OK) return rc;
+    const int Ho = g->is >> lvl;
+    return run_apply(g, N, Ho, Ho, L.cout, true, dst, ld_dst, nullptr, 0, warps, nwarp, align, st);
+}
+
+// ResidualBlock i (generator.py:8-20): x + IN(conv(ReLU(IN(conv(x))))) [+ warps]; xin -> xout
+int run_resblock(lwg_generator *g, const StreamNet &s, int i, const float *xin, float *xout, int N,
+                 const Warp *warps, int nwarp, int align, hipStream_t st)
+{
+    const int h = g->is >> kNDown, C = g->cd << kNDown;
+    int rc = run_conv(g, s.res[2 * i], xin, C, N, h, h, g->raw, st);
+    if (rc != LWG_OK) return rc;
+    if ((rc = run_apply(g, N, h, h, C, true, g->trunk[2], C, nullptr, 0, nullptr, 0, align, st)) != LWG_OK) return rc;
+    if ((rc = run_conv(g, s.res[2 * i + 1], g->trunk[2], C, N, h, h, g->raw, st)) != LWG_OK) return rc;
+    return run_apply(g, N, h, h, C, false, xout, C, xin, C, warps, nwarp, align, st);
+}
+
+int check_ready(const lwg_generator *g, int bs)
+{
+    if (!g) LWG_FAIL(LWG_ERR_INVALID_ARG, "NULL generator handle");
+    if (bs <= 0 || bs > g->max_batch) LWG_FAIL(LWG_ERR_STATE, "batch %d outside 1..max_batch=%d", bs, g->max_batch);
+    const int m = missing_in(g->src, false) + missing_in(g->tsf, true);
+    if (m) LWG_FAIL(LWG_ERR_STATE, "%d weight tensors have not been loaded", m);
+    return LWG_OK;
+}
+
+// the tsf stream shared by inference (one warp set) and swap (two)
+int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *const T[2],
+            const float *const *feats[2], int nsets, int bs, int align, float *color, float *mask, const float *bg,
+            int bg_bs, float *pred, hipStream_t st)
+{
+    const StreamNet &s = g->tsf;
+    const int is = g->is, cd = g->cd;
+    int rc;
+    for (int k = 0; k < nsets; ++k)
+        for (int l = 1; l <= kNDown; ++l)
+            if ((rc = lwg_resize_flow(T[k], bs, is, is, is >> l, is >> l, g->tscale[k][l - 1], st)) != LWG_OK) return rc;
+
+    const float *x0 = nullptr;
+    if ((rc = pack_input(g, tsf_inputs, layout, bs, g->tsf_dim, st, &x0)) != LWG_OK) return rc;
+
+    // encoders: level l output lives in the first half of cat[l] (the decoder's skip operand), level 3 in the trunk
+    if ((rc = run_encoder(g, s, 0, x0, 8, bs, g->cat[0], 2 * cd, nullptr, 0, align, st)) != LWG_OK) return rc;
+    for (int l = 1; l <= kNDown; ++l) {
+        Warp w[2];
+        for (int k = 0; k < nsets; ++k) {
+            w[k].src = feats[k][l];
+            w[k].T = g->tscale[k][l - 1];
+        }
+        const float *xin = g->cat[l - 1];
+        const int ldx = 2 * (cd << (l - 1));
+        float *dst = l < kNDown ? g->cat[l] : g->trunk[0];
+        const int ld_dst = l < kNDown ? 2 * (cd << l) : (cd << l);
+        if ((rc = run_encoder(g, s, l, xin, ldx, bs, dst, ld_dst, w, nsets, align, st)) != LWG_OK) return rc;
+    }
+    // residual trunk (generator.py:291-295): the 32x32 flow is shared by all blocks
+    int cur = 0;
+    for (int i = 0; i < g->repeat; ++i) {
+        Warp w[2];
+        for (int k = 0; k < nsets; ++k) {
+            w[k].src = feats[k][kNDown + 1 + i];
+            w[k].T = g->tscale[k][kNDown - 1];
+        }
+        if ((rc = run_resblock(g, s, i, g->trunk[cur], g->trunk[cur ^ 1], bs, w, nsets, align, st)) != LWG_OK) return rc;
+        cur ^= 1;
+    }
+    // decoder (generator.py:173-181): convT -> second half of cat[level]; skipper conv over the whole cat buffer
+    g->trunk_out = cur;
+    const float *d = g->trunk[cur];
+    int dC = cd << kNDown, dH = is >> kNDown;
+    for (int i = 0; i < kNDown; ++i) {
+        const int lvl = kNDown - 1 - i, oC = dC / 2, oH = dH * 2;
+        if ((rc = run_conv(g, s.dec[i], d, dC, bs, dH, dH, g->raw, st)) != LWG_OK) return rc;
+        if ((rc = run_apply(g, bs, oH, oH, oC, true, g->cat[lvl] + oC, 2 * oC, nullptr, 0, nullptr, 0, align, st)) != LWG_OK)
+            return rc;
+        if ((rc = run_conv(g, s.skip[i], g->cat[lvl], 2 * oC, bs, oH, oH, g->raw, st)) != LWG_OK) return rc;
+        if (i + 1 < kNDown) {
+            if ((rc = run_apply(g, bs, oH, oH, oC, true, g->sk[i], oC, nullptr, 0, nullptr, 0, align, st)) != LWG_OK)
+                return rc;
+            d = g->sk[i];
+        }
+        dC = oC;
+        dH = oH;
+    }
+    // heads read the last skipper's raw output and fold its InstanceNorm+ReLU into their halo load
+    HeadsArgs h = {};
+    h.x = g->raw;
+    h.N = bs;
+    h.H = is;
+    h.W = is;
+    h.scale_shift = g->ss;
+    h.wh = s.heads_w;
+    h.color = color;
+    h.mask = mask;
+    h.bg = bg;
+    h.bg_bs = bg_bs;
+    h.pred = pred;
+    return launch_heads(h, st);
+}
+
+}  // namespace
+}  // namespace lwg
+
+extern "C" {
+
+int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, int conv_dim, int repeat_num, int image_size,
+                         int max_batch)
+{
+    LWG_REQUIRE(out, "generator_create: NULL out");
+    *out = nullptr;
+    LWG_REQUIRE(src_dim > 0 && src_dim <= 8 && tsf_dim > 0 && tsf_dim <= 8, "generator_create: input dims must be 1..8");
+    LWG_REQUIRE(repeat_num > 0 && max_batch > 0, "generator_create: repeat_num/max_batch must be positive");
+    if (conv_dim != 64)
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "generator_create: conv_dim=%d (the kernels are built for the reference's 64)", conv_dim);
+    const int hb = image_size >> kNDown;
+    if (image_size <= 0 || (image_size & 7) || (hb * hb) % kConvBM != 0)
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "generator_create: image_size=%d; (image_size/8)^2 must be a multiple of %d",
+                 image_size, kConvBM);
+    int ndev = 0;
+    LWG_HIP(hipGetDeviceCount(&ndev));
+
+    lwg_generator *g = new lwg_generator();
+    g->src_dim = src_dim;
+    g->tsf_dim = tsf_dim;
+    g->cd = conv_dim;
+    g->repeat = repeat_num;
+    g->is = image_size;
+    g->max_batch = max_batch;
+    int rc = build_stream(g->src, src_dim, conv_dim, repeat_num, false);
+    if (rc == LWG_OK) rc = build_stream(g->tsf, tsf_dim, conv_dim, repeat_num, true);
+
+    const size_t B = (size_t)max_batch, P = (size_t)image_size * image_size;
+    const int cd = conv_dim;
+    if (rc == LWG_OK) rc = dev_alloc(&g->x0, B * P * 8);
+    if (rc == LWG_OK) rc = dev_alloc(&g->raw, B * P * cd);
+    for (int l = 0; l < kNDown && rc == LWG_OK; ++l) rc = dev_alloc(&g->cat[l], B * (P >> (2 * l)) * (size_t)(2 * (cd << l)));
+    for (int i = 0; i < 3 && rc == LWG_OK; ++i) rc = dev_alloc(&g->trunk[i], B * (P >> (2 * kNDown)) * (size_t)(cd << kNDown));
+    for (int i = 0; i + 1 < kNDown && rc == LWG_OK; ++i) {
+        const int lvl = kNDown - 1 - i;
+        rc = dev_alloc(&g->sk[i], B * (P >> (2 * lvl)) * (size_t)(cd << lvl));
+    }
+    for (int k = 0; k < 2; ++k)
+        for (int l = 1; l <= kNDown && rc == LWG_OK; ++l) rc = dev_alloc(&g->tscale[k][l - 1], B * (P >> (2 * l)) * 2);
+    // statistics partials: the widest need is 4 phases x tiles x channels of a decoder conv-transpose
+    if (rc == LWG_OK) {
+        size_t need = 0;
+        for (int l = 0; l <= kNDown; ++l) {
+            const size_t tiles = B * (P >> (2 * l)) / kConvBM;
+            const size_t c = (size_t)(cd << l);
+            need = need > tiles * c ? need : tiles * c;
+        }
+        float *p = nullptr;
+        rc = dev_alloc(&p, need * 2);
+        g->partials = reinterpret_cast<float2 *>(p);
+    }
+    if (rc == LWG_OK) {
+        float *p = nullptr;
+        rc = dev_alloc(&p, B * (size_t)(cd << kNDown) * 2);
+        g->ss = reinterpret_cast<float2 *>(p);
+    }
+    if (rc != LWG_OK) {
+        lwg_generator_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return LWG_OK;
+}
+
+void lwg_generator_destroy(lwg_generator *g)
+{
+    if (!g) return;
+    free_stream(g->src);
+    free_stream(g->tsf);
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    fr(g->x0);
+    fr(g->raw);
+    for (auto p : g->cat) fr(p);
+    for (auto p : g->trunk) fr(p);
+    for (auto p : g->sk) fr(p);
+    for (auto &k : g->tscale)
+        for (auto p : k) fr(p);
+    fr(g->partials);
+    fr(g->ss);
+    for (auto e : g->ev_pool) (void)hipEventDestroy(e);
+    delete g;
+}
+
+int lwg_generator_load_weight(lwg_generator *g, const char *key, const float *data_host, const int64_t *shape, int ndim)
+{
+    LWG_REQUIRE(g && key && data_host && shape, "load_weight: NULL argument");
+    std::string k(key);
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);  // DataParallel prefix (models/models.py:163-171)
+    if (k.rfind("bg_model.", 0) == 0) {
+        g->ignored_keys++;
+        return LWG_OK;  // BGNet is not on the Imitator.forward path (models/imitator.py:30-34)
+    }
+    StreamNet *s = nullptr;
+    bool is_tsf = false;
+    if (k.rfind("src_model.", 0) == 0) s = &g->src;
+    else if (k.rfind("tsf_model.", 0) == 0) { s = &g->tsf; is_tsf = true; }
+    else LWG_FAIL(LWG_ERR_INVALID_ARG, "load_weight: unknown key '%s'", key);
+    k = k.substr(10);
+
+    int i = -1, j = -1;
+    char tail[32] = {0};
+    auto norm_or_conv = [&](Layer &L, int sub, const char *what) -> int {
+        // <block>.<i>.0.weight = conv ; <block>.<i>.1.{weight,bias} = InstanceNorm affine
+        if (sub == 0 && !strcmp(what, "weight"))
+            return L.transposed ? upload_convT(L, data_host, shape, ndim, key) : upload_conv(L, data_host, shape, ndim, key);
+        if (sub == 1 && !strcmp(what, "weight")) return upload_vec(L.gamma, L.cout, &L.got_g, data_host, shape, ndim, key);
+        if (sub == 1 && !strcmp(what, "bias")) return upload_vec(L.beta, L.cout, &L.got_b, data_host, shape, ndim, key);
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "load_weight: unknown key '%s'", key);
+    };
+    if (sscanf(k.c_str(), "encoders.%d.%d.%31s", &i, &j, tail) == 3 && i >= 0 && i <= kNDown)
+        return norm_or_conv(s->enc[i], j, tail);
+    if (sscanf(k.c_str(), "resnets.%d.main.%d.%31s", &i, &j, tail) == 3 && i >= 0 && i < g->repeat) {
+        // main = [conv, IN, ReLU, conv, IN] (generator.py:12-17)
+        if (j == 0 || j == 1) return norm_or_conv(s->res[2 * i], j, tail);
+        if (j == 3 || j == 4) return norm_or_conv(s->res[2 * i + 1], j - 3, tail);
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "load_weight: unknown key '%s'", key);
+    }
+    const bool dec = sscanf(k.c_str(), "decoders.%d.%d.%31s", &i, &j, tail) == 3;
+    const bool skp = !dec && sscanf(k.c_str(), "skippers.%d.%d.%31s", &i, &j, tail) == 3;
+    if ((dec || skp) && i >= 0 && i < kNDown) {
+        if (!is_tsf) { g->ignored_keys++; return LWG_OK; }  // the source stream's decoder is never run (generator.py:136-147)
+        return norm_or_conv(dec ? s->dec[i] : s->skip[i], j, tail);
+    }
+    if (k == "img_reg.0.weight" || k == "attetion_reg.0.weight") {
+        if (!is_tsf) { g->ignored_keys++; return LWG_OK; }
+        const bool img = k[0] == 'i';
+        const int rc = upload_head(*s, data_host, shape, ndim, img ? 0 : 3, img ? 3 : 1, g->cd, key);
+        if (rc == LWG_OK) (img ? s->got_img : s->got_att) = true;
+        return rc;
+    }
+    LWG_FAIL(LWG_ERR_INVALID_ARG, "load_weight: unknown key '%s'", key);
+}
+
+int lwg_generator_missing_weights(const lwg_generator *g)
+{
+    if (!g) return -1;
+    return missing_in(g->src, false) + missing_in(g->tsf, true);
+}
+
+int lwg_generator_num_src_features(const lwg_generator *g) { return g ? kNDown + 1 + g->repeat : 0; }
+
+int lwg_generator_src_feature_shape(const lwg_generator *g, int index, int *C, int *H, int *W)
+{
+    LWG_REQUIRE(g && C && H && W, "src_feature_shape: NULL argument");
+    LWG_REQUIRE(index >= 0 && index < kNDown + 1 + g->repeat, "src_feature_shape: index %d out of range", index);
+    const int lvl = index <= kNDown ? index : kNDown;
+    *C = g->cd << lvl;
+    *H = *W = g->is >> lvl;
+    return LWG_OK;
+}
+
+int lwg_generator_encode_src(lwg_generator *g, const float *src_inputs_nchw, float *const *feats_nhwc,
+                             lwg_stream_t stream)
+{
+    int rc = check_ready(g, 1);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(src_inputs_nchw && feats_nhwc, "encode_src: NULL argument");
+    for (int i = 0; i < kNDown + 1 + g->repeat; ++i) LWG_REQUIRE(feats_nhwc[i], "encode_src: feats_nhwc[%d] is NULL", i);
+    hipStream_t st = as_stream(stream);
+    const float *x0 = nullptr;
+    if ((rc = pack_input(g, src_inputs_nchw, 0, 1, g->src_dim, st, &x0)) != LWG_OK) return rc;
+    const float *x = x0;
+    int ldx = 8;
+    for (int l = 0; l <= kNDown; ++l) {
+        const int C = g->cd << l;
+        if ((rc = run_encoder(g, g->src, l, x, ldx, 1, feats_nhwc[l], C, nullptr, 0, 0, st)) != LWG_OK) return rc;
+        x = feats_nhwc[l];
+        ldx = C;
+    }
+    for (int i = 0; i < g->repeat; ++i) {
+        float *o = feats_nhwc[kNDown + 1 + i];
+        if ((rc = run_resblock(g, g->src, i, x, o, 1, nullptr, 0, 0, st)) != LWG_OK) return rc;
+        x = o;
+    }
+    return LWG_OK;
+}
+
+int lwg_generator_inference(lwg_generator *g, const float *tsf_inputs, int layout, const float *T, int bs,
+                            const float *const *feats_nhwc, int align_corners, float *color, float *mask,
+                            const float *bg, int bg_bs, float *pred, lwg_stream_t stream)
+{
+    int rc = check_ready(g, bs);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(tsf_inputs && T && feats_nhwc, "inference: NULL argument");
+    LWG_REQUIRE(!pred || (bg && (bg_bs == 1 || bg_bs == bs)), "inference: pred needs bg with batch 1 or %d", bs);
+    for (int i = 0; i < kNDown + 1 + g->repeat; ++i) LWG_REQUIRE(feats_nhwc[i], "inference: feats_nhwc[%d] is NULL", i);
+    const float *const Ts[2] = {T, nullptr};
+    const float *const *fs[2] = {feats_nhwc, nullptr};
+    return run_tsf(g, tsf_inputs, layout, Ts, fs, 1, bs, align_corners, color, mask, bg, bg_bs, pred, as_stream(stream));
+}
+
+int lwg_generator_swap(lwg_generator *g, const float *tsf_inputs, int layout, const float *T12, const float *T21,
+                       int bs, const float *const *feats12_nhwc, const float *const *feats21_nhwc, int align_corners,
+                       float *color, float *mask, lwg_stream_t stream)
+{
+    int rc = check_ready(g, bs);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(tsf_inputs && T12 && T21 && feats12_nhwc && feats21_nhwc, "swap: NULL argument");
+    const float *const Ts[2] = {T12, T21};
+    const float *const *fs[2] = {feats12_nhwc, feats21_nhwc};
+    return run_tsf(g, tsf_inputs, layout, Ts, fs, 2, bs, align_corners, color, mask, nullptr, 0, nullptr, as_stream(stream));
+}
+
+int lwg_generator_peek(lwg_generator *g, int which, float *dst, size_t n_floats, lwg_stream_t stream)
+{
+    LWG_REQUIRE(g && dst, "peek: NULL argument");
+    const size_t B = (size_t)g->max_batch, P = (size_t)g->is * g->is;
+    const int cd = g->cd;
+    const float *src = nullptr;
+    size_t cap = 0;
+    if (which >= 0 && which < kNDown) {
+        src = g->cat[which];
+        cap = B * (P >> (2 * which)) * (size_t)(2 * (cd << which));
+    } else if (which == 3) {
+        src = g->trunk[g->trunk_out];
+        cap = B * (P >> (2 * kNDown)) * (size_t)(cd << kNDown);
+    } else if (which == 4 || which == 5) {
+        const int lvl = kNDown - 1 - (which - 4);
+        src = g->sk[which - 4];
+        cap = B * (P >> (2 * lvl)) * (size_t)(cd << lvl);
+    } else if (which == 6) {
+        src = g->raw;
+        cap = B * P * cd;
+    } else if (which >= 7 && which < 7 + kNDown) {
+        const int l = which - 6;
+        src = g->tscale[0][l - 1];
+        cap = B * (P >> (2 * l)) * 2;
+    } else {
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "peek: unknown buffer %d", which);
+    }
+    const size_t n = n_floats < cap ? n_floats : cap;
+    LWG_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return LWG_OK;
+}
+
+int lwg_generator_profile(lwg_generator *g, int enable)
+{
+    LWG_REQUIRE(g, "profile: NULL handle");
+    g->profile = enable != 0;
+    g->ev_used = 0;
+    g->prof_flops = 0.0;
+    g->prof_launches = 0;
+    return LWG_OK;
+}
+
+int lwg_generator_profile_read(lwg_generator *g, int *launches, double *total_ms, double *total_flops)
+{
+    LWG_REQUIRE(g && launches && total_ms && total_flops, "profile_read: NULL argument");
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g->ev_used; i += 2) {
+        LWG_HIP(hipEventSynchronize(g->ev_pool[i + 1]));
+        float t = 0.f;
+        LWG_HIP(hipEventElapsedTime(&t, g->ev_pool[i], g->ev_pool[i + 1]));
+        ms += t;
+    }
+    *launches = g->prof_launches;
+    *total_ms = ms;
+    *total_flops = g->prof_flops;
+    g->ev_used = 0;
+    g->prof_flops = 0.0;
+    g->prof_launches = 0;
+    return LWG_OK;
+}
+
+}  // extern "C"

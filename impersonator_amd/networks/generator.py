@@ -1,0 +1,314 @@
+"""ImpersonatorGenerator on MI355X: the reference's module surface, liblwg underneath.
+
+Mirrors `networks/generator.py` of the reference (ResidualBlock :8-20, ResNetGenerator :23-65,
+ResUnetGenerator :68-184, ImpersonatorGenerator :187-320):
+
+  * same constructor arguments, same `state_dict` keys and shapes (including the `attetion_reg`
+    spelling, generator.py:134), so reference checkpoints load with `load_state_dict`;
+  * same method names / argument order / return structure for the inference path:
+    `encode_src`, `inference`, `swap`, `transform`, `stn`, `resize_trans`;
+  * NO torch compute: the nn.Modules below only hold parameters.  Every method packs pointers and
+    calls the C ABI (include/lwg.h); a missing library or a CPU tensor raises.
+
+Feature maps returned by `encode_src` are NCHW-shaped tensors in `torch.channels_last` memory format:
+numerically what the reference returns, physically the NHWC layout the HIP kernels consume.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .networks import NetworkBase
+
+N_DOWN = 3
+
+
+class _ConvParams(nn.Module):
+    """Parameter holder named like nn.Conv2d / nn.ConvTranspose2d (weight only: bias=False everywhere)."""
+
+    def __init__(self, cin, cout, k, transposed=False):
+        super().__init__()
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        self.weight = nn.Parameter(torch.empty(shape))
+        self.transposed = transposed
+        nn.init.normal_(self.weight, 0.0, 0.02)  # NetworkBase.init_weights (networks/networks.py:54-65)
+
+    def forward(self, *_):
+        raise RuntimeError("parameter holder: computation runs in liblwg (impersonator_amd/csrc)")
+
+
+class _InstanceNormParams(nn.Module):
+    """Parameter holder named like nn.InstanceNorm2d(affine=True): weight (gamma) and bias (beta)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+    def forward(self, *_):
+        raise RuntimeError("parameter holder: computation runs in liblwg (impersonator_amd/csrc)")
+
+
+def _seq(*mods):
+    return nn.Sequential(*mods)
+
+
+def _conv_norm(cin, cout, k, transposed=False):
+    # index 0 = conv, 1 = InstanceNorm, 2 = ReLU placeholder (keeps the reference's Sequential indices)
+    return _seq(_ConvParams(cin, cout, k, transposed), _InstanceNormParams(cout), nn.Identity())
+
+
+class ResidualBlock(nn.Module):
+    """generator.py:8-20: main = [conv3, IN, ReLU, conv3, IN]."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.main = _seq(_ConvParams(dim_in, dim_out, 3), _InstanceNormParams(dim_out), nn.Identity(),
+                         _ConvParams(dim_out, dim_out, 3), _InstanceNormParams(dim_out))
+
+
+class ResNetGenerator(NetworkBase):
+    """BGNet (generator.py:23-65).  Parameters only: it is not on the Imitator.forward path."""
+
+    def __init__(self, conv_dim=64, c_dim=5, repeat_num=9, k_size=4, n_down=2):
+        super().__init__()
+        self._name = 'resnet_generator'
+        layers = [_ConvParams(c_dim, conv_dim, 7), _InstanceNormParams(conv_dim), nn.Identity()]
+        cur = conv_dim
+        for _ in range(n_down):
+            layers += [_ConvParams(cur, cur * 2, k_size), _InstanceNormParams(cur * 2), nn.Identity()]
+            cur *= 2
+        for _ in range(repeat_num):
+            layers.append(ResidualBlock(cur, cur))
+        for _ in range(n_down):
+            layers += [_ConvParams(cur, cur // 2, k_size, transposed=True), _InstanceNormParams(cur // 2), nn.Identity()]
+            cur //= 2
+        layers += [_ConvParams(cur, 3, 7), nn.Identity()]
+        self.model = _seq(*layers)
+
+
+class ResUnetGenerator(NetworkBase):
+    """generator.py:68-134: encoders / resnets / decoders / skippers / img_reg / attetion_reg."""
+
+    def __init__(self, conv_dim=64, c_dim=5, repeat_num=6, k_size=4, n_down=2):
+        super().__init__()
+        self._name = 'resunet_generator'
+        self.repeat_num = repeat_num
+        self.n_down = n_down
+        enc = [_conv_norm(c_dim, conv_dim, 7)]
+        cur = conv_dim
+        for _ in range(n_down):
+            enc.append(_conv_norm(cur, cur * 2, k_size))
+            cur *= 2
+        self.encoders = _seq(*enc)
+        self.resnets = _seq(*[ResidualBlock(cur, cur) for _ in range(repeat_num)])
+        dec, skp = [], []
+        for _ in range(n_down):
+            dec.append(_conv_norm(cur, cur // 2, k_size, transposed=True))
+            skp.append(_conv_norm(cur, cur // 2, k_size))
+            cur //= 2
+        self.decoders = _seq(*dec)
+        self.skippers = _seq(*skp)
+        self.img_reg = _seq(_ConvParams(cur, 3, 7), nn.Identity())
+        self.attetion_reg = _seq(_ConvParams(cur, 1, 7), nn.Identity())
+
+
+class ImpersonatorGenerator(NetworkBase):
+    """generator.py:187-320.  `max_batch` (extension) sizes the device scratch; frames of one source
+    are independent, so any batch up to it runs in one launch sequence."""
+
+    def __init__(self, bg_dim, src_dim, tsf_dim, conv_dim=64, repeat_num=6, image_size=256, max_batch=8,
+                 align_corners=False):
+        super().__init__()
+        self._name = 'impersonator_generator'
+        self.n_down = N_DOWN
+        self.repeat_num = repeat_num
+        self.conv_dim = conv_dim
+        self.src_dim, self.tsf_dim = src_dim, tsf_dim
+        self.image_size = image_size
+        self.max_batch = max_batch
+        # hazard H1: the reference calls F.grid_sample without align_corners (generator.py:313); torch 1.2
+        # meant True, torch >= 1.3 means False.  False is the parity target; True serves 2019 checkpoints.
+        self.align_corners = bool(align_corners)
+        self.bg_model = ResNetGenerator(conv_dim=conv_dim, c_dim=bg_dim, repeat_num=repeat_num, k_size=3, n_down=N_DOWN)
+        self.src_model = ResUnetGenerator(conv_dim=conv_dim, c_dim=src_dim, repeat_num=repeat_num, k_size=3, n_down=N_DOWN)
+        self.tsf_model = ResUnetGenerator(conv_dim=conv_dim, c_dim=tsf_dim, repeat_num=repeat_num, k_size=3, n_down=N_DOWN)
+        self._handle = None
+        self._uploaded_version = None
+
+    # ------------------------------------------------------------------ handle / weights
+    def _weights_version(self):
+        return tuple(p._version for p in self.parameters()) + (id(self),)
+
+    def _ensure_handle(self, bs=1):
+        lib = _lib.load()
+        if bs > self.max_batch:
+            self.release()
+            self.max_batch = bs
+        if self._handle is None:
+            h = ctypes.c_void_p()
+            _lib.check(lib.lwg_generator_create(ctypes.byref(h), self.src_dim, self.tsf_dim, self.conv_dim,
+                                                self.repeat_num, self.image_size, self.max_batch))
+            self._handle = h
+            self._uploaded_version = None
+        ver = self._weights_version()
+        if self._uploaded_version != ver:
+            for key, val in self.state_dict().items():
+                if key.startswith("bg_model."):
+                    continue
+                arr = val.detach().to("cpu", torch.float32).contiguous()
+                shape = (ctypes.c_int64 * arr.dim())(*arr.shape)
+                _lib.check(lib.lwg_generator_load_weight(self._handle, key.encode(), ctypes.c_void_p(arr.data_ptr()),
+                                                         shape, arr.dim()))
+            missing = lib.lwg_generator_missing_weights(self._handle)
+            if missing:
+                raise _lib.LwgError(-5, "%d generator weights missing after upload" % missing)
+            self._uploaded_version = ver
+        return self._handle
+
+    def release(self):
+        if self._handle is not None:
+            _lib.load().lwg_generator_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _need_cuda(*tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError("impersonator_amd runs on the GPU only (got a %s tensor); there is no CPU fallback"
+                                   % t.device)
+
+    def _feature_shapes(self):
+        shapes = [(self.conv_dim << l, self.image_size >> l) for l in range(N_DOWN + 1)]
+        shapes += [shapes[-1]] * self.repeat_num
+        return shapes
+
+    @staticmethod
+    def _nhwc(t):
+        """(N,C,H,W)-shaped tensor whose storage is NHWC; converts only if the caller handed plain NCHW."""
+        t = t.float()
+        if t.shape[1] > 1 and t.is_contiguous(memory_format=torch.channels_last):
+            return t
+        return t.contiguous(memory_format=torch.channels_last)
+
+    def _input_layout(self, x):
+        """1 when `x` is the NHWC8-backed view produced by SMPLRenderer.transfer, else 0 (plain NCHW)."""
+        n, c, h, w = x.shape
+        if x.stride() == (h * w * 8, 1, w * 8, 8) and x.storage_offset() == 0 and c <= 8:
+            return x, 1
+        return x.float().contiguous(), 0
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def encode_src(self, src_inputs):
+        """generator.py:213-214 -> (encoder_outs[4], resnet_outs[repeat_num])."""
+        self._need_cuda(src_inputs)
+        if src_inputs.shape[0] != 1:
+            raise ValueError("encode_src runs once per source image (batch 1), as models/imitator.py:136 does")
+        h = self._ensure_handle(1)
+        x = src_inputs.float().contiguous()
+        feats = [torch.empty((1, c, s, s), device=x.device, dtype=torch.float32).contiguous(
+            memory_format=torch.channels_last) for c, s in self._feature_shapes()]
+        _lib.check(_lib.load().lwg_generator_encode_src(h, _lib.ptr(x), _lib.ptr_array(feats), _lib.stream_ptr()))
+        return feats[:N_DOWN + 1], feats[N_DOWN + 1:]
+
+    @torch.no_grad()
+    def inference(self, src_encoder_outs, src_resnet_outs, tsf_inputs, T, bg_img=None):
+        """generator.py:277-301 -> (tsf_img, tsf_mask).  With `bg_img` (extension) the blend of
+        models/imitator.py:331 is fused into the last kernel and (pred, tsf_img, tsf_mask) is returned."""
+        self._need_cuda(tsf_inputs, T)
+        bs = tsf_inputs.shape[0]
+        h = self._ensure_handle(bs)
+        feats = [self._nhwc(f) for f in list(src_encoder_outs) + list(src_resnet_outs)]
+        x, layout = self._input_layout(tsf_inputs)
+        T = T.float().contiguous()
+        dev = x.device
+        s = self.image_size
+        color = torch.empty((bs, 3, s, s), device=dev, dtype=torch.float32)
+        mask = torch.empty((bs, 1, s, s), device=dev, dtype=torch.float32)
+        pred = bg = None
+        if bg_img is not None:
+            bg = bg_img.float().contiguous()
+            pred = torch.empty_like(color)
+        _lib.check(_lib.load().lwg_generator_inference(
+            h, _lib.ptr(x), layout, _lib.ptr(T), bs, _lib.ptr_array(feats), int(self.align_corners), _lib.ptr(color),
+            _lib.ptr(mask), _lib.ptr(bg), 0 if bg is None else bg.shape[0], _lib.ptr(pred), _lib.stream_ptr()))
+        return (color, mask) if bg_img is None else (pred, color, mask)
+
+    @torch.no_grad()
+    def swap(self, tsf_inputs, src_encoder_outs12, src_encoder_outs21, src_resnet_outs12, src_resnet_outs21, T12, T21):
+        """generator.py:245-275."""
+        self._need_cuda(tsf_inputs, T12, T21)
+        bs = tsf_inputs.shape[0]
+        h = self._ensure_handle(bs)
+        f12 = [self._nhwc(f) for f in list(src_encoder_outs12) + list(src_resnet_outs12)]
+        f21 = [self._nhwc(f) for f in list(src_encoder_outs21) + list(src_resnet_outs21)]
+        x, layout = self._input_layout(tsf_inputs)
+        T12, T21 = T12.float().contiguous(), T21.float().contiguous()
+        s = self.image_size
+        color = torch.empty((bs, 3, s, s), device=x.device, dtype=torch.float32)
+        mask = torch.empty((bs, 1, s, s), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().lwg_generator_swap(h, _lib.ptr(x), layout, _lib.ptr(T12), _lib.ptr(T21), bs,
+                                                  _lib.ptr_array(f12), _lib.ptr_array(f21), int(self.align_corners),
+                                                  _lib.ptr(color), _lib.ptr(mask), _lib.stream_ptr()))
+        return color, mask
+
+    @torch.no_grad()
+    def resize_trans(self, x, T):
+        """generator.py:303-310: bilinear (align_corners=True) resize of the flow to x's resolution."""
+        self._need_cuda(T)
+        _, _, h, w = x.shape
+        T = T.float().contiguous()
+        bs, H, W, _ = T.shape
+        out = torch.empty((bs, h, w, 2), device=T.device, dtype=torch.float32)
+        _lib.check(_lib.load().lwg_resize_flow(_lib.ptr(T), bs, H, W, h, w, _lib.ptr(out), _lib.stream_ptr()))
+        return out
+
+    @torch.no_grad()
+    def stn(self, x, T):
+        """generator.py:312-315: F.grid_sample(x, T)."""
+        self._need_cuda(x, T)
+        x = x.float().contiguous()
+        T = T.float().contiguous()
+        n, ho, wo, _ = T.shape
+        xn, c, h, w = x.shape
+        out = torch.empty((n, c, ho, wo), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().lwg_grid_sample(_lib.ptr(x), xn, c, h, w, _lib.ptr(T), n, ho, wo,
+                                               int(self.align_corners), _lib.ptr(out), _lib.stream_ptr()))
+        return out
+
+    def transform(self, x, T):
+        """generator.py:317-320."""
+        return self.stn(x, self.resize_trans(x, T))
+
+    def infer_front(self, src_inputs, tsf_inputs, T):
+        raise NotImplementedError("training-time joint src/tsf forward (generator.py:216-243) is outside the "
+                                  "Imitator.forward() inference path this build covers")
+
+    def forward(self, bg_inputs, src_inputs, tsf_inputs, T):
+        raise NotImplementedError("training-time forward (generator.py:204-211) is outside the Imitator.forward() "
+                                  "inference path; use encode_src() + inference()")
+
+    def peek(self, which, shape):
+        """Test hook (lwg_generator_peek): copy of an internal NHWC scratch buffer, shaped `shape`."""
+        out = torch.empty(shape, device="cuda", dtype=torch.float32)
+        _lib.check(_lib.load().lwg_generator_peek(self._ensure_handle(1), which, _lib.ptr(out), out.numel(),
+                                                  _lib.stream_ptr()))
+        return out
+
+    # profiling hooks used by bench.py (roofline of the implicit-GEMM kernel)
+    def profile(self, enable=True):
+        _lib.check(_lib.load().lwg_generator_profile(self._ensure_handle(1), int(enable)))
+
+    def profile_read(self):
+        n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.load().lwg_generator_profile_read(self._ensure_handle(1), ctypes.byref(n), ctypes.byref(ms),
+                                                          ctypes.byref(fl)))
+        return n.value, ms.value, fl.value

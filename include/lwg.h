@@ -1,0 +1,175 @@
+/*
+ * lwg.h -- C ABI of liblwg.so, the MI355X (gfx950) native library behind the Imitator.forward()
+ * hot path of Liquid Warping GAN (reference: svip-lab/impersonator).
+ *
+ * This is the drop-in boundary.  The reference's native boundary for this path
+ * is the pybind11 module `neural_renderer.cuda.rasterize` (rasterize_cuda.cpp:70-95,194-200) plus the
+ * ATen/cuDNN operators PyTorch dispatches for networks/generator.py; liblwg replaces both with plain
+ * C entry points: raw device pointers + sizes, no C++ or torch types, never throws, returns 0 or a
+ * negative LWG_ERR_* code (text via lwg_last_error()).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - the caller owns every input/output buffer (PyTorch tensors in the Python host code);
+ *   - all work is enqueued on the caller's stream (`lwg_stream_t` = hipStream_t), no implicit sync;
+ *   - fp32 everywhere, int32 face ids; image tensors are NCHW at the boundary like the reference's,
+ *     feature maps handed between entry points are NHWC (== torch.channels_last storage);
+ *   - a `lwg_generator` handle owns only what the caller cannot see: re-laid-out weights and scratch.
+ *     One handle per device, not to be used from two threads at once.
+ */
+#ifndef LWG_H_
+#define LWG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LWG_API __attribute__((visibility("default")))
+
+typedef void *lwg_stream_t; /* hipStream_t */
+
+enum {
+    LWG_OK = 0,
+    LWG_ERR_INVALID_ARG = -1, /* NULL pointer, non-positive size, ... (reference: AT_CHECK -> RuntimeError) */
+    LWG_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
+    LWG_ERR_WORKSPACE = -3,   /* workspace too small / misaligned */
+    LWG_ERR_HIP = -4,         /* a HIP runtime call or kernel launch failed (reference only printf'd these) */
+    LWG_ERR_STATE = -5        /* handle not ready (weights missing, batch above max_batch, ...) */
+};
+
+LWG_API int lwg_version(void);
+/* thread-local text of the last failure in this thread; never NULL */
+LWG_API const char *lwg_last_error(void);
+/* name may be NULL; returns LWG_ERR_HIP when no device is visible */
+LWG_API int lwg_device_info(int *cu_count, size_t *hbm_bytes, char *name_host, size_t name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Geometry: replaces the python glue in front of the rasteriser.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* verts (bs,nv,3), cam (bs,3) = [s,tx,ty], faces_idx (nf,3) -> f2verts (bs,nf,3,3).
+ * = orthographic_proj_withz_idrot (utils/nmr.py:10-28) + y flip (nmr.py:271) + nr.look_at with the
+ * renderer's eye (0,0,eye_z) (nmr.py:177,273; look_at.py:6-62: identity rotation, z -= eye_z)
+ * + nr.vertices_to_faces (vertices_to_faces.py:4-22). */
+LWG_API int lwg_project_faces(const float *verts, const float *cam, const int32_t *faces_idx, int bs, int nv,
+                              int nf, float eye_z, float *f2verts, lwg_stream_t stream);
+
+/* Rasteriser: replaces rasterize_cuda.forward_face_index_map (rasterize_cuda.cpp:70-95; kernels
+ * rasterize_cuda_kernel.cu:40-186) together with the fills of rasterize.py:50-52 and the vertical
+ * flips of rasterize.py:334-338.  faces (bs,nf,3,3) -> fim int32 (bs,is,is) [-1 = background],
+ * wim (bs,is,is,3) [0 where uncovered], depth (bs,is,is) [far where uncovered] or NULL.
+ * Results are bit-identical to the reference algorithm (lowest face index wins depth ties). */
+LWG_API size_t lwg_rasterize_workspace_bytes(int bs, int nf, int image_size);
+LWG_API int lwg_rasterize_fim_wim(const float *faces, int bs, int nf, int image_size, float near_z, float far_z,
+                                  int32_t *fim, float *wim, float *depth, void *workspace, size_t workspace_bytes,
+                                  lwg_stream_t stream);
+
+/* SMPLRenderer.encode_fim (utils/nmr.py:328-341): out = map_fn[fim] with fim == -1 -> last row.
+ * map_fn (nrows,nc); fim (bs,npix); out (bs,nc,npix) when transpose != 0 else (bs,npix,nc). */
+LWG_API int lwg_encode_fim(const int32_t *fim, const float *map_fn, int bs, int npix, int nrows, int nc,
+                           int transpose, float *out, lwg_stream_t stream);
+
+/* SMPLRenderer.cal_bc_transform (utils/nmr.py:617-659): T = sum_k wim[k] * src_f2pts[fim][k] on
+ * covered pixels, (-2,-2) elsewhere.  src_f2pts (src_bs,nf,3,2) with src_bs == 1 (shared) or bs. */
+LWG_API int lwg_cal_bc_transform(const float *src_f2pts, int src_bs, const int32_t *fim, const float *wim, int bs,
+                                 int nf, int image_size, float *T, lwg_stream_t stream);
+
+/* F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros') as called at models/imitator.py:259 and
+ * networks/generator.py:313.  x (xn,C,H,W) NCHW with xn == 1 (shared) or n; grid (n,Ho,Wo,2);
+ * out (n,C,Ho,Wo).  align_corners: 0 = torch>=1.3 default (parity target), 1 = torch 1.2 behaviour (H1). */
+LWG_API int lwg_grid_sample(const float *x, int xn, int C, int H, int W, const float *grid, int n, int Ho, int Wo,
+                            int align_corners, float *out, lwg_stream_t stream);
+
+/* ImpersonatorGenerator.resize_trans (networks/generator.py:303-310): bilinear, align_corners=True,
+ * of the flow field T (bs,H,W,2) -> (bs,h,w,2). */
+LWG_API int lwg_resize_flow(const float *T, int bs, int H, int W, int h, int w, float *out, lwg_stream_t stream);
+
+/* One launch sequence for models/imitator.py:250-260 given posed vertices:
+ * project -> rasterise -> cond = map_fn[fim] -> T -> tsf_img = grid_sample(src_img, T)
+ * -> tsf_inputs = cat(tsf_img, cond).  Shared source: src_p2verts (nf,3,2), src_img (3,is,is).
+ * Outputs (any of cond/tsf_img/tsf_inputs_nhwc8 may be NULL): f2verts (bs,nf,3,3), fim, wim,
+ * cond (bs,nc,is,is), T (bs,is,is,2), tsf_img (bs,3,is,is), tsf_inputs_nhwc8 (bs,is,is,8) =
+ * [tsf_img(3), cond(nc=3), 0, 0] per pixel -- the layout lwg_generator_* consumes directly. */
+LWG_API size_t lwg_transfer_workspace_bytes(int bs, int nf, int image_size);
+LWG_API int lwg_transfer_frame(const float *verts, const float *cam, const int32_t *faces_idx, int bs, int nv, int nf,
+                               int image_size, float eye_z, float near_z, float far_z, const float *map_fn, int nc,
+                               const float *src_p2verts, const float *src_img, int align_corners, float *f2verts,
+                               int32_t *fim, float *wim, float *cond, float *T, float *tsf_img,
+                               float *tsf_inputs_nhwc8, void *workspace, size_t workspace_bytes,
+                               lwg_stream_t stream);
+
+/* NCHW (n,C,H,W) -> NHWC with the channel count padded to cpad (zeros), and back (first C channels). */
+LWG_API int lwg_pack_nhwc(const float *x_nchw, int n, int C, int H, int W, int cpad, float *out_nhwc,
+                          lwg_stream_t stream);
+LWG_API int lwg_unpack_nchw(const float *x_nhwc, int n, int C, int H, int W, int cpad, float *out_nchw,
+                            lwg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generator: replaces what PyTorch dispatches for ImpersonatorGenerator (networks/generator.py:187-320):
+ * conv / conv-transpose / InstanceNorm / ReLU / grid_sample / interpolate / cat / tanh / sigmoid.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lwg_generator lwg_generator;
+
+/* ImpersonatorGenerator(bg_dim, src_dim, tsf_dim, conv_dim=64, repeat_num=6), n_down = 3
+ * (generator.py:189-202).  Allocates weights + scratch for batches up to max_batch. */
+LWG_API int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, int conv_dim, int repeat_num,
+                                 int image_size, int max_batch);
+LWG_API void lwg_generator_destroy(lwg_generator *g);
+
+/* Feed one state_dict entry (PyTorch layout, HOST memory), e.g.
+ * "tsf_model.encoders.0.0.weight" (64,6,7,7), "tsf_model.resnets.2.main.1.bias" (512,),
+ * "tsf_model.decoders.0.0.weight" (512,256,3,3), "tsf_model.attetion_reg.0.weight" (1,64,7,7).
+ * Keys of bg_model.* are accepted and ignored (not on this path).  Unknown keys: LWG_ERR_INVALID_ARG. */
+LWG_API int lwg_generator_load_weight(lwg_generator *g, const char *key, const float *data_host, const int64_t *shape,
+                                      int ndim);
+/* number of src_model/tsf_model entries still missing (0 = ready) */
+LWG_API int lwg_generator_missing_weights(const lwg_generator *g);
+
+/* Shapes of the 4 + repeat_num cached source feature maps, in the order
+ * encoder_outs[0..3], resnet_outs[0..repeat_num-1] (generator.py:136-147). */
+LWG_API int lwg_generator_num_src_features(const lwg_generator *g);
+LWG_API int lwg_generator_src_feature_shape(const lwg_generator *g, int index, int *C, int *H, int *W);
+
+/* ImpersonatorGenerator.encode_src (generator.py:213-214): src_inputs (1,src_dim,is,is) NCHW ->
+ * feats_nhwc[i] (1,H,W,C) for every feature above (caller-allocated). */
+LWG_API int lwg_generator_encode_src(lwg_generator *g, const float *src_inputs_nchw, float *const *feats_nhwc,
+                                     lwg_stream_t stream);
+
+/* ImpersonatorGenerator.inference (generator.py:277-301) + the blend of Imitator.forward
+ * (models/imitator.py:326-336).
+ *   tsf_inputs: layout 0 = NCHW (bs,tsf_dim,is,is); 1 = NHWC8 (bs,is,is,8)
+ *   T (bs,is,is,2); feats_nhwc as produced by encode_src (batch 1, shared by all frames)
+ *   color (bs,3,is,is), mask (bs,1,is,is): may be NULL
+ *   bg (bg_bs,3,is,is) with bg_bs in {1,bs} and pred (bs,3,is,is) = mask*bg + (1-mask)*color: both may be NULL
+ */
+LWG_API int lwg_generator_inference(lwg_generator *g, const float *tsf_inputs, int layout, const float *T, int bs,
+                                    const float *const *feats_nhwc, int align_corners, float *color, float *mask,
+                                    const float *bg, int bg_bs, float *pred, lwg_stream_t stream);
+
+/* ImpersonatorGenerator.swap (generator.py:245-275): two warped sources per level. */
+LWG_API int lwg_generator_swap(lwg_generator *g, const float *tsf_inputs, int layout, const float *T12,
+                               const float *T21, int bs, const float *const *feats12_nhwc,
+                               const float *const *feats21_nhwc, int align_corners, float *color, float *mask,
+                               lwg_stream_t stream);
+
+/* Test hook: copies an internal scratch buffer (device to device) after inference/swap/encode_src.
+ * which: 0..2 = concat buffers cat[l] (bs, is>>l, is>>l, 2*conv_dim<<l)  [skip half | decoder half],
+ *        3 = residual trunk output (bs, is/8, is/8, 8*conv_dim), 4..5 = skipper outputs 0..1,
+ *        6 = raw (pre-norm) output of the last conv, 7..9 = resized flows at is/2, is/4, is/8.
+ * Copies min(n_floats, buffer size) floats. */
+LWG_API int lwg_generator_peek(lwg_generator *g, int which, float *dst, size_t n_floats, lwg_stream_t stream);
+
+/* Kernel timing for bench.py's roofline: when enabled, every launch of the implicit-GEMM conv kernel is
+ * bracketed by HIP events on the launch stream.  read() synchronises those events and returns the launch
+ * count, their summed duration and the algorithmic FLOPs (2*M*N*K of the convolution, zero padding
+ * included as the reference's cuDNN would count it) they covered, then clears the record. */
+LWG_API int lwg_generator_profile(lwg_generator *g, int enable);
+LWG_API int lwg_generator_profile_read(lwg_generator *g, int *launches, double *total_ms, double *total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LWG_H_ */

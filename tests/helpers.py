@@ -1,0 +1,51 @@
+"""Shared fixtures for the parity tests: the seeded synthetic scene of tests/golden/make_golden.py,
+rebuilt WITHOUT the reference (it does not exist on the GPU box)."""
+import os
+
+import numpy as np
+import torch
+
+from impersonator_amd.utils import synthetic
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def has_gpu():
+    return torch.cuda.is_available()
+
+
+def scene():
+    """Numpy/torch CPU inputs identical to make_golden.make_frame()."""
+    rest, faces = synthetic.body_mesh()
+    s = dict(rest=rest, faces=faces, map_fn=synthetic.uv_seg_map_fn(rest, faces))
+    s["src_cam"] = synthetic.cams(1, seed=100)
+    s["src_verts"] = rest[None].copy()
+    s["src_img"] = synthetic.smooth_image(11)
+    s["bg_img"] = synthetic.smooth_image(12)
+    s["tgt_verts"] = np.stack([synthetic.motion_verts(rest, t) for t in (3, 200)])
+    s["tgt_cam"] = synthetic.cams(2, seed=5)
+    return s
+
+
+def generator_state_dict(seed=0, affine="random"):
+    """Seeded weights keyed like ImpersonatorGenerator.state_dict() (numpy)."""
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6)
+    shapes = [(k, tuple(v.shape)) for k, v in G.state_dict().items()]
+    return synthetic.random_state_dict(shapes, seed=seed, affine=affine)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def t(x, device="cpu"):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device)
+
+
+def maxdiff(a, b):
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.from_numpy(np.asarray(a)).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.from_numpy(np.asarray(b)).double()
+    d = (a - b).abs()
+    idx = int(d.argmax())
+    return float(d.max()), np.unravel_index(idx, tuple(d.shape))

@@ -1,0 +1,178 @@
+"""GPU parity: ImpersonatorGenerator / Imitator.forward through the C ABI against the CPU oracle
+(oracle/torch_ref.py, pinned to the reference) and against outputs of the real reference
+(tests/golden/frame_golden.npz).  Tolerance: the north-star bound, 1e-3 per-pixel L-inf on the final
+image; intermediate feature maps are held to a tighter relative bound so a wrong layer is named."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+TOL_IMAGE = 1e-3     # BASELINE.json north_star: per-pixel L-inf vs the reference
+TOL_FEATURE = 2e-4   # intermediate activations (O(1) magnitude after InstanceNorm)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    """One generator + oracle state shared by the tests of this module (the CPU oracle takes seconds)."""
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    from impersonator_amd.utils.nmr import SMPLRenderer
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    s = helpers.scene()
+    sd_np = helpers.generator_state_dict(seed=0, affine="random")
+    sd = torch_ref.state_dict_from_numpy(sd_np)
+    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, max_batch=2)
+    G.load_state_dict(sd)
+    G = G.cuda()
+    r = SMPLRenderer(image_size=256, faces=s["faces"], map_fn=s["map_fn"]).cuda()
+
+    faces_t = helpers.t(s["faces"])
+    sf2v, sfim, _ = torch_ref.render_fim_wim(helpers.t(s["src_cam"]), helpers.t(s["src_verts"]), faces_t)
+    scond = torch_ref.encode_fim(sfim, helpers.t(s["map_fn"]))
+    p2v = torch_ref.source_p2verts(sf2v)
+    src_img, bg_img = helpers.t(s["src_img"]), helpers.t(s["bg_img"])
+    ft_mask = 1 - torch_ref.morph(scond[:, -1:], ks=3, mode="erode")
+    src_inputs = torch.cat([src_img * ft_mask, scond], dim=1)
+    fr = torch_ref.transfer_frame(src_img, p2v, helpers.t(s["tgt_cam"]), helpers.t(s["tgt_verts"]), faces_t,
+                                  helpers.t(s["map_fn"]))
+    with torch.no_grad():
+        o_enc, o_res = torch_ref.encode_src(sd, src_inputs)
+    return dict(s=s, sd=sd, G=G, r=r, p2v=p2v, src_img=src_img, bg_img=bg_img, src_inputs=src_inputs, fr=fr,
+                o_enc=o_enc, o_res=o_res)
+
+
+def test_encode_src_every_level(ctx):
+    enc, res = ctx["G"].encode_src(ctx["src_inputs"].cuda())
+    assert len(enc) == 4 and len(res) == 6
+    for i, (a, b) in enumerate(zip(enc + res, ctx["o_enc"] + ctx["o_res"])):
+        assert tuple(a.shape) == tuple(b.shape)
+        d, where = helpers.maxdiff(a, b)
+        assert d <= TOL_FEATURE * max(1.0, float(b.abs().max())), ("feature %d" % i, d, where)
+    g = helpers.golden("frame_golden.npz")
+    for a, st in zip(enc, g["src_enc_stat"]):
+        assert abs(float(a.double().mean()) - st[0]) < 1e-5 and abs(float((a.double() ** 2).mean()) - st[2]) < 1e-4
+
+
+def test_inference_matches_oracle_and_reference_golden(ctx):
+    G, fr = ctx["G"], ctx["fr"]
+    enc, res = G.encode_src(ctx["src_inputs"].cuda())
+    pred, color, mask = G.inference(enc, res, fr["tsf_inputs"].cuda(), fr["T"].cuda(), bg_img=ctx["bg_img"].cuda())
+    with torch.no_grad():
+        o_pred, o_color, o_mask = torch_ref.imitator_forward(ctx["sd"], ctx["o_enc"], ctx["o_res"], ctx["bg_img"],
+                                                             fr["tsf_inputs"], fr["T"])
+    for name, a, b in (("color", color, o_color), ("mask", mask, o_mask), ("pred", pred, o_pred)):
+        d, where = helpers.maxdiff(a, b)
+        assert d <= TOL_IMAGE, (name, d, where)
+    # intermediate checkpoints through the test hook: residual trunk output and the decoder concat buffers
+    g = helpers.golden("frame_golden.npz")
+    d, where = helpers.maxdiff(pred, g["preds"])
+    assert d <= TOL_IMAGE, ("reference golden", d, where)
+    d, _ = helpers.maxdiff(color[:1, :, ::4, ::4], g["color0_sub"])
+    assert d <= TOL_IMAGE
+    d, _ = helpers.maxdiff(mask[:1, :, ::4, ::4], g["mask0_sub"])
+    assert d <= TOL_IMAGE
+    # without the fused blend the two-output form of the reference API is returned
+    c2, m2 = G.inference(enc, res, fr["tsf_inputs"].cuda(), fr["T"].cuda())
+    assert torch.equal(c2, color) and torch.equal(m2, mask)
+
+
+def test_trunk_and_decoder_checkpoints(ctx):
+    """Localises a failing layer: compares internal buffers with the oracle's activations."""
+    G, fr, sd = ctx["G"], ctx["fr"], ctx["sd"]
+    enc, res = G.encode_src(ctx["src_inputs"].cuda())
+    G.inference(enc, res, fr["tsf_inputs"].cuda(), fr["T"].cuda())
+    bs = 2
+    with torch.no_grad():
+        def lwb(feat, T):
+            h, w = feat.shape[2:]
+            return torch_ref.grid_sample(feat.expand(bs, -1, -1, -1), torch_ref.resize_trans(T, h, w))
+        x = torch_ref._encoder(fr["tsf_inputs"], sd, "tsf_model", 0)
+        encs = [x]
+        for i in range(1, 4):
+            x = torch_ref._encoder(x, sd, "tsf_model", i) + lwb(ctx["o_enc"][i], fr["T"])
+            encs.append(x)
+        for i in range(6):
+            x = torch_ref._resblock(x, sd, "tsf_model", i) + lwb(ctx["o_res"][i], fr["T"])
+    for l in (1, 2, 3):
+        ts = G.peek(6 + l, (bs, 256 >> l, 256 >> l, 2))
+        d, where = helpers.maxdiff(ts, torch_ref.resize_trans(fr["T"], 256 >> l, 256 >> l))
+        assert d <= 2e-6, ("resized flow", l, d, where)
+    for l in range(3):
+        c = 64 << l
+        cat = G.peek(l, (bs, 256 >> l, 256 >> l, 2 * c))
+        d, where = helpers.maxdiff(cat[..., :c].permute(0, 3, 1, 2), encs[l])
+        assert d <= TOL_FEATURE * max(1.0, float(encs[l].abs().max())), ("tsf encoder", l, d, where)
+    trunk = G.peek(3, (bs, 32, 32, 512)).permute(0, 3, 1, 2)
+    d, where = helpers.maxdiff(trunk, x)
+    assert d <= 5 * TOL_FEATURE * max(1.0, float(x.abs().max())), ("trunk", d, where)
+
+
+def test_batch_composition_is_independent(ctx):
+    """Frames of one source are independent: a frame's result must not depend on its batch-mates."""
+    G, fr = ctx["G"], ctx["fr"]
+    enc, res = G.encode_src(ctx["src_inputs"].cuda())
+    x, T, bg = fr["tsf_inputs"].cuda(), fr["T"].cuda(), ctx["bg_img"].cuda()
+    p2, _, _ = G.inference(enc, res, x, T, bg_img=bg)
+    p0, _, _ = G.inference(enc, res, x[:1], T[:1], bg_img=bg)
+    p1, _, _ = G.inference(enc, res, x[1:], T[1:], bg_img=bg)
+    assert torch.equal(p2[:1], p0) and torch.equal(p2[1:], p1)
+    # and the run is deterministic (no atomics in the statistics path)
+    p2b, _, _ = G.inference(enc, res, x, T, bg_img=bg)
+    assert torch.equal(p2, p2b)
+
+
+def test_nhwc8_input_path_equals_nchw(ctx):
+    """SMPLRenderer.transfer hands the generator an NHWC8-backed view; plain NCHW input must agree bitwise."""
+    G, r, s = ctx["G"], ctx["r"], ctx["s"]
+    out = r.transfer(helpers.t(s["tgt_cam"]).cuda(), helpers.t(s["tgt_verts"]).cuda(), ctx["p2v"].cuda(),
+                     ctx["src_img"].cuda())
+    enc, res = G.encode_src(ctx["src_inputs"].cuda())
+    x = out["tsf_inputs"]
+    assert x.shape == (2, 6, 256, 256) and x.stride()[1] == 1
+    ca, ma = G.inference(enc, res, x, out["T"])
+    cb, mb = G.inference(enc, res, x.contiguous(), out["T"])
+    assert torch.equal(ca, cb) and torch.equal(ma, mb)
+
+
+def test_swap_two_sources(ctx):
+    """ImpersonatorGenerator.swap (generator.py:245-275) against the oracle; reuses the source features twice."""
+    G, fr = ctx["G"], ctx["fr"]
+    enc, res = G.encode_src(ctx["src_inputs"].cuda())
+    T12 = fr["T"][:1]
+    T21 = fr["T"][1:].clamp(-2, 2)
+    color, mask = G.swap(fr["tsf_inputs"][:1].cuda(), enc, enc, res, res, T12.cuda(), T21.cuda())
+    with torch.no_grad():
+        oc, om = torch_ref.generator_swap(ctx["sd"], fr["tsf_inputs"][:1], ctx["o_enc"], ctx["o_enc"], ctx["o_res"],
+                                          ctx["o_res"], T12, T21)
+    assert helpers.maxdiff(color, oc)[0] <= TOL_IMAGE
+    assert helpers.maxdiff(mask, om)[0] <= TOL_IMAGE
+
+
+def test_align_corners_true_mode(ctx):
+    """Hazard H1: torch-1.2 semantics (align_corners=True) are selectable at run time."""
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    G2 = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, max_batch=1, align_corners=True)
+    G2.load_state_dict(ctx["sd"])
+    G2 = G2.cuda()
+    fr = ctx["fr"]
+    enc, res = G2.encode_src(ctx["src_inputs"].cuda())
+    color, mask = G2.inference(enc, res, fr["tsf_inputs"][:1].cuda(), fr["T"][:1].cuda())
+    with torch.no_grad():
+        oc, om = torch_ref.generator_inference(ctx["sd"], ctx["o_enc"], ctx["o_res"], fr["tsf_inputs"][:1],
+                                               fr["T"][:1], align_corners=True)
+    assert helpers.maxdiff(color, oc)[0] <= TOL_IMAGE and helpers.maxdiff(mask, om)[0] <= TOL_IMAGE
+    G2.release()
+
+
+def test_state_and_shape_errors(ctx):
+    from impersonator_amd import _lib
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    with pytest.raises(_lib.LwgError):
+        ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, conv_dim=32)._ensure_handle(1)
+    with pytest.raises(_lib.LwgError):
+        ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, image_size=96)._ensure_handle(1)
+    with pytest.raises(RuntimeError):
+        ctx["G"].encode_src(ctx["src_inputs"])   # CPU tensor: no silent fallback

@@ -1,0 +1,85 @@
+"""Pins oracle/torch_ref.py (the CPU restatement that travels to the GPU box) against the REAL reference
+imported from /root/reference.  Skipped where the reference tree is absent (the GPU box)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_loader, torch_ref
+from tests import helpers
+
+pytestmark = pytest.mark.skipif(not reference_loader.available(), reason="/root/reference not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return reference_loader.load()
+
+
+def test_state_dict_keys_match_reference(ref):
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    mine = [(k, tuple(v.shape)) for k, v in ImpersonatorGenerator(4, 6, 6).state_dict().items()]
+    theirs = [(k, tuple(v.shape)) for k, v in ref.generator.ImpersonatorGenerator(4, 6, 6).state_dict().items()]
+    assert mine == theirs
+
+
+def test_geometry_restatement_is_bit_identical(ref):
+    s = helpers.scene()
+    R = ref.nmr.SMPLRenderer
+    rs = types.SimpleNamespace(faces=helpers.t(s["faces"]), image_size=256, map_fn=helpers.t(s["map_fn"]),
+                               proj_func=ref.nmr.orthographic_proj_withz_idrot,
+                               eye=[0, 0, -(1. / np.tan(np.radians(30)) + 1)])
+    cam, verts = helpers.t(s["tgt_cam"]), helpers.t(s["tgt_verts"])
+    f2v, fim, wim = R.render_fim_wim(rs, cam, verts)
+    of2v, ofim, owim = torch_ref.render_fim_wim(cam, verts, helpers.t(s["faces"]))
+    assert torch.equal(f2v, of2v) and torch.equal(fim, ofim) and torch.equal(wim, owim)
+    cond, _ = R.encode_fim(rs, cam, verts, fim=fim, transpose=True)
+    assert torch.equal(cond, torch_ref.encode_fim(ofim, helpers.t(s["map_fn"])))
+    p2v = torch_ref.source_p2verts(f2v[:1])
+    T = torch.cat([R.cal_bc_transform(rs, p2v, fim[i:i + 1], wim[i:i + 1]) for i in range(2)])
+    assert torch.equal(T, torch_ref.cal_bc_transform(p2v, ofim, owim))
+    assert torch.equal(ref.util.morph(cond[:, -1:], ks=3, mode="erode"), torch_ref.morph(cond[:, -1:], 3, "erode"))
+    assert torch.equal(ref.util.morph(cond[:, -1:], ks=13, mode="dilate"), torch_ref.morph(cond[:, -1:], 13, "dilate"))
+
+
+def test_generator_restatement_matches_reference_small(ref):
+    # a 64x64 problem keeps this fast; the full-size pass is pinned by tests/golden/frame_golden.npz
+    G = ref.generator.ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6).eval()
+    sd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=1))
+    G.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(0)
+    src = torch.rand(1, 6, 64, 64, generator=gen) * 2 - 1
+    tsf = torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1
+    T = torch.rand(2, 64, 64, 2, generator=gen) * 2.4 - 1.2
+    T[0, 20:40, 10:30] = -2
+    with torch.no_grad():
+        enc, res = G.encode_src(src)
+        o_enc, o_res = torch_ref.encode_src(sd, src)
+        for a, b in zip(enc + res, o_enc + o_res):
+            assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+        for i in range(2):
+            c, m = G.inference(enc, res, tsf[i:i + 1], T[i:i + 1])
+            oc, om = torch_ref.generator_inference(sd, o_enc, o_res, tsf[i:i + 1], T[i:i + 1])
+            assert torch.allclose(c, oc, atol=1e-5) and torch.allclose(m, om, atol=1e-5)
+        c, m = G.swap(tsf[:1], enc, enc, res, res, T[:1], T[1:])
+        oc, om = torch_ref.generator_swap(sd, tsf[:1], o_enc, o_enc, o_res, o_res, T[:1], T[1:])
+        assert torch.allclose(c, oc, atol=1e-5) and torch.allclose(m, om, atol=1e-5)
+        # batching target frames over one source (this build's extension) equals the reference's batch-1 loop
+        oc2, om2 = torch_ref.generator_inference(sd, o_enc, o_res, tsf, T)
+        c0, m0 = G.inference(enc, res, tsf[:1], T[:1])
+        assert torch.allclose(oc2[:1], c0, atol=1e-5) and torch.allclose(om2[:1], m0, atol=1e-5)
+
+
+def test_golden_frame_is_reproduced_by_the_oracle():
+    """The committed golden (made by the real reference) equals what the travelling oracle computes."""
+    g = helpers.golden("frame_golden.npz")
+    s = helpers.scene()
+    faces_t = helpers.t(s["faces"])
+    sf2v, sfim, _ = torch_ref.render_fim_wim(helpers.t(s["src_cam"]), helpers.t(s["src_verts"]), faces_t)
+    assert np.array_equal(sfim.numpy(), g["src_fim"])
+    fr = torch_ref.transfer_frame(helpers.t(s["src_img"]), torch_ref.source_p2verts(sf2v), helpers.t(s["tgt_cam"]),
+                                  helpers.t(s["tgt_verts"]), faces_t, helpers.t(s["map_fn"]))
+    assert np.array_equal(fr["fim"].numpy(), g["fim"])
+    assert np.array_equal(fr["wim"].numpy()[g["fim"] >= 0], g["wim_covered"])
+    assert np.abs(fr["T"].numpy() - g["T"]).max() <= 1e-6
