@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the Imitator.forward() hot path on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of 8 synthetic 256x256 target frames of ONE personalised
+source (BASELINE.json configs[1]): camera policy -> SMPL vertices -> project/rasterise -> cond, flow T, warped
+source (one fused launch sequence) -> tsf ResUnet with the Liquid Warping Block adds -> tanh/sigmoid heads and the
+background blend.  Inputs (SMPL vectors, source image, cached source features) are resident in HBM before the timed
+region; the per-batch device->host copy of the result is outside it.  Every rank runs the same per-GPU work on its
+own frames (weak scaling, no data-path collective).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the implicit-GEMM conv kernel (exact-fp32 MFMA), algorithmic FLOP / HIP-event time of its launches
+  cpu_baseline : the CPU oracle (port of the reference's PyTorch path + C rasteriser) timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from impersonator_amd import demo, sharding  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BATCH = 8
+IMAGE_SIZE = 256
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--frames", type=int, default=1024, help="length of the synthetic reference sequence")
+    p.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
+    p.add_argument("--no-roofline", action="store_true", help="skip the HIP-event pass over the conv kernel")
+    return p.parse_args()
+
+
+def cpu_baseline(seed=0, batches=3):
+    """Times the CPU oracle (kind 'port': oracle/torch_ref.py + oracle/raster_ref.c, see their headers) on the same
+    workload: one warm-up + `batches` batches of 8 frames, all host cores."""
+    from oracle import torch_ref
+    from impersonator_amd.networks.batch_smpl import HumanModelRecovery, synthetic_smpl_params
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    from impersonator_amd.utils import synthetic
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rest, faces = synthetic.body_mesh()
+    faces_t = torch.from_numpy(faces)
+    map_fn = torch.from_numpy(synthetic.uv_seg_map_fn(rest, faces))
+    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6)
+    shapes = [(k, tuple(v.shape)) for k, v in G.state_dict().items()]
+    sd = torch_ref.state_dict_from_numpy(synthetic.random_state_dict(shapes, seed=seed, affine="identity"))
+    hmr = HumanModelRecovery(smpl_params=synthetic_smpl_params(seed))
+    src_smpl = torch.from_numpy(demo.synthetic_smpls(1, seed + 1))
+    src_smpl[:, 3:75] = 0
+    src_img = torch.from_numpy(synthetic.smooth_image(seed + 11))
+    bg_img = torch.from_numpy(synthetic.smooth_image(seed + 12))
+    smpls = torch.from_numpy(demo.synthetic_smpls(1024, seed))
+    with torch.no_grad():
+        si = hmr.get_details(src_smpl)
+        sf2v, sfim, _ = torch_ref.render_fim_wim(si["cam"], si["verts"], faces_t)
+        p2v = torch_ref.source_p2verts(sf2v)
+        scond = torch_ref.encode_fim(sfim, map_fn)
+        ft = 1 - torch_ref.morph(scond[:, -1:], 3, "erode")
+        enc, res = torch_ref.encode_src(sd, torch.cat([src_img * ft, scond], 1))
+
+        def one_batch(b):
+            chunk = smpls[b * BATCH:(b + 1) * BATCH]
+            cam = si["cam"].expand(BATCH, -1).clone()
+            cam[:, 1:] += chunk[:, 1:3] - smpls[0:1, 1:3]
+            info = hmr.get_details(torch.cat([cam, chunk[:, 3:75], si["shape"].expand(BATCH, -1)], 1))
+            fr = torch_ref.transfer_frame(src_img, p2v, info["cam"], info["verts"], faces_t, map_fn)
+            return torch_ref.imitator_forward(sd, enc, res, bg_img, fr["tsf_inputs"], fr["T"])[0]
+
+        one_batch(0)
+        t0 = time.perf_counter()
+        for b in range(1, batches + 1):
+            one_batch(b)
+        dt = time.perf_counter() - t0
+    return {"value": round(batches * BATCH / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d batches of %d frames (256x256) after 1 warm-up batch, torch %s CPU fp32 + OpenMP C rasteriser"
+                      % (batches, BATCH, torch.__version__)}
+
+
+def main():
+    args = parse()
+    rank, local_rank, world = sharding.init_process_group()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=BATCH, seed=0, image_size=IMAGE_SIZE)
+    imitator.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+    smpls = torch.from_numpy(demo.synthetic_smpls(args.frames, seed=0)).to(dev)
+    imitator.first_cam = smpls[0:1, 0:3].clone()
+    blocks = sharding.shard_blocks(args.frames, BATCH, rank, world)
+
+    def step(i):
+        s, e = blocks[i % len(blocks)]
+        tsf_inputs = imitator.transfer_params_by_smpl(smpls[s:e], "smooth", t=s)
+        return imitator.forward(tsf_inputs, imitator.tsf_info["T"])
+
+    for i in range(args.warmup):
+        step(i)
+    sharding.barrier(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    sharding.barrier(dev)
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else "cpu")
+    assert bool(torch.isfinite(out).all())
+
+    roofline = None
+    if not args.no_roofline:
+        # same steps again with HIP events around every launch of the implicit-GEMM kernel (on its launch stream)
+        imitator.generator.profile(True)
+        for i in range(args.steps):
+            step(args.warmup + i)
+        n, ms, flops = imitator.generator.profile_read()
+        imitator.generator.profile(False)
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_f32", "achieved": round(achieved, 3),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
+                    "flop_per_launch": flops / max(n, 1)}
+
+    if rank == 0:
+        frames = world * BATCH * args.steps
+        line = {
+            "metric": "frames/sec (256x256 motion-imitation, batch=8)",
+            "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Imitator inference 256x256 batch=8, random-init ImpersonatorGenerator (tsf ResUnet, "
+                                   "105.58 GFLOP/frame) + synthetic SMPL (6890 verts / 13776 faces), 1 source, "
+                                   "%d-frame synthetic reference sequence" % args.frames,
+                       "batch_per_gpu": BATCH, "image_size": IMAGE_SIZE, "parallelism": "frame-sharded replicas x%d" % world,
+                       "grid_sample_align_corners": False},
+        }
+        if roofline is not None:
+            line["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,252 @@
+"""Imitator (motion imitation) on MI355X -- the reference's task model surface (models/imitator.py:14-342).
+
+Same public methods and side effects:
+    Imitator(opt), personalize(src_path, src_smpl=None, output_path='', visualizer=None),
+    inference(tgt_paths, tgt_smpls=None, cam_strategy='smooth', output_dir='', visualizer=None, verbose=True),
+    inference_by_smpls(tgt_smpls, cam_strategy='smooth', output_dir='', visualizer=None),
+    swap_smpl, transfer_params_by_smpl, transfer_params, forward(tsf_inputs, T), warp_front
+with `self.src_info` / `self.tsf_info` carrying the reference's keys.
+
+What changed underneath: the reference walks frames one by one in Python (imitator.py:166), syncing the device
+every frame; here frames of one source are independent given the cached source features, so `inference*`
+groups them into batches of `opt.batch_size` and each batch is ONE launch sequence in liblwg
+(SMPLRenderer.transfer + ImpersonatorGenerator.inference with the blend fused), with one device->host copy
+per batch.  `first_cam` (imitator.py:243-244) is taken from frame 0 up front instead of being discovered at t == 0.
+"""
+import os
+
+import numpy as np
+import torch
+
+from ..networks.networks import NetworksFactory
+from ..utils import cv_utils, util
+from ..utils.nmr import SMPLRenderer
+from .models import BaseModel
+
+
+class Imitator(BaseModel):
+    def __init__(self, opt, hmr=None, render=None, generator=None, bgnet=None):
+        """`opt` as produced by options.test_options.TestOptions.  The keyword arguments (extension) inject
+        pre-built components -- used for the synthetic configuration where the reference's downloaded assets
+        (SMPL pickle, UV mapper, checkpoints) do not exist."""
+        super().__init__(opt)
+        self._name = 'Imitator'
+        self._create_networks(hmr, render, generator, bgnet)
+        self.src_info = None
+        self.tsf_info = None
+        self.first_cam = None
+
+    # ------------------------------------------------------------------ construction (imitator.py:26-74)
+    def _create_networks(self, hmr, render, generator, bgnet):
+        opt = self._opt
+        self.generator = (generator if generator is not None else self._create_generator()).cuda()
+        if bgnet is not None:
+            self.bgnet = bgnet
+        elif getattr(opt, 'bg_model', 'ORIGINAL') != 'ORIGINAL':
+            self.bgnet = self._create_bgnet()
+        else:
+            self.bgnet = None  # bg_model == 'ORIGINAL' would run generator.bg_model (BGNet): not on this path yet
+        self.hmr = (hmr if hmr is not None else self._create_hmr()).cuda()
+        if render is None:
+            render = SMPLRenderer(image_size=opt.image_size, tex_size=opt.tex_size, has_front=opt.front_warp,
+                                  fill_back=False, align_corners=getattr(opt, 'align_corners', False))
+        self.render = render.cuda()
+        self.detector = None
+        if getattr(opt, 'has_detector', False):
+            raise NotImplementedError("--has_detector (torchvision Mask-RCNN, utils/detectors.py) is outside the "
+                                      "Imitator.forward() path")
+
+    def _create_bgnet(self):
+        raise NotImplementedError("InpaintSANet (networks/inpaintor.py) runs once per source and is the next row of the "
+                                  "hot-path scope table; pass bg_img to personalize() or inject bgnet=")
+
+    def _create_generator(self):
+        opt = self._opt
+        net = NetworksFactory.get_by_name(opt.gen_name, bg_dim=4, src_dim=3 + self._G_cond_nc,
+                                          tsf_dim=3 + self._G_cond_nc, repeat_num=opt.repeat_num,
+                                          image_size=opt.image_size, max_batch=max(1, opt.batch_size),
+                                          align_corners=getattr(opt, 'align_corners', False))
+        if opt.load_path:
+            self._load_params(net, opt.load_path)
+        else:
+            raise ValueError('load_path {} is empty and load_epoch {} is 0'.format(opt.load_path, opt.load_epoch))
+        net.eval()
+        return net
+
+    def _create_hmr(self):
+        from ..networks.batch_smpl import HumanModelRecovery
+        return HumanModelRecovery(self._opt.smpl_model).eval()
+
+    def visualize(self, *args, **kwargs):
+        visualizer = args[0]
+        if visualizer is not None:
+            for key, value in kwargs.items():
+                visualizer.vis_named_img(key, value)
+
+    # ------------------------------------------------------------------ once per source (imitator.py:82-145)
+    def _load_image(self, src, size):
+        """path | HxWx3 uint8 array | (3,H,W) float array in [-1,1] -> (1,3,size,size) cuda tensor, original image."""
+        if isinstance(src, str):
+            ori = cv_utils.read_cv2_img(src)
+        else:
+            ori = src
+        if torch.is_tensor(ori):
+            return ori.float().cuda().reshape(1, 3, size, size), ori
+        ori = np.asarray(ori)
+        if ori.dtype != np.uint8:
+            return torch.tensor(ori, dtype=torch.float32).cuda().reshape(1, 3, size, size), ori
+        img = cv_utils.transform_img(ori, size, transpose=True) * 2 - 1.0
+        return torch.tensor(img, dtype=torch.float32).cuda()[None, ...], ori
+
+    @torch.no_grad()
+    def personalize(self, src_path, src_smpl=None, output_path='', visualizer=None, bg_img=None):
+        opt = self._opt
+        img, ori_img = self._load_image(src_path, opt.image_size)
+        if src_smpl is None:
+            raise NotImplementedError("estimating SMPL from the image needs the HMR regressor (networks/hmr.py), "
+                                      "which is outside the Imitator.forward() path; pass src_smpl")
+        src_smpl = torch.as_tensor(np.asarray(src_smpl), dtype=torch.float32).cuda().reshape(1, -1)
+
+        src_info = self.hmr.get_details(src_smpl)
+        src_f2verts, src_fim, src_wim = self.render.render_fim_wim(src_info['cam'], src_info['verts'])
+        src_info['fim'] = src_fim
+        src_info['wim'] = src_wim
+        src_info['cond'], _ = self.render.encode_fim(src_info['cam'], src_info['verts'], fim=src_fim, transpose=True)
+        src_info['f2verts'] = src_f2verts
+        # hazard H9 (imitator.py:105-107): p2verts is a VIEW of f2verts and the y flip mutates f2verts too
+        src_info['p2verts'] = src_f2verts[:, :, :, 0:2]
+        src_info['p2verts'][:, :, :, 1] *= -1
+        if opt.only_vis:
+            src_info['p2verts'] = self.render.get_vis_f2pts(src_info['p2verts'], src_fim)
+        src_info['img'] = img
+        src_info['image'] = ori_img
+
+        bg_mask = util.morph(src_info['cond'][:, -1:, :, :], ks=opt.bg_ks, mode='erode')
+        body_mask = 1 - bg_mask
+        if bg_img is not None:
+            src_info['bg'] = torch.as_tensor(bg_img, dtype=torch.float32).cuda().reshape(1, 3, opt.image_size, opt.image_size)
+        elif self.bgnet is not None:
+            src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)
+        else:
+            raise NotImplementedError("no background network: pass bg_img (see _create_bgnet)")
+
+        ft_mask = 1 - util.morph(src_info['cond'][:, -1:, :, :], ks=opt.ft_ks, mode='erode')
+        src_inputs = torch.cat([img * ft_mask, src_info['cond']], dim=1)
+        src_info['feats'] = self.generator.encode_src(src_inputs)
+        # contiguous copy of the (nf,3,2) source face vertices for the fused per-frame kernel
+        src_info['p2verts_c'] = src_info['p2verts'].contiguous()
+        self.src_info = src_info
+
+        if visualizer is not None:
+            visualizer.vis_named_img('src', img)
+            visualizer.vis_named_img('bg', src_info['bg'])
+        if output_path:
+            cv_utils.save_cv2_img(np.asarray(src_info['image']), output_path, image_size=opt.image_size)
+
+    # ------------------------------------------------------------------ per frame (imitator.py:216-268)
+    def swap_smpl(self, src_cam, src_shape, tgt_smpl, cam_strategy='smooth'):
+        """imitator.py:216-234.  All arguments may carry a batch of frames (the source rows broadcast)."""
+        n = tgt_smpl.shape[0]
+        tgt_cam = tgt_smpl[:, 0:3].contiguous()
+        pose = tgt_smpl[:, 3:75].contiguous()
+        if cam_strategy == 'smooth':
+            cam = src_cam.expand(n, -1).clone()
+            cam[:, 1:] += tgt_cam[:, 1:] - self.first_cam[:, 1:]
+        elif cam_strategy == 'source':
+            cam = src_cam.expand(n, -1)
+        else:
+            cam = tgt_cam
+        return torch.cat([cam, pose, src_shape.expand(n, -1)], dim=1)
+
+    @torch.no_grad()
+    def transfer_params_by_smpl(self, tgt_smpl, cam_strategy='smooth', t=0):
+        """imitator.py:236-268 for one frame (85,) or a batch (n,85); sets self.tsf_info, returns tsf_inputs."""
+        src_info = self.src_info
+        if isinstance(tgt_smpl, np.ndarray):
+            tgt_smpl = torch.tensor(tgt_smpl).float()
+        tgt_smpl = tgt_smpl.float().cuda()
+        if tgt_smpl.dim() == 1:
+            tgt_smpl = tgt_smpl[None, ...]
+        if t == 0 and cam_strategy == 'smooth':
+            self.first_cam = tgt_smpl[0:1, 0:3].clone()
+
+        tsf_smpl = self.swap_smpl(src_info['cam'], src_info['shape'], tgt_smpl, cam_strategy=cam_strategy)
+        tsf_info = self.hmr.get_details(tsf_smpl)
+        out = self.render.transfer(tsf_info['cam'], tsf_info['verts'], src_info['p2verts_c'], src_info['img'])
+        tsf_info['fim'] = out['fim']
+        tsf_info['wim'] = out['wim']
+        tsf_info['cond'] = out['cond']
+        tsf_info['tsf_img'] = out['tsf_img']
+        tsf_info['T'] = out['T']
+        self.tsf_info = tsf_info
+        return out['tsf_inputs']
+
+    def transfer_params(self, tgt_path, tgt_smpl=None, cam_strategy='smooth', t=0):
+        """imitator.py:270-283."""
+        if tgt_smpl is None:
+            raise NotImplementedError("estimating SMPL from target images needs the HMR regressor; pass tgt_smpl")
+        tsf_inputs = self.transfer_params_by_smpl(tgt_smpl=tgt_smpl, cam_strategy=cam_strategy, t=t)
+        self.tsf_info['image'] = cv_utils.read_cv2_img(tgt_path) if isinstance(tgt_path, str) and tgt_path else None
+        return tsf_inputs
+
+    @torch.no_grad()
+    def forward(self, tsf_inputs, T):
+        """imitator.py:326-336: pred = mask*bg + (1-mask)*color, blend fused into the generator's last kernel."""
+        src_encoder_outs, src_resnet_outs = self.src_info['feats']
+        pred_imgs, _, tsf_mask = self.generator.inference(src_encoder_outs, src_resnet_outs, tsf_inputs, T,
+                                                          bg_img=self.src_info['bg'])
+        if self._opt.front_warp:
+            pred_imgs = self.warp_front(pred_imgs, tsf_mask)
+        return pred_imgs
+
+    def warp_front(self, preds, mask):
+        """imitator.py:338-342."""
+        front_mask = self.render.encode_front_fim(self.tsf_info['fim'], transpose=True, front_fn=True)
+        return (1 - front_mask) * preds + self.tsf_info['tsf_img'] * front_mask * (1 - mask)
+
+    # ------------------------------------------------------------------ drivers (imitator.py:157-214)
+    def _run_batches(self, tgt_smpls, cam_strategy, on_batch):
+        smpls = torch.as_tensor(np.asarray(tgt_smpls), dtype=torch.float32).reshape(len(tgt_smpls), -1)
+        bs = max(1, int(self._opt.batch_size))
+        outputs = []
+        if cam_strategy == 'smooth' and len(smpls):
+            self.first_cam = smpls[0:1, 0:3].clone().cuda()
+        for s in range(0, len(smpls), bs):
+            chunk = smpls[s:s + bs]
+            tsf_inputs = self.transfer_params_by_smpl(chunk, cam_strategy, t=s)
+            preds = self.forward(tsf_inputs, self.tsf_info['T'])
+            host = preds.permute(0, 2, 3, 1).cpu().numpy()   # one device->host copy per batch
+            for i in range(host.shape[0]):
+                outputs.append(host[i])
+                on_batch(s + i, host[i], preds[i:i + 1])
+        return outputs
+
+    @torch.no_grad()
+    def inference(self, tgt_paths, tgt_smpls=None, cam_strategy='smooth', output_dir='', visualizer=None,
+                  verbose=True):
+        """imitator.py:157-189 -> list of (H,W,3) float arrays in [-1,1]."""
+        if tgt_smpls is None:
+            raise NotImplementedError("estimating SMPL from target images needs the HMR regressor; pass tgt_smpls")
+
+        def sink(t, pred, pred_dev):
+            if visualizer is not None:
+                visualizer.vis_named_img('pred_' + cam_strategy, pred_dev)
+            if output_dir:
+                filename = os.path.split(tgt_paths[t])[-1] if tgt_paths and tgt_paths[t] else 'pred_%.8d.jpg' % t
+                cv_utils.save_cv2_img(pred, os.path.join(output_dir, 'pred_' + filename), normalize=True)
+
+        return self._run_batches(tgt_smpls, cam_strategy, sink)
+
+    @torch.no_grad()
+    def inference_by_smpls(self, tgt_smpls, cam_strategy='smooth', output_dir='', visualizer=None):
+        """imitator.py:191-214."""
+        def sink(t, pred, pred_dev):
+            if visualizer is not None:
+                visualizer.vis_named_img('pred_' + cam_strategy, pred_dev)
+            if output_dir:
+                cv_utils.save_cv2_img(pred, os.path.join(output_dir, 'pred_%.8d.jpg' % t), normalize=True)
+
+        return self._run_batches(tgt_smpls, cam_strategy, sink)
+
+    def post_personalize(self, *args, **kwargs):
+        raise NotImplementedError("post_personalize is a fine-tuning (training) loop (imitator.py:344-472): out of scope")

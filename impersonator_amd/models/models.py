@@ -1,0 +1,50 @@
+"""Model factory / base class with the reference's names (models/models.py:7-203), inference subset."""
+import os
+from collections import OrderedDict
+
+import torch
+
+
+class ModelsFactory(object):
+    @staticmethod
+    def get_by_name(model_name, *args, **kwargs):
+        if model_name == 'imitator':
+            from .imitator import Imitator
+            return Imitator(*args, **kwargs)
+        raise ValueError("Model %s is not part of the MI355X Imitator.forward path" % model_name)
+
+
+class BaseModel(object):
+    def __init__(self, opt):
+        self._name = 'BaseModel'
+        self._opt = opt
+        self._is_train = getattr(opt, 'is_train', False)
+        self._G_cond_nc = self._cond_nc(getattr(opt, 'map_name', 'uv_seg'))
+
+    @staticmethod
+    def _cond_nc(map_name):
+        # models/models.py:85-94 -> utils/mesh.py:446-473: channel count of the face->condition table
+        if map_name in ('uv_seg', 'uv'):
+            return 3
+        if map_name == 'par':
+            return 11  # 10 body parts + background
+        raise ValueError("map_name %s not supported" % map_name)
+
+    @property
+    def name(self):
+        return self._name
+
+    @staticmethod
+    def _load_params(network, load_path, need_module=False):
+        """models/models.py:159-179: load a checkpoint, stripping DataParallel's 'module.' prefix."""
+        assert os.path.exists(load_path), \
+            'Weights file not found. Have you trained a model!? We are not providing one %s' % load_path
+        save_data = torch.load(load_path, map_location='cpu')
+        if need_module:
+            network.load_state_dict(save_data)
+        else:
+            state_dict = OrderedDict()
+            for k, v in save_data.items():
+                state_dict[k[7:] if 'module' in k else k] = v
+            network.load_state_dict(state_dict)
+        print('Loading net: %s' % load_path)

@@ -1,0 +1,151 @@
+"""SMPL body model with the reference's interface (networks/batch_smpl.py:229-375).
+
+Row "f1 / next" of the hot-path scope: per frame it is ~0.02 GFLOP of small GEMMs
+in front of the rasteriser, so this round keeps it as PyTorch-ROCm tensor ops (device memory plumbing);
+everything downstream of the vertices is liblwg.  The parameters come from `smpl_model.pkl` when present
+(README.md:48-68 of the reference: a download) or from a seeded synthetic model with the same tensor shapes.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..utils import synthetic
+from ..utils.util import load_pickle_file
+
+# SMPL kinematic tree (kintree_table[0] of smpl_model.pkl)
+SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], np.int32)
+
+
+def synthetic_smpl_params(seed=0):
+    """A stand-in with SMPL's shapes: 6890 vertices, 10 betas, 24 joints, 207 pose features, 19 keypoints."""
+    rng = np.random.default_rng(seed + 4242)
+    rest, faces = synthetic.body_mesh()
+    nv = rest.shape[0]
+    # 24 joints spread along the body axis with small lateral offsets
+    jy = np.linspace(-0.75, 0.75, 24)
+    joints = np.stack([0.08 * np.sin(np.arange(24) * 1.7), jy, 0.03 * np.cos(np.arange(24) * 2.3)], 1)
+    d2 = ((rest[:, None, :].astype(np.float64) - joints[None]) ** 2).sum(-1)
+    w = np.exp(-d2 / (2 * 0.08 ** 2))
+    w /= w.sum(1, keepdims=True)
+    jr = np.exp(-d2 / (2 * 0.05 ** 2)).T
+    jr /= jr.sum(1, keepdims=True)
+    coco = np.exp(-d2[:, :19] / (2 * 0.06 ** 2)).T
+    coco /= coco.sum(1, keepdims=True)
+    smooth = np.sin(rest.astype(np.float64) @ rng.normal(0, 3.0, (3, 10)))          # (nv,10)
+    shapedirs = (smooth[:, None, :] * rng.normal(0, 0.01, (1, 3, 10)))              # (nv,3,10)
+    posedirs = rng.normal(0, 1e-3, (nv, 3, 207))
+    return dict(v_template=rest.astype(np.float64), f=faces.astype(np.int64), shapedirs=shapedirs,
+                J_regressor=jr, posedirs=posedirs, kintree_table=np.stack([SMPL_PARENTS, np.arange(24)]),
+                weights=w, cocoplus_regressor=coco)
+
+
+def batch_rodrigues(theta):
+    """networks/batch_smpl.py:64-101: axis-angle (N,3) -> rotation matrices (N,3,3)."""
+    n = theta.shape[0]
+    angle = torch.norm(theta + 1e-8, p=2, dim=1, keepdim=True)
+    r = (theta / angle).unsqueeze(-1)
+    angle = angle.unsqueeze(-1)
+    cos, sin = torch.cos(angle), torch.sin(angle)
+    outer = torch.matmul(r, r.permute(0, 2, 1))
+    eye = torch.eye(3, dtype=theta.dtype, device=theta.device).unsqueeze(0).expand(n, 3, 3)
+    rx, ry, rz = r[:, 0, 0], r[:, 1, 0], r[:, 2, 0]
+    zero = torch.zeros_like(rx)
+    skew = torch.stack([zero, -rz, ry, rz, zero, -rx, -ry, rx, zero], dim=1).view(n, 3, 3)
+    return cos * eye + (1 - cos) * outer + sin * skew
+
+
+def batch_global_rigid_transformation(Rs, Js, parent):
+    """networks/batch_smpl.py:129-218 (rotate_base=False): world transforms of the 24 joints."""
+    n = Rs.shape[0]
+    Js = Js.unsqueeze(-1)
+
+    def make_A(R, t):
+        top = torch.cat([R, t], dim=2)
+        bottom = torch.tensor([0., 0., 0., 1.], dtype=R.dtype, device=R.device).view(1, 1, 4).expand(n, 1, 4)
+        return torch.cat([top, bottom], dim=1)
+
+    results = [make_A(Rs[:, 0], Js[:, 0])]
+    for i in range(1, parent.shape[0]):
+        j_here = Js[:, i] - Js[:, parent[i]]
+        results.append(torch.matmul(results[parent[i]], make_A(Rs[:, i], j_here)))
+    results = torch.stack(results, dim=1)
+    new_J = results[:, :, :3, 3]
+    Js_w0 = torch.cat([Js, torch.zeros(n, 24, 1, 1, dtype=Rs.dtype, device=Rs.device)], dim=2)
+    init_bone = torch.matmul(results, Js_w0)
+    init_bone = torch.nn.functional.pad(init_bone, (3, 0, 0, 0, 0, 0, 0, 0))
+    return new_J, results - init_bone
+
+
+def batch_orth_proj_idrot(X, camera):
+    """networks/batch_smpl.py:221-234."""
+    return camera[:, None, 0:1] * (X[:, :, :2] + camera[:, None, 1:])
+
+
+class SMPL(nn.Module):
+    def __init__(self, pkl_path=None, rotate=False, params=None):
+        super().__init__()
+        if rotate:
+            raise NotImplementedError("rotate_base is never enabled on the Imitator path")
+        if params is None:
+            if pkl_path is None or not os.path.exists(pkl_path):
+                raise FileNotFoundError("SMPL model %s not found; pass params=synthetic_smpl_params()" % pkl_path)
+            dd = load_pickle_file(pkl_path)
+            params = dict(v_template=np.asarray(dd['v_template']), f=np.asarray(dd['f']),
+                          shapedirs=np.asarray(dd['shapedirs']), J_regressor=np.asarray(dd['J_regressor'].todense()),
+                          posedirs=np.asarray(dd['posedirs']), kintree_table=np.asarray(dd['kintree_table']),
+                          weights=np.asarray(dd['weights']),
+                          cocoplus_regressor=np.asarray(dd['cocoplus_regressor'].todense()))
+        f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+        self.faces = torch.from_numpy(np.asarray(params['f']).astype(np.int32))
+        self.register_buffer('v_template', f32(params['v_template']))
+        self.size = [self.v_template.shape[0], 3]
+        self.num_betas = params['shapedirs'].shape[-1]
+        self.register_buffer('shapedirs', f32(np.reshape(params['shapedirs'], [-1, self.num_betas]).T))
+        self.register_buffer('J_regressor', f32(np.asarray(params['J_regressor']).T))
+        npose = params['posedirs'].shape[-1]
+        self.register_buffer('posedirs', f32(np.reshape(params['posedirs'], [-1, npose]).T))
+        self.parents = np.asarray(params['kintree_table'][0]).astype(np.int32)
+        self.register_buffer('weights', f32(params['weights']))
+        self.register_buffer('joint_regressor', f32(np.asarray(params['cocoplus_regressor']).T))
+
+    def forward(self, beta, theta, get_skin=False):
+        """networks/batch_smpl.py:285-375."""
+        n = beta.shape[0]
+        nv = self.size[0]
+        v_shaped = torch.matmul(beta, self.shapedirs).view(-1, nv, 3) + self.v_template
+        J = torch.stack([torch.matmul(v_shaped[:, :, k], self.J_regressor) for k in range(3)], dim=2)
+        Rs = batch_rodrigues(theta.reshape(-1, 3)).view(-1, 24, 3, 3)
+        pose_feature = (Rs[:, 1:] - torch.eye(3, device=beta.device)).view(-1, 207)
+        v_posed = torch.matmul(pose_feature, self.posedirs).view(-1, nv, 3) + v_shaped
+        _, A = batch_global_rigid_transformation(Rs, J, self.parents)
+        W = self.weights.unsqueeze(0).expand(n, -1, -1)
+        T = torch.matmul(W, A.view(n, 24, 16)).view(n, -1, 4, 4)
+        v_homo = torch.cat([v_posed, torch.ones(n, nv, 1, dtype=torch.float32, device=beta.device)], dim=2)
+        verts = torch.matmul(T, v_homo.unsqueeze(-1))[:, :, :3, 0]
+        joints = torch.stack([torch.matmul(verts[:, :, k], self.joint_regressor) for k in range(3)], dim=2)
+        if get_skin:
+            return verts, joints, Rs
+        return joints
+
+
+class HumanModelRecovery(nn.Module):
+    """The part of networks/hmr.py on the Imitator path when target SMPL vectors are given:
+    `get_details` (hmr.py:302-330).  The image -> theta ResNet-50 regressor is out of scope."""
+
+    def __init__(self, smpl_pkl_path=None, smpl_params=None):
+        super().__init__()
+        self.smpl = SMPL(smpl_pkl_path, params=smpl_params)
+
+    def forward(self, inputs):
+        raise NotImplementedError("the HMR image regressor (networks/hmr.py:200-300) is not part of the "
+                                  "Imitator.forward() path; pass src_smpl / tgt_smpls")
+
+    def get_details(self, theta):
+        cam = theta[:, 0:3].contiguous()
+        pose = theta[:, 3:75].contiguous()
+        shape = theta[:, 75:].contiguous()
+        verts, j3d, _ = self.smpl(beta=shape, theta=pose, get_skin=True)
+        return {'theta': theta, 'cam': cam, 'pose': pose, 'shape': shape, 'verts': verts,
+                'j2d': batch_orth_proj_idrot(j3d, cam), 'j3d': j3d}

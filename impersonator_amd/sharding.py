@@ -1,0 +1,83 @@
+"""Frame sharding across the GPUs of one node.
+
+After `personalize`, frame t depends only on the cached source features, the background, the source face
+vertices, tgt_smpl[t] and `first_cam` (= tgt_smpl[0][:3]).  So motion imitation shards embarrassingly:
+one process per GPU, each with a full replica of weights + cached source features, round-robin blocks of
+`batch` consecutive frames, NO data-path collective.  torch.distributed (RCCL on GPUs, gloo in the CPU
+tests) is used only for the timing barrier / max-over-ranks and to collect outputs in frame order.
+The reference has no multi-GPU inference at all (it hard-codes `.cuda()` and loops frames, imitator.py:166).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment; (0, 0, 1) standalone."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
+            int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def init_process_group(backend=None):
+    """Initialises torch.distributed when launched under torchrun; returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def frame_blocks(num_frames, batch):
+    """[(start, end)) blocks of `batch` consecutive frames covering 0..num_frames."""
+    return [(s, min(s + batch, num_frames)) for s in range(0, num_frames, batch)]
+
+
+def shard_blocks(num_frames, batch, rank, world):
+    """Blocks owned by `rank`: block b goes to rank b % world (round-robin keeps ranks within one block of each other)."""
+    return [blk for i, blk in enumerate(frame_blocks(num_frames, batch)) if i % world == rank]
+
+
+def barrier(device=None):
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX all-reduce of a python float (the step time every rank must wait for)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_in_frame_order(local_items, num_frames, batch, rank, world):
+    """local_items: this rank's per-frame outputs in the order of shard_blocks().  Returns the full
+    frame-ordered list on rank 0 (None elsewhere)."""
+    if world == 1 or not dist.is_initialized():
+        return list(local_items)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(list(local_items), gathered, dst=0)
+    if rank != 0:
+        return None
+    out = [None] * num_frames
+    for r in range(world):
+        it = iter(gathered[r])
+        for (s, e) in shard_blocks(num_frames, batch, r, world):
+            for t in range(s, e):
+                out[t] = next(it)
+    return out

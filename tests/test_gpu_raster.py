@@ -138,10 +138,10 @@ def test_grid_sample_and_resize(align):
     out = G.stn(x.cuda(), grid.cuda())
     ref = torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=align)
     d, where = helpers.maxdiff(out, ref)
-    assert d <= 2e-6, (d, where)
+    assert d <= 1e-5, (d, where)   # |x| reaches ~4: a few ulp of the 4-tap sum
     out1 = G.stn(x[:1].cuda(), grid.cuda())   # shared source broadcast
     ref1 = torch.nn.functional.grid_sample(x[:1].expand(2, -1, -1, -1), grid, align_corners=align)
-    assert helpers.maxdiff(out1, ref1)[0] <= 2e-6
+    assert helpers.maxdiff(out1, ref1)[0] <= 1e-5
 
     T = torch.rand(2, 64, 64, 2, generator=gen) * 2 - 1
     T[0, 10:20, 10:30] = -2.0

@@ -1,0 +1,75 @@
+"""CPU checks of the Python host code that wraps the C ABI (no device work)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from impersonator_amd import demo
+from impersonator_amd.utils import synthetic, util
+from oracle import torch_ref
+
+
+def test_synthetic_mesh_has_smpl_counts_and_is_deterministic():
+    v, f = synthetic.body_mesh()
+    assert v.shape == (6890, 3) and f.shape == (13776, 3) and f.min() == 0 and f.max() == 6889
+    v2, f2 = synthetic.body_mesh()
+    assert np.array_equal(v, v2) and np.array_equal(f, f2)
+    # closed genus-0 surface: every edge shared by exactly two faces
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
+    _, counts = np.unique(e, axis=0, return_counts=True)
+    assert (counts == 2).all()
+    m = synthetic.uv_seg_map_fn(v, f)
+    assert m.shape == (13777, 3) and tuple(m[-1]) == (0.0, 0.0, 1.0) and (m[:-1, 2] == 0).all()
+    a = synthetic.random_state_dict([("x.0.weight", (4, 3, 3, 3)), ("x.1.weight", (4,)), ("x.1.bias", (4,))], 0)
+    b = synthetic.random_state_dict([("x.0.weight", (4, 3, 3, 3)), ("x.1.weight", (4,)), ("x.1.bias", (4,))], 0)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_morph_matches_reference_restatement():
+    g = torch.Generator().manual_seed(0)
+    m = (torch.rand(2, 1, 48, 48, generator=g) > 0.3).float()
+    m[:, :, 10:40, 10:40] = 1
+    for ks in (3, 13):
+        for mode in ("erode", "dilate"):
+            assert torch.equal(util.morph(m, ks, mode), torch_ref.morph(m, ks, mode))
+
+
+def test_swap_smpl_camera_policies():
+    # models/imitator.py:216-234
+    from impersonator_amd.models.imitator import Imitator
+    self = types.SimpleNamespace(first_cam=torch.tensor([[1.0, 0.1, 0.2]]))
+    src_cam = torch.tensor([[0.9, 0.0, 0.05]])
+    shape = torch.arange(10).float()[None]
+    tgt = torch.from_numpy(demo.synthetic_smpls(4, 0))
+    out = Imitator.swap_smpl(self, src_cam, shape, tgt, "smooth")
+    assert out.shape == (4, 85)
+    assert torch.allclose(out[:, 0], src_cam[:, 0].expand(4))
+    assert torch.allclose(out[:, 1:3], src_cam[:, 1:] + tgt[:, 1:3] - self.first_cam[:, 1:])
+    assert torch.equal(out[:, 3:75], tgt[:, 3:75]) and torch.equal(out[:, 75:], shape.expand(4, -1))
+    assert torch.equal(Imitator.swap_smpl(self, src_cam, shape, tgt, "source")[:, :3], src_cam.expand(4, -1))
+    assert torch.equal(Imitator.swap_smpl(self, src_cam, shape, tgt, "copy")[:, :3], tgt[:, :3])
+
+
+def test_options_keep_reference_flag_names():
+    from impersonator_amd.options.test_options import TestOptions
+    opt = TestOptions().parse(["--src_path", "a.jpg", "--tgt_path", "b", "--cam_strategy", "copy", "--front_warp"])
+    assert opt.image_size == 256 and opt.bg_ks == 13 and opt.ft_ks == 3 and opt.map_name == "uv_seg"
+    assert opt.repeat_num == 6 and opt.cam_strategy == "copy" and opt.front_warp and not opt.only_vis
+
+
+def test_smpl_stage_matches_reference():
+    from oracle import reference_loader
+    if not reference_loader.available():
+        pytest.skip("/root/reference not present")
+    ref = reference_loader.load()
+    from impersonator_amd.networks.batch_smpl import SMPL, synthetic_smpl_params
+    m = SMPL(params=synthetic_smpl_params(0))
+    g = torch.Generator().manual_seed(0)
+    beta, theta = torch.randn(3, 10, generator=g), torch.randn(3, 72, generator=g) * 0.3
+    v, j, _ = m(beta, theta, get_skin=True)
+    stub = types.SimpleNamespace(shapedirs=m.shapedirs, v_template=m.v_template, size=m.size,
+                                 J_regressor=m.J_regressor, posedirs=m.posedirs, parents=m.parents,
+                                 weights=m.weights, joint_regressor=m.joint_regressor, rotate=False)
+    rv, rj, _ = ref.batch_smpl.SMPL.forward(stub, beta, theta, get_skin=True)
+    assert torch.allclose(v, rv, atol=1e-6) and torch.allclose(j, rj, atol=1e-6)
