@@ -36,6 +36,8 @@ _PROTOS = {
     "lwg_transfer_workspace_bytes": (_sz, [_i, _i, _i]),
     "lwg_transfer_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lwg_smpl_workspace_bytes": (_sz, [_i]),
+    "lwg_smpl_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lwg_pack_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lwg_unpack_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lwg_generator_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
@@ -70,6 +72,10 @@ def load():
         raise ImportError(
             "liblwg.so is missing (%s). Build it with `python -m impersonator_amd.build` (needs hipcc); "
             "there is no CPU fallback for the hot path." % LIB_PATH)
+    # liblwg works on PyTorch's device memory and streams, so it must share PyTorch's HIP runtime instance:
+    # import torch first so that its libamdhip64 is the one already mapped when liblwg's dependency is resolved
+    # (loading liblwg first binds a second runtime that sees no device context: "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -22,6 +22,7 @@ SOURCES = [
     ("capi.hip", []),
     ("raster.hip", ["-ffp-contract=off"]),
     ("warp.hip", ["-ffp-contract=off"]),
+    ("smpl.hip", []),
     ("conv.hip", []),
     ("generator.hip", []),
 ]

@@ -21,6 +21,8 @@
 //               channels, writes straight into channel slices of the decoder's concat buffers (torch.cat is free).
 // heads       : direct 7x7 conv 64->3+1 on the vector ALU (N=4 outputs cannot feed a 32-wide MFMA tile),
 //               InstanceNorm+ReLU of its input folded into the halo load, tanh/sigmoid/blend fused.
+#include <type_traits>
+
 #include "conv.h"
 #include "sample.h"
 
@@ -33,7 +35,7 @@ constexpr int BM = kConvBM;
 constexpr int BK = kConvBK;
 constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B alignment, spreads banks)
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool SMALL_CIN>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 {
     constexpr int WAVES_N = BN / (32 * WN);
@@ -58,46 +60,90 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     const int rem0 = m0 - img * hw_m;
 
     // ---- loader geometry: thread -> (row = tid/8 + 32*j, 16-byte column kq = tid%8)
+    // Everything a stage load needs is reduced to: one int offset per row (pixel origin of the filter window),
+    // a per-row bit mask of the taps that fall inside the image, and a tap offset that is wave-uniform for
+    // Cin >= 32 (tracked incrementally in scalar registers: no division, no branch in the loop).
     const int lrow = tid >> 3, kq = tid & 7;
-    int hi0[4], wi0[4];
+    int aoff[4];                   // float offset of (hi0, wi0) from the image base, may be negative
+    int hi0[4], wi0[4];            // SMALL_CIN: window origin, taps are checked per lane
+    unsigned long long amask[4];   // !SMALL_CIN: bit t = tap t is inside the image for this row
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int rem = rem0 + lrow + 32 * j;
         const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
         hi0[j] = hm * a.stride - a.pad;
         wi0[j] = wm * a.stride - a.pad;
+        aoff[j] = (hi0[j] * a.W + wi0[j]) * a.ldx + kq * 4;
+        amask[j] = 0ull;
+        if (!SMALL_CIN) {
+            for (int t = 0, kh = 0, kw = 0; t < ph.ntaps; ++t) {
+                const bool ok = (unsigned)(hi0[j] + kh) < (unsigned)a.H && (unsigned)(wi0[j] + kw) < (unsigned)a.W;
+                amask[j] |= (unsigned long long)ok << t;
+                if (++kw == ph.KW) { kw = 0; ++kh; }
+            }
+        }
     }
     const float *xin = a.x + (size_t)img * a.H * a.W * a.ldx;
     const float *wt = a.w + ph.w_off + (size_t)(n0 + lrow) * ph.Kpad + kq * 4;
     const int cin_mask = a.Cin - 1;
 
     float4 ra[4], rb[B_ROWS];
+    unsigned rvalid = 0;  // bit j: ra[j] holds real data (else it is zero padding and is cleared when staged)
 #pragma unroll
     for (int j = 0; j < 4; ++j) ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < B_ROWS; ++j) rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_stage = [&](int kt) {
-        const int kg = kt * BK + kq * 4;
-        const int tap = kg >> a.cin_log2;
-        const int ci = kg & cin_mask;
-        const int kh = tap / ph.KW, kw = tap - kh * ph.KW;
-        const bool tap_ok = tap < ph.ntaps;
+
+    // scalar walk over (tap, ci0) for the wave-uniform case
+    int s_tap = 0, s_kh = 0, s_kw = 0, s_ci0 = 0;
+    // stage fetch, split in two halves so that they can be slotted between MFMA groups
+    int toff = 0;
+    auto load_a = [&](int kt) {
+        rvalid = 0;
+        if (SMALL_CIN) {
+            const int kg = kt * BK + kq * 4;
+            const int tap = kg >> a.cin_log2;
+            const int kh = tap / ph.KW, kw = tap - kh * ph.KW;
+            toff = (kh * a.W + kw) * a.ldx + (kg & cin_mask);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = tap < ph.ntaps && (unsigned)(hi0[j] + kh) < (unsigned)a.H &&
+                                (unsigned)(wi0[j] + kw) < (unsigned)a.W;
+                rvalid |= (unsigned)ok << j;
+            }
+        } else {
+            toff = (s_kh * a.W + s_kw) * a.ldx + s_ci0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rvalid |= (unsigned)((amask[j] >> s_tap) & 1ull) << j;
+            s_ci0 += BK;
+            if (s_ci0 == a.Cin) {
+                s_ci0 = 0;
+                ++s_tap;
+                if (++s_kw == ph.KW) { s_kw = 0; ++s_kh; }
+            }
+        }
+        // branch-free: an out-of-image tap reads a harmless in-range address and is zeroed when staged
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = tap_ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            ra[j] = ok ? *reinterpret_cast<const float4 *>(xin + (size_t)(hi * a.W + wi) * a.ldx + ci)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int off = ((rvalid >> j) & 1u) ? aoff[j] + toff : kq * 4;
+            ra[j] = *reinterpret_cast<const float4 *>(xin + off);
         }
+    };
+    auto load_b = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < B_ROWS; ++j)
             rb[j] = *reinterpret_cast<const float4 *>(wt + (size_t)(32 * j) * ph.Kpad + kt * BK);
     };
-    auto store_stage = [&](int buf) {
+    auto store_a = [&](int buf) {
         float *ad = As + buf * BM * LDK + lrow * LDK + kq * 4;
-        float *bd = Bs + buf * BN * LDK + lrow * LDK + kq * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(ad + 32 * j * LDK) = ra[j];
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = ((rvalid >> j) & 1u) ? ra[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(ad + 32 * j * LDK) = v;
+        }
+    };
+    auto store_b = [&](int buf) {
+        float *bd = Bs + buf * BN * LDK + lrow * LDK + kq * 4;
 #pragma unroll
         for (int j = 0; j < B_ROWS; ++j) *reinterpret_cast<float4 *>(bd + 32 * j * LDK) = rb[j];
     };
@@ -114,35 +160,73 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     const int a_frag = (wave_m * 32 * WM) * LDK + frag;
     const int b_frag = (wave_n * 32 * WN) * LDK + frag;
 
-    // software pipeline with a single call site per stage function (kt = -1 is the prologue fill)
-    const int nk = ph.Kpad / BK;
-    for (int kt = -1; kt < nk; ++kt) {
+    // ---- main loop.  Registers hold stage kt+1 (fetched during iteration kt-1); iteration kt stages them into the
+    // idle LDS buffer, re-issues the same registers for stage kt+2 and runs the MFMAs of stage kt.  Global latency
+    // is covered by a full iteration, and the staging instructions are slotted BETWEEN this wave's own 64-cycle
+    // MFMAs (straight-line body, no branches) instead of in front of them.  One barrier per stage.
+    auto stage_body = [&](int kt, auto do_store, auto do_load) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_stage(kt + 1);
-        if (kt >= 0) {
-            const float *Ab = As + buf * BM * LDK + a_frag;
-            const float *Bb = Bs + buf * BN * LDK + b_frag;
+        const float *Ab = As + buf * BM * LDK + a_frag;
+        const float *Bb = Bs + buf * BN * LDK + b_frag;
+        float4 af[WM], bf[WN];
 #pragma unroll
-            for (int k8 = 0; k8 < BK / 8; ++k8) {
-                float4 af[WM], bf[WN];
+        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4 *>(Ab + i * 32 * LDK);
 #pragma unroll
-                for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4 *>(Ab + i * 32 * LDK + k8 * 8);
+        for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const float4 *>(Bb + j * 32 * LDK);
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const float4 *>(Bb + j * 32 * LDK + k8 * 8);
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            float4 an[WM], bn4[WN];
+            if (k8 + 1 < BK / 8) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i) an[i] = *reinterpret_cast<const float4 *>(Ab + i * 32 * LDK + (k8 + 1) * 8);
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < WN; ++j) bn4[j] = *reinterpret_cast<const float4 *>(Bb + j * 32 * LDK + (k8 + 1) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+            // stage kt+1 -> LDS right behind the first MFMA group, then immediately re-issue the registers for
+            // stage kt+2: its loads get ~3/4 of an iteration (1.5-3k cycles) plus the barrier to land
+            if (decltype(do_store)::value && k8 == 0) {
+                store_a(buf ^ 1);
+                store_b(buf ^ 1);
+            }
+            if (decltype(do_load)::value && k8 == 1) {
+                load_a(kt + 2);
+                load_b(kt + 2);
+            }
+            if (k8 + 1 < BK / 8) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = an[i];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bf[j] = bn4[j];
             }
         }
-        if (kt + 1 < nk) store_stage(buf ^ 1);
         __syncthreads();
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    const int nk = ph.Kpad / BK;
+    load_a(0);
+    load_b(0);
+    store_a(0);
+    store_b(0);
+    if (nk > 1) {
+        load_a(1);
+        load_b(1);
     }
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) stage_body(kt, yes{}, yes{});
+    if (kt + 1 < nk) stage_body(kt++, yes{}, no{});
+    stage_body(kt, no{}, no{});
 
     // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rsel = 4 * (lane >> 5);
@@ -202,36 +286,44 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// grid (C/64, N), 256 threads = 4 tile slices x 64 channels
+// grid (C/16, N), 256 threads = 16 tile slices x 16 channels (64-byte coalesced rows of float2 partials)
+constexpr int FIN_CH = 16, FIN_SL = 16;
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float2 *__restrict__ partials, int nphase, int mtiles,
                                                           int tiles_per_img, int C, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
                                                           float2 *__restrict__ scale_shift)
 {
-    __shared__ double sh[3][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int slice = threadIdx.x >> 6;
+    __shared__ double sh[3][FIN_SL][FIN_CH];
+    const int cl = threadIdx.x & (FIN_CH - 1);
+    const int c = blockIdx.x * FIN_CH + cl;
+    const int slice = threadIdx.x / FIN_CH;
     const int n = blockIdx.y;
     double sm = 0., sq = 0., m2 = 0.;
     if (c < C) {
-        for (int p = 0; p < nphase; ++p)
-            for (int t = slice; t < tiles_per_img; t += 4) {
-                const float2 v = partials[((size_t)p * mtiles + (size_t)n * tiles_per_img + t) * C + c];
+        for (int p = 0; p < nphase; ++p) {
+            const float2 *base = partials + ((size_t)p * mtiles + (size_t)n * tiles_per_img) * C + c;
+#pragma unroll 4
+            for (int t = slice; t < tiles_per_img; t += FIN_SL) {
+                const float2 v = base[(size_t)t * C];
                 sm += v.x;
                 sq += (double)v.x * v.x;
                 m2 += v.y;
             }
+        }
     }
-    sh[0][slice][threadIdx.x & 63] = sm;
-    sh[1][slice][threadIdx.x & 63] = sq;
-    sh[2][slice][threadIdx.x & 63] = m2;
+    sh[0][slice][cl] = sm;
+    sh[1][slice][cl] = sq;
+    sh[2][slice][cl] = m2;
     __syncthreads();
     if (slice == 0 && c < C) {
-        const int l = threadIdx.x;
+        sm = sq = m2 = 0.;
+#pragma unroll
+        for (int k = 0; k < FIN_SL; ++k) {
+            sm += sh[0][k][cl];
+            sq += sh[1][k][cl];
+            m2 += sh[2][k][cl];
+        }
         const double cnt = (double)nphase * tiles_per_img;
-        sm = sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l];
-        sq = sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l];
-        m2 = sh[2][0][l] + sh[2][1][l] + sh[2][2][l] + sh[2][3][l];
         const double mean = sm / cnt;
         // Chan et al.: M2_total = sum M2_i + n_i * sum (mean_i - mean)^2, every tile holds BM samples
         double between = sq - cnt * mean * mean;
@@ -379,16 +471,23 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st)
     // the 128-channel tile needs 72 KiB of LDS: above the 64 KiB default, well inside gfx950's 160 KiB per CU
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + 64) * LDK * (int)sizeof(float)));
-        LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<128, 2, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + 128) * LDK * (int)sizeof(float)));
+        const int l64 = 2 * (BM + 64) * LDK * (int)sizeof(float), l128 = 2 * (BM + 128) * LDK * (int)sizeof(float);
+        LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, l64));
+        LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, l64));
+        LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<128, 2, 2, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, l128));
         lds_opt_in = true;
     }
-    if (bn == 64) {
-        conv_igemm_f32<64, 1, 2><<<grid, 256, lds, st>>>(a);
+    const bool small_cin = a.Cin < BK;
+    if (small_cin && bn != 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d < %d is only built for the 64-channel tile", a.Cin, BK);
+    if (small_cin) {
+        conv_igemm_f32<64, 1, 2, true><<<grid, 256, lds, st>>>(a);
+    } else if (bn == 64) {
+        conv_igemm_f32<64, 1, 2, false><<<grid, 256, lds, st>>>(a);
     } else {
-        conv_igemm_f32<128, 2, 2><<<grid, 256, lds, st>>>(a);
+        conv_igemm_f32<128, 2, 2, false><<<grid, 256, lds, st>>>(a);
     }
     LWG_LAUNCH_CHECK("conv_igemm_f32");
     return LWG_OK;
@@ -398,7 +497,7 @@ int launch_in_finalize(const float2 *partials, int nphase, int mtiles, int N, in
                        const float *beta, float eps, float2 *scale_shift, hipStream_t st)
 {
     if (mtiles % N != 0) LWG_FAIL(LWG_ERR_UNSUPPORTED, "in_finalize: %d tiles do not split over %d images", mtiles, N);
-    const dim3 grid(ceil_div(C, 64), N);
+    const dim3 grid(ceil_div(C, FIN_CH), N);
     in_finalize_kernel<<<grid, 256, 0, st>>>(partials, nphase, mtiles, mtiles / N, C, gamma, beta, eps, scale_shift);
     LWG_LAUNCH_CHECK("in_finalize_kernel");
     return LWG_OK;

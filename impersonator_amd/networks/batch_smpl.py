@@ -109,9 +109,53 @@ class SMPL(nn.Module):
         self.parents = np.asarray(params['kintree_table'][0]).astype(np.int32)
         self.register_buffer('weights', f32(params['weights']))
         self.register_buffer('joint_regressor', f32(np.asarray(params['cocoplus_regressor']).T))
+        # device path (liblwg, smpl.hip): the joint regression is linear in the shape, fold it once in float64
+        jreg = np.asarray(params['J_regressor'], np.float64)                       # (24, nv)
+        vt = np.asarray(params['v_template'], np.float64)                          # (nv, 3)
+        sdirs = np.asarray(params['shapedirs'], np.float64)                        # (nv, 3, nb)
+        self.register_buffer('J_template', f32(jreg @ vt))                         # (24, 3)
+        self.register_buffer('J_shapedirs', f32(np.einsum('jv,vck->kjc', jreg, sdirs).reshape(self.num_betas, -1)))
+        self.register_buffer('parents_t', torch.from_numpy(self.parents.astype(np.int32)))
+        self._ws = None
 
     def forward(self, beta, theta, get_skin=False):
-        """networks/batch_smpl.py:285-375."""
+        """networks/batch_smpl.py:285-375.  CUDA tensors run the fused HIP kernels of liblwg (smpl.hip);
+        CPU tensors run the reference's tensor-op formulation (used by the CPU tests)."""
+        if beta.is_cuda:
+            return self.forward_device(beta, theta, get_skin)
+        return self.forward_ops(beta, theta, get_skin)
+
+    @torch.no_grad()
+    def forward_device(self, beta, theta, get_skin=False):
+        n = beta.shape[0]
+        th = torch.cat([torch.zeros(n, 3, device=beta.device), theta.float(), beta.float()], dim=1)
+        verts, joints, Rs = self.forward_theta(th)
+        if get_skin:
+            return verts, joints, Rs
+        return joints
+
+    @torch.no_grad()
+    def forward_theta(self, theta):
+        """theta (n, 3+72+num_betas) = [cam, pose, shape] on the GPU -> (verts, joints, Rs) in one liblwg call."""
+        from .. import _lib
+        lib = _lib.load()
+        th = theta.float().contiguous()
+        n, nv, dev = th.shape[0], self.size[0], th.device
+        verts = torch.empty((n, nv, 3), device=dev, dtype=torch.float32)
+        joints = torch.empty((n, self.joint_regressor.shape[1], 3), device=dev, dtype=torch.float32)
+        Rs = torch.empty((n, 24, 3, 3), device=dev, dtype=torch.float32)
+        need = lib.lwg_smpl_workspace_bytes(n)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _lib.check(lib.lwg_smpl_forward(
+            _lib.ptr(th), n, self.num_betas, nv, joints.shape[1], _lib.ptr(self.v_template), _lib.ptr(self.shapedirs),
+            _lib.ptr(self.posedirs), _lib.ptr(self.J_template), _lib.ptr(self.J_shapedirs), _lib.ptr(self.parents_t),
+            _lib.ptr(self.weights), _lib.ptr(self.joint_regressor), _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(Rs),
+            _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()))
+        return verts, joints, Rs
+
+    def forward_ops(self, beta, theta, get_skin=False):
+        """networks/batch_smpl.py:285-375 as tensor ops."""
         n = beta.shape[0]
         nv = self.size[0]
         v_shaped = torch.matmul(beta, self.shapedirs).view(-1, nv, 3) + self.v_template
@@ -146,6 +190,9 @@ class HumanModelRecovery(nn.Module):
         cam = theta[:, 0:3].contiguous()
         pose = theta[:, 3:75].contiguous()
         shape = theta[:, 75:].contiguous()
-        verts, j3d, _ = self.smpl(beta=shape, theta=pose, get_skin=True)
+        if theta.is_cuda:
+            verts, j3d, _ = self.smpl.forward_theta(theta)
+        else:
+            verts, j3d, _ = self.smpl(beta=shape, theta=pose, get_skin=True)
         return {'theta': theta, 'cam': cam, 'pose': pose, 'shape': shape, 'verts': verts,
                 'j2d': batch_orth_proj_idrot(j3d, cam), 'j3d': j3d}

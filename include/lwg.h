@@ -101,6 +101,19 @@ LWG_API int lwg_transfer_frame(const float *verts, const float *cam, const int32
                                float *tsf_inputs_nhwc8, void *workspace, size_t workspace_bytes,
                                lwg_stream_t stream);
 
+/* SMPL.forward (networks/batch_smpl.py:285-375) for a batch of frames: theta (bs, 3+72+num_betas) =
+ * [cam, pose, shape] -> verts (bs,nv,3), joints (bs,num_out_joints,3) [optional], Rs (bs,24,3,3) [optional].
+ * Model tensors in the reference's own layouts: v_template (nv,3), shapedirs (num_betas, nv*3),
+ * posedirs (207, nv*3), weights (nv,24), joint_regressor (nv,num_out_joints), parents (24).
+ * J_template (24,3) and J_shapedirs (num_betas, 72) are the joint regressor applied to v_template / shapedirs
+ * (the regression J_regressor^T v_shaped of batch_smpl.py:318-321 is linear in the shape; precomputed once). */
+LWG_API size_t lwg_smpl_workspace_bytes(int bs);
+LWG_API int lwg_smpl_forward(const float *theta, int bs, int num_betas, int nv, int num_out_joints,
+                             const float *v_template, const float *shapedirs, const float *posedirs,
+                             const float *J_template, const float *J_shapedirs, const int32_t *parents,
+                             const float *weights, const float *joint_regressor, float *verts, float *joints,
+                             float *Rs, void *workspace, size_t workspace_bytes, lwg_stream_t stream);
+
 /* NCHW (n,C,H,W) -> NHWC with the channel count padded to cpad (zeros), and back (first C channels). */
 LWG_API int lwg_pack_nhwc(const float *x_nchw, int n, int C, int H, int W, int cpad, float *out_nhwc,
                           lwg_stream_t stream);

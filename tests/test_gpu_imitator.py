@@ -54,6 +54,7 @@ def test_inference_by_smpls_matches_oracle_and_is_batch_invariant(imi):
     imitator._opt.batch_size = 1
     outs1 = imitator.inference_by_smpls(smpls, cam_strategy="smooth")
     imitator._opt.batch_size = 4
+    # every stage (SMPL skinning, rasteriser, generator) is batch-invariant bit for bit
     for a, b in zip(outs, outs1):
         assert np.array_equal(a, b)
     # oracle on the vertices of the last batch (frames 45, 63)
@@ -93,3 +94,22 @@ def test_front_warp(imi):
     assert fm.shape == (2, 1, 256, 256)
     same = (fm == 0).expand_as(base)
     assert torch.equal(warped[same], base[same])
+
+
+def test_smpl_device_kernels_match_tensor_op_formulation():
+    """smpl.hip (fused LBS) vs the reference's tensor-op formulation evaluated on the CPU."""
+    from impersonator_amd.networks.batch_smpl import SMPL, synthetic_smpl_params
+    m = SMPL(params=synthetic_smpl_params(0))
+    g = torch.Generator().manual_seed(0)
+    beta = torch.randn(5, 10, generator=g)
+    theta = torch.randn(5, 72, generator=g) * 0.4
+    theta[0] = 0                                     # rest pose: the 1e-8 guard of batch_rodrigues matters here
+    v, j, Rs = m.forward_ops(beta, theta, get_skin=True)
+    md = m.cuda()
+    dv, dj, dRs = md(beta.cuda(), theta.cuda(), get_skin=True)
+    assert float((dv.cpu() - v).abs().max()) <= 2e-6
+    assert float((dj.cpu() - j).abs().max()) <= 2e-6
+    assert float((dRs.cpu() - Rs).abs().max()) <= 2e-6
+    # batch-size invariance of the device kernels (bit for bit)
+    dv1, _, _ = md(beta[2:3].cuda(), theta[2:3].cuda(), get_skin=True)
+    assert torch.equal(dv1, dv[2:3])
