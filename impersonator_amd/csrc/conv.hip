@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
             const int kg = kt * BK + kq * 4;
             const int tap = kg >> a.cin_log2;
             const int kh = tap / ph.KW, kw = tap - kh * ph.KW;
-            toff = (kh * a.W + kw) * a.ldx + (kg & cin_mask);
+            toff = (kh * a.W + kw) * a.ldx + (kg & cin_mask) - kq * 4;  // aoff already carries the lane's kq*4
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = tap < ph.ntaps && (unsigned)(hi0[j] + kh) < (unsigned)a.H &&
