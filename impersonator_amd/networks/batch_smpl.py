@@ -97,7 +97,8 @@ class SMPL(nn.Module):
                           posedirs=np.asarray(dd['posedirs']), kintree_table=np.asarray(dd['kintree_table']),
                           weights=np.asarray(dd['weights']),
                           cocoplus_regressor=np.asarray(dd['cocoplus_regressor'].todense()))
-        f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+        # liblwg reads these through raw pointers: row-major, whatever strides numpy's transposes had
+        f32 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32).contiguous()
         self.faces = torch.from_numpy(np.asarray(params['f']).astype(np.int32))
         self.register_buffer('v_template', f32(params['v_template']))
         self.size = [self.v_template.shape[0], 3]

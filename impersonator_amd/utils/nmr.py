@@ -57,20 +57,20 @@ class SMPLRenderer(nn.Module):
         if self.fill_back:
             faces = np.concatenate((faces, faces[:, ::-1]), axis=0)
         self.nf = faces.shape[0]
-        self.register_buffer('faces', torch.tensor(faces.astype(np.int32)).int())
+        self.register_buffer('faces', torch.tensor(np.ascontiguousarray(faces.astype(np.int32))).int().contiguous())
 
         if map_fn is None:
             from . import mesh
             map_fn = mesh.create_mapping(map_name, uv_map_path, contain_bg=True, fill_back=fill_back)
             if has_front and front_map_fn is None:
                 front_map_fn = mesh.create_mapping('front', uv_map_path, contain_bg=True, fill_back=fill_back)
-        self.register_buffer('map_fn', torch.as_tensor(np.asarray(map_fn)).float())
+        self.register_buffer('map_fn', torch.as_tensor(np.ascontiguousarray(map_fn)).float().contiguous())
         if back_map_fn is not None:
-            self.register_buffer('back_map_fn', torch.as_tensor(np.asarray(back_map_fn)).float())
+            self.register_buffer('back_map_fn', torch.as_tensor(np.ascontiguousarray(back_map_fn)).float().contiguous())
         else:
             self.back_map_fn = None
         if front_map_fn is not None:
-            self.register_buffer('front_map_fn', torch.as_tensor(np.asarray(front_map_fn)).float())
+            self.register_buffer('front_map_fn', torch.as_tensor(np.ascontiguousarray(front_map_fn)).float().contiguous())
         else:
             self.front_map_fn = None
 
