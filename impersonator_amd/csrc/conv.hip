@@ -243,42 +243,42 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
             for (int j = 0; j < WN; ++j) yo[j * 32] = acc[i][j][r];
         }
 
-    // ---- epilogue 2: per-tile InstanceNorm statistics (mean, M2) per channel over the tile's 128 pixels
+    // ---- epilogue 2: per-tile InstanceNorm statistics (mean, M2) per channel over the tile's 128 pixels.
+    // Reduced per 32-row MFMA tile first and combined over the four row tiles in a fixed order, so the numbers do not
+    // depend on which wave layout (BN/WM/WN variant) produced them: results stay bit-identical across batch sizes.
     if (a.partials) {
-        float2 *red = reinterpret_cast<float2 *>(smem);  // [WAVES_M][BN], LDS is free again after the last barrier
-        constexpr float kInvRows = 1.f / (32 * WM);
+        float2 *red = reinterpret_cast<float2 *>(smem);  // [BM/32][BN], LDS is free again after the last barrier
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            float s = 0.f;
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+            for (int j = 0; j < WN; ++j) {
+                float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-            s += __shfl_xor(s, 32);
-            const float mu = s * kInvRows;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
+                s += __shfl_xor(s, 32);
+                const float mu = s * (1.f / 32.f);
+                float q = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float d = acc[i][j][r] - mu;
                     q += d * d;
                 }
-            q += __shfl_xor(q, 32);
-            if (lane < 32) red[wave_m * BN + wave_n * 32 * WN + j * 32 + col] = make_float2(mu, q);
-        }
+                q += __shfl_xor(q, 32);
+                if (lane < 32) red[(wave_m * WM + i) * BN + wave_n * 32 * WN + j * 32 + col] = make_float2(mu, q);
+            }
         __syncthreads();
         if (tid < BN) {
+            constexpr int RT = BM / 32;
             float mean = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES_M; ++w) mean += red[w * BN + tid].x;
-            mean *= 1.f / WAVES_M;
+            for (int w = 0; w < RT; ++w) mean += red[w * BN + tid].x;
+            mean *= 1.f / RT;
             float m2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < WAVES_M; ++w) {
+            for (int w = 0; w < RT; ++w) {
                 const float2 p = red[w * BN + tid];
                 const float d = p.x - mean;
-                m2 += p.y + (32 * WM) * d * d;
+                m2 += p.y + 32.f * d * d;
             }
             a.partials[((size_t)blockIdx.z * a.mtiles + blockIdx.x) * a.Cout + n0 + tid] = make_float2(mean, m2);
         }

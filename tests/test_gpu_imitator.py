@@ -57,11 +57,12 @@ def test_inference_by_smpls_matches_oracle_and_is_batch_invariant(imi):
     # every stage (SMPL skinning, rasteriser, generator) is batch-invariant bit for bit
     for a, b in zip(outs, outs1):
         assert np.array_equal(a, b)
-    # oracle on the vertices of the last batch (frames 45, 63)
+    # oracle on the vertices of the last launch (tsf_info belongs to the batch-1 pass: frame 63 only)
     info = imitator.tsf_info
+    n = info["verts"].shape[0]
     fr, pred = _oracle_frames(imitator, src_img, bg_img, info["verts"].cpu(), info["cam"].cpu())
     assert torch.equal(fr["fim"], info["fim"].cpu())
-    got = np.stack(outs[4:]).transpose(0, 3, 1, 2)
+    got = np.stack(outs[-n:]).transpose(0, 3, 1, 2)
     assert np.abs(got - pred.numpy()).max() <= 1e-3
     for k in ("theta", "cam", "pose", "shape", "verts", "j2d", "j3d", "fim", "wim", "cond", "tsf_img", "T"):
         assert k in info, k
@@ -107,9 +108,10 @@ def test_smpl_device_kernels_match_tensor_op_formulation():
     v, j, Rs = m.forward_ops(beta, theta, get_skin=True)
     md = m.cuda()
     dv, dj, dRs = md(beta.cuda(), theta.cuda(), get_skin=True)
-    assert float((dv.cpu() - v).abs().max()) <= 2e-6
-    assert float((dj.cpu() - j).abs().max()) <= 2e-6
-    assert float((dRs.cpu() - Rs).abs().max()) <= 2e-6
+    # fp32 sums over 207 pose-blend terms and 6890-vertex regressions, different association order
+    assert float((dv.cpu() - v).abs().max()) <= 1e-5
+    assert float((dj.cpu() - j).abs().max()) <= 2e-5
+    assert float((dRs.cpu() - Rs).abs().max()) <= 1e-6
     # batch-size invariance of the device kernels (bit for bit)
     dv1, _, _ = md(beta[2:3].cuda(), theta[2:3].cuda(), get_skin=True)
     assert torch.equal(dv1, dv[2:3])
