@@ -144,12 +144,22 @@ def main():
         for i in range(args.steps):
             step(args.warmup + i)
         n, ms, flops = imitator.generator.profile_read()
+        table = imitator.generator.profile_table()
         imitator.generator.profile(False)
-        achieved = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_f32", "achieved": round(achieved, 3),
+        # the conv runs as a few instantiations of one implicit-GEMM kernel; `roofline` is the one with the most time
+        # (names are the ones rocprofv3 --stats prints, so profiles/ can be checked against this line)
+        name, (kn, kms, kfl) = max(table.items(), key=lambda kv: kv[1][1])
+        achieved = kfl / (kms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
-                    "flop_per_launch": flops / max(n, 1)}
+                    "traffic": None, "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
+                    "flop_per_launch": kfl / max(kn, 1),
+                    "all_conv_kernels": {"achieved": round(flops / (ms * 1e-3) / 1e12, 3),
+                                         "frac": round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                         "launches": n, "ms_per_step": round(ms / args.steps, 4),
+                                         "by_kernel": {k: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 5),
+                                                           "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
+                                                       for k, v in table.items()}}}
 
     if rank == 0:
         frames = world * BATCH * args.steps

@@ -51,7 +51,9 @@ _PROTOS = {
     "lwg_generator_swap": (_i, [_vp, _vp, _i, _vp, _vp, _i, _c.POINTER(_vp), _c.POINTER(_vp), _i, _vp, _vp, _vp]),
     "lwg_generator_peek": (_i, [_vp, _i, _vp, _sz, _vp]),
     "lwg_generator_profile": (_i, [_vp, _i]),
-    "lwg_generator_profile_read": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
+    "lwg_generator_profile_variants": (_i, []),
+    "lwg_generator_profile_variant_name": (_c.c_char_p, [_i]),
+    "lwg_generator_profile_read": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@ struct ConvArgs {
     const float *x; int ldx;        // input NHWC, pixel stride in floats (>= Cin: reads a channel slice of a wider buffer)
     int N, H, W, Cin, cin_log2;
     const float *w;
+    const float *zeros;             // >= 16 bytes of zeros (source of out-of-image taps on the DMA path), may be null
     float *y; int ldy;              // raw (pre-norm) output NHWC
     int Ho, Wo, Cout;
     int Hm, Wm, stride, pad, os;
@@ -32,8 +33,10 @@ struct ConvArgs {
     ConvPhase ph[4];
 };
 
-// bn = 64 or 128 output channels per workgroup tile
-int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st);
+// bn = 64 or 128 output channels per workgroup tile.  *variant (optional) receives which kernel instantiation ran:
+enum { kIgemmReg64 = 0, kIgemmReg128 = 1, kIgemmSmallCin = 2, kIgemmDma64 = 3, kIgemmDma128 = 4, kIgemmVariants = 5 };
+extern const char *const kIgemmVariantNames[kIgemmVariants];
+int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant = nullptr);
 
 // (mean, M2) partials -> per (image, channel) scale/shift of InstanceNorm2d(affine, eps) (biased variance)
 int launch_in_finalize(const float2 *partials, int nphase, int mtiles, int N, int C, const float *gamma,

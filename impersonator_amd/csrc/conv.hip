@@ -35,7 +35,71 @@ constexpr int BM = kConvBM;
 constexpr int BK = kConvBK;
 constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B alignment, spreads banks)
 
-template <int BN, int WM, int WN, bool SMALL_CIN>
+// Shared epilogue: raw output store + per-tile InstanceNorm statistics.
+template <int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, f32x16 (&acc)[WM][WN], float *smem,
+                                               int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0)
+{
+    // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+            const int rem = rem0 + row;
+            const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
+            const size_t opix = ((size_t)img * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
+            float *yo = a.y + opix * a.ldy + n0 + wave_n * 32 * WN + col;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) yo[j * 32] = acc[i][j][r];
+        }
+
+    // ---- epilogue 2: per-tile InstanceNorm statistics (mean, M2) per channel over the tile's 128 pixels.
+    // Reduced per 32-row MFMA tile first and combined over the four row tiles in a fixed order, so the numbers do not
+    // depend on which wave layout (BN/WM/WN variant) produced them: results stay bit-identical across batch sizes.
+    if (a.partials) {
+        float2 *red = reinterpret_cast<float2 *>(smem);  // [BM/32][BN], LDS is free again after the last barrier
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+                s += __shfl_xor(s, 32);
+                const float mu = s * (1.f / 32.f);
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[i][j][r] - mu;
+                    q += d * d;
+                }
+                q += __shfl_xor(q, 32);
+                if (lane < 32) red[(wave_m * WM + i) * BN + wave_n * 32 * WN + j * 32 + col] = make_float2(mu, q);
+            }
+        __syncthreads();
+        if (tid < BN) {
+            constexpr int RT = BM / 32;
+            float mean = 0.f;
+#pragma unroll
+            for (int w = 0; w < RT; ++w) mean += red[w * BN + tid].x;
+            mean *= 1.f / RT;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < RT; ++w) {
+                const float2 p = red[w * BN + tid];
+                const float d = p.x - mean;
+                m2 += p.y + 32.f * d * d;
+            }
+            a.partials[((size_t)blockIdx.z * a.mtiles + blockIdx.x) * a.Cout + n0 + tid] = make_float2(mean, m2);
+        }
+    }
+}
+
+// DBG is 0 in the product; tools/igemm_bench.hip instantiates ablation variants (timing only, results invalid):
+//   1 no global loads in the loop, 2 no LDS staging stores, 4 no barrier, 8 no fragment re-reads, 16 s_setprio around MFMAs
+template <int BN, int WM, int WN, bool SMALL_CIN, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 {
     constexpr int WAVES_N = BN / (32 * WN);
@@ -176,12 +240,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 #pragma unroll
         for (int k8 = 0; k8 < BK / 8; ++k8) {
             float4 an[WM], bn4[WN];
-            if (k8 + 1 < BK / 8) {
+            if (k8 + 1 < BK / 8 && !(DBG & 8)) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i) an[i] = *reinterpret_cast<const float4 *>(Ab + i * 32 * LDK + (k8 + 1) * 8);
 #pragma unroll
                 for (int j = 0; j < WN; ++j) bn4[j] = *reinterpret_cast<const float4 *>(Bb + j * 32 * LDK + (k8 + 1) * 8);
             }
+            if (DBG & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -191,24 +256,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
+            if (DBG & 16) __builtin_amdgcn_s_setprio(0);
             // stage kt+1 -> LDS right behind the first MFMA group, then immediately re-issue the registers for
             // stage kt+2: its loads get ~3/4 of an iteration (1.5-3k cycles) plus the barrier to land
-            if (decltype(do_store)::value && k8 == 0) {
+            if (decltype(do_store)::value && k8 == 0 && !(DBG & 2)) {
                 store_a(buf ^ 1);
                 store_b(buf ^ 1);
             }
-            if (decltype(do_load)::value && k8 == 1) {
+            if (decltype(do_load)::value && k8 == 1 && !(DBG & 1)) {
                 load_a(kt + 2);
                 load_b(kt + 2);
             }
-            if (k8 + 1 < BK / 8) {
+            if (k8 + 1 < BK / 8 && !(DBG & 8)) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i) af[i] = an[i];
 #pragma unroll
                 for (int j = 0; j < WN; ++j) bf[j] = bn4[j];
             }
         }
-        __syncthreads();
+        if (!(DBG & 4)) __syncthreads();
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
@@ -228,61 +294,215 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     if (kt + 1 < nk) stage_body(kt++, yes{}, no{});
     stage_body(kt, no{}, no{});
 
-    // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col = lane & 31, rsel = 4 * (lane >> 5);
+    igemm_epilogue<BN, WM, WN>(a, ph, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_igemm_dma_f32: the same implicit GEMM with the operands streamed global -> LDS by the DMA path
+// (global_load_lds_dwordx4, 1 KiB per wave instruction) into a 3-stage ring, two stages in flight.
+//   * no staging VGPRs, no ds_write pass, no select/zero VALU in the loop: what remains between the MFMAs of a
+//     stage is 4 + BN/32 address adds and DMA issues per wave;
+//   * a DMA writes wave-uniform base + lane*16 B, so the LDS image of a tile is row-major with a 128-B pitch;
+//     the b128 fragment reads stay conflict-free because each lane fetches the 16-B column (lane&7) ^ f(row),
+//     f(row) = (row>>1)&7, of its row (swizzle on the SOURCE address, linear destination) and the fragment read
+//     applies the same involution;
+//   * zero padding: a tap outside the image makes the lane read from a 16-byte zero buffer instead;
+//   * synchronisation is a raw s_barrier plus counted vmcnt: at the end of iteration t every wave waits until only
+//     its DMAs of stage t+2 are outstanding (=> stage t+1 has landed), then the barrier publishes it.
+template <int BN, int WM, int WN, int DBG = 0, int NS = 3>
+__global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
+{
+    constexpr int WAVES_N = BN / (32 * WN);
+    constexpr int WAVES_M = BM / (32 * WM);
+    static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
+    constexpr int B_ROWS = BN / 32;            // DMA instructions per wave for the weight tile
+    // NS = LDS ring depth: NS-1 stages are in flight while one is being consumed
+    constexpr int STAGE = (BM + BN) * BK;      // floats per stage: A [BM][32] then B [BN][32], 128-B rows
+    constexpr int LPS = 4 + B_ROWS;            // DMA instructions per wave per stage
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+
+    const ConvPhase ph = a.ph[blockIdx.z];
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int hw_m = a.Hm * a.Wm;
+    const int img = m0 / hw_m;
+    const int rem0 = m0 - img * hw_m;
+
+    // ---- DMA geometry: wave w, instruction j moves tile rows (w*4 + j)*8 .. +7; lane -> (row = lane>>3, slot = lane&7)
+    const int lr = lane >> 3, ls = lane & 7;
+    int aoff[4];                   // float offset of the lane's source chunk at tap 0 / channel 0 (may be negative)
+    unsigned amask[4];             // bit t: tap t of that row is inside the image (<= 32 taps on this path)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + lr;
+        const int rem = rem0 + row;
+        const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
+        const int hi0 = hm * a.stride - a.pad, wi0 = wm * a.stride - a.pad;
+        const int src_col = ls ^ ((row >> 1) & 7);
+        aoff[j] = (hi0 * a.W + wi0) * a.ldx + src_col * 4;
+        unsigned m = 0;
+        for (int t = 0, kh = 0, kw = 0; t < ph.ntaps; ++t) {
+            const bool ok = (unsigned)(hi0 + kh) < (unsigned)a.H && (unsigned)(wi0 + kw) < (unsigned)a.W;
+            m |= (unsigned)ok << t;
+            if (++kw == ph.KW) { kw = 0; ++kh; }
+        }
+        amask[j] = m;
+    }
+    const float *xin = a.x + (size_t)img * a.H * a.W * a.ldx;
+    const float *wsrc[B_ROWS];
+#pragma unroll
+    for (int j = 0; j < B_ROWS; ++j) {
+        const int row = (wave * B_ROWS + j) * 8 + lr;
+        wsrc[j] = a.w + ph.w_off + (size_t)(n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4;
+    }
+
+    // The DMA is issued from inline asm on purpose: hipcc treats a compiler-visible global_load_lds as a pending LDS
+    // write that may alias every later ds_read and drains it with s_waitcnt vmcnt(0) -- which would serialise the
+    // ring.  Hidden in asm, its completion is tracked by hand (counted vmcnt before the barrier, see below).
+    // m0 carries the wave-uniform LDS byte address of the 1 KiB chunk; it is saved/restored around the instruction.
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    auto dma16 = [&](const float *gsrc, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_byte)
+                     : "memory");
+    };
+    int s_tap = 0, s_kh = 0, s_kw = 0, s_ci0 = 0;   // scalar walk over (tap, channel slice)
+    // One DMA instruction occupies the wave's issue port for ~60 cycles; a stage needs LPS of them.  They are issued
+    // ONE AT A TIME, each behind a chain of four MFMAs (256 cycles of matrix-pipe work already queued), never
+    // back to back: piece p < 4 moves A chunk p, piece p >= 4 moves weight chunk p-4 of stage `kt` into ring slot `slot`.
+    auto dma_piece = [&](int p, int kt, int slot) {
+        if (p < 4) {
+            const unsigned sa = __builtin_amdgcn_readfirstlane(
+                lds_base + (unsigned)((slot * STAGE + (wave * 4 + p) * 8 * BK) * 4));
+            const int toff = (s_kh * a.W + s_kw) * a.ldx + s_ci0;
+            const float *src = ((amask[p] >> s_tap) & 1u) ? xin + (aoff[p] + toff) : a.zeros;
+            dma16(src, sa);
+        } else {
+            const unsigned sb = __builtin_amdgcn_readfirstlane(
+                lds_base + (unsigned)((slot * STAGE + BM * BK + (wave * B_ROWS + (p - 4)) * 8 * BK) * 4));
+            dma16(wsrc[p - 4] + kt * BK, sb);
+        }
+        if (p == LPS - 1) {
+            s_ci0 += BK;
+            if (s_ci0 == a.Cin) {
+                s_ci0 = 0;
+                ++s_tap;
+                if (++s_kw == ph.KW) { s_kw = 0; ++s_kh; }
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
-            const int rem = rem0 + row;
-            const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
-            const size_t opix = ((size_t)img * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
-            float *yo = a.y + opix * a.ldy + n0 + wave_n * 32 * WN + col;
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int j = 0; j < WN; ++j) yo[j * 32] = acc[i][j][r];
-        }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- epilogue 2: per-tile InstanceNorm statistics (mean, M2) per channel over the tile's 128 pixels.
-    // Reduced per 32-row MFMA tile first and combined over the four row tiles in a fixed order, so the numbers do not
-    // depend on which wave layout (BN/WM/WN variant) produced them: results stay bit-identical across batch sizes.
-    if (a.partials) {
-        float2 *red = reinterpret_cast<float2 *>(smem);  // [BM/32][BN], LDS is free again after the last barrier
+    // fragment addressing: row = base + (lane&31); 16-B column (2*k8 + (lane>>5)) ^ f(row); f only depends on lane
+    const int frow = lane & 31;
+    const int fsw = (frow >> 1) & 7;
+    const int a_row = (wave_m * 32 * WM + frow) * BK;
+    const int b_row = BM * BK + (wave_n * 32 * WN + frow) * BK;
+    int fcol[BK / 8];
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+    for (int k8 = 0; k8 < BK / 8; ++k8) fcol[k8] = (((2 * k8 + (lane >> 5)) ^ fsw) * 4);
+
+    // iteration kt: MFMAs of stage kt from ring slot `slot`, DMA pieces of stage kt+2 (if any) in their shadow
+    auto stage_body = [&](int kt, int slot, auto do_dma) {
+        const float *As = smem + slot * STAGE + a_row;
+        const float *Bs = smem + slot * STAGE + b_row;
+        int slot2 = slot + (NS - 1);
+        if (slot2 >= NS) slot2 -= NS;
+        float4 af[WM], bf[WN];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                float s = 0.f;
+        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + fcol[0]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-                s += __shfl_xor(s, 32);
-                const float mu = s * (1.f / 32.f);
-                float q = 0.f;
+        for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + fcol[0]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = acc[i][j][r] - mu;
-                    q += d * d;
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            float4 an[WM], bn4[WN];
+            if (k8 + 1 < BK / 8 && !(DBG & 8)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) an[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + fcol[k8 + 1]);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bn4[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + fcol[k8 + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    const int piece = k8 * (WM * WN) + i * WN + j;
+                    if (decltype(do_dma)::value && piece < LPS && !(DBG & 1)) {
+                        __builtin_amdgcn_sched_barrier(0);   // keep the piece where it is: behind this MFMA chain
+                        dma_piece(piece, kt + (NS - 1), slot2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                q += __shfl_xor(q, 32);
-                if (lane < 32) red[(wave_m * WM + i) * BN + wave_n * 32 * WN + j * 32 + col] = make_float2(mu, q);
-            }
-        __syncthreads();
-        if (tid < BN) {
-            constexpr int RT = BM / 32;
-            float mean = 0.f;
+            if (k8 + 1 < BK / 8 && !(DBG & 8)) {
 #pragma unroll
-            for (int w = 0; w < RT; ++w) mean += red[w * BN + tid].x;
-            mean *= 1.f / RT;
-            float m2 = 0.f;
+                for (int i = 0; i < WM; ++i) af[i] = an[i];
 #pragma unroll
-            for (int w = 0; w < RT; ++w) {
-                const float2 p = red[w * BN + tid];
-                const float d = p.x - mean;
-                m2 += p.y + 32.f * d * d;
+                for (int j = 0; j < WN; ++j) bf[j] = bn4[j];
             }
-            a.partials[((size_t)blockIdx.z * a.mtiles + blockIdx.x) * a.Cout + n0 + tid] = make_float2(mean, m2);
         }
+        // stage kt+1 must have landed (for every wave) before anyone reads it: only this iteration's own pieces
+        // (stage kt+2) may still be in flight
+        if (decltype(do_dma)::value) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail: drain (a few iterations, not worth counting)
+        }
+        if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    static_assert(LPS <= (BK / 8) * WM * WN, "not enough MFMA chains to hide the DMA pieces of a stage");
+
+    const int nk = ph.Kpad / BK;
+    // prologue: NS-1 stages in flight, the first one must have landed
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) {
+#pragma unroll
+            for (int p = 0; p < LPS; ++p) dma_piece(p, st, st);
+        }
+    if (nk >= NS - 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int slot = 0, kt = 0;
+    for (; kt + (NS - 1) < nk; ++kt) {
+        stage_body(kt, slot, yes{});
+        if (++slot == NS) slot = 0;
+    }
+    for (; kt < nk; ++kt) {
+        stage_body(kt, slot, no{});
+        if (++slot == NS) slot = 0;
+    }
+    igemm_epilogue<BN, WM, WN>(a, ph, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -455,7 +675,11 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 
 }  // namespace
 
-int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st)
+const char *const kIgemmVariantNames[kIgemmVariants] = {
+    "conv_igemm_f32<64, 1, 2, false, 0>", "conv_igemm_f32<128, 2, 2, false, 0>", "conv_igemm_f32<64, 1, 2, true, 0>",
+    "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>"};
+
+int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
 {
     if (a.Cout % bn != 0 || (bn != 64 && bn != 128))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cout=%d not a multiple of the %d-channel tile", a.Cout, bn);
@@ -482,6 +706,49 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st)
     }
     const bool small_cin = a.Cin < BK;
     if (small_cin && bn != 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d < %d is only built for the 64-channel tile", a.Cin, BK);
+    // Kernel choice (tools/igemm_bench.hip, warm clocks, TFLOP/s): the 64-channel tile runs best DMA-fed (118-122 vs
+    // 115-120); the 128-channel tile runs best DMA-fed when the grid is a single round of one workgroup per CU
+    // (the 96 KiB ring allows one per CU anyway: 127 vs 122) and register-staged when several rounds are queued
+    // (74 KiB: two resident workgroups per CU, 130 vs 126).  Both kernels add the products of an output in the
+    // same order, so the choice never changes a result bit.
+    int ncu = 256;
+    {
+        static int cached_cus = 0;
+        if (!cached_cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cached_cus = prop.multiProcessorCount;
+            else
+                cached_cus = 256;
+        }
+        ncu = cached_cus;
+    }
+    const long nblocks = (long)grid.x * grid.y * grid.z;
+    const bool use_dma = !small_cin && a.zeros && (bn == 64 || nblocks <= ncu);
+    if (use_dma) {
+        // DMA-fed 3-stage ring: (BM + bn) * 32 floats per stage
+        const size_t lds_dma = (size_t)3 * (BM + bn) * BK * sizeof(float);
+        static bool dma_opt_in = false;
+        if (!dma_opt_in) {
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<64, 1, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 64) * BK * (int)sizeof(float)));
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<128, 2, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 128) * BK * (int)sizeof(float)));
+            dma_opt_in = true;
+        }
+        for (int p = 0; p < a.nphase; ++p)
+            if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the DMA path");
+        if (bn == 64) {
+            conv_igemm_dma_f32<64, 1, 2><<<grid, 256, lds_dma, st>>>(a);
+        } else {
+            conv_igemm_dma_f32<128, 2, 2><<<grid, 256, lds_dma, st>>>(a);
+        }
+        if (variant) *variant = bn == 64 ? kIgemmDma64 : kIgemmDma128;
+        LWG_LAUNCH_CHECK("conv_igemm_dma_f32");
+        return LWG_OK;
+    }
+    if (variant) *variant = small_cin ? kIgemmSmallCin : (bn == 64 ? kIgemmReg64 : kIgemmReg128);
     if (small_cin) {
         conv_igemm_f32<64, 1, 2, true><<<grid, 256, lds, st>>>(a);
     } else if (bn == 64) {
@@ -492,6 +759,72 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st)
     LWG_LAUNCH_CHECK("conv_igemm_f32");
     return LWG_OK;
 }
+
+#ifdef LWG_IGEMM_BENCH
+// ablation launcher for tools/igemm_bench.hip
+template <int DBG>
+static void launch_dbg(const ConvArgs &a, int bn, hipStream_t st)
+{
+    const dim3 grid(a.mtiles, a.Cout / bn, a.nphase);
+    const size_t lds = (size_t)2 * (BM + bn) * LDK * sizeof(float);
+    if (bn == 64) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2, false, DBG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv_igemm_f32<64, 1, 2, false, DBG><<<grid, 256, lds, st>>>(a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<128, 2, 2, false, DBG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv_igemm_f32<128, 2, 2, false, DBG><<<grid, 256, lds, st>>>(a);
+    }
+}
+template <int DBG>
+static void launch_dma_dbg(const ConvArgs &a, int bn, hipStream_t st)
+{
+    const dim3 grid(a.mtiles, a.Cout / bn, a.nphase);
+    const size_t lds = (size_t)3 * (BM + bn) * BK * sizeof(float);
+    if (bn == 64) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<64, 1, 2, DBG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv_igemm_dma_f32<64, 1, 2, DBG><<<grid, 256, lds, st>>>(a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<128, 2, 2, DBG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv_igemm_dma_f32<128, 2, 2, DBG><<<grid, 256, lds, st>>>(a);
+    }
+}
+int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
+{
+    switch (dbg) {
+        case 0: launch_dbg<0>(a, bn, st); break;
+        case 1: launch_dbg<1>(a, bn, st); break;
+        case 3: launch_dbg<3>(a, bn, st); break;
+        case 7: launch_dbg<7>(a, bn, st); break;
+        case 15: launch_dbg<15>(a, bn, st); break;
+        case 16: launch_dbg<16>(a, bn, st); break;
+        case 4: launch_dbg<4>(a, bn, st); break;
+        case 100: launch_dma_dbg<0>(a, bn, st); break;
+        case 116: launch_dma_dbg<16>(a, bn, st); break;
+        case 101: launch_dma_dbg<1>(a, bn, st); break;
+        case 104: launch_dma_dbg<4>(a, bn, st); break;
+        case 140: {   // 4-slot ring (3 stages in flight)
+            const dim3 grid(a.mtiles, a.Cout / bn, a.nphase);
+            const size_t lds4 = (size_t)4 * (BM + bn) * BK * sizeof(float);
+            if (bn == 64) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<64, 1, 2, 0, 4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                conv_igemm_dma_f32<64, 1, 2, 0, 4><<<grid, 256, lds4, st>>>(a);
+            } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<128, 2, 2, 0, 4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                conv_igemm_dma_f32<128, 2, 2, 0, 4><<<grid, 256, lds4, st>>>(a);
+            }
+            break;
+        }
+        default: return LWG_ERR_INVALID_ARG;
+    }
+    return LWG_OK;
+}
+#endif
 
 int launch_in_finalize(const float2 *partials, int nphase, int mtiles, int N, int C, const float *gamma,
                        const float *beta, float eps, float2 *scale_shift, hipStream_t st)

@@ -65,14 +65,16 @@ struct lwg_generator {
     float *tscale[2][kNDown] = {};    // resized flows per level (two sets for swap)
     float2 *partials = nullptr;
     float2 *ss = nullptr;             // scale/shift [max_batch][8cd]
+    float *zeros = nullptr;           // 256 B of zeros: source of out-of-image taps for the DMA-fed conv kernel
     int trunk_out = 0;                // which trunk buffer holds the residual trunk's output
 
     // profiling of the implicit-GEMM kernel
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
-    double prof_flops = 0.0;
-    int prof_launches = 0;
+    std::vector<int> ev_variant;      // kernel instantiation of each bracketed launch
+    double prof_flops[kIgemmVariants] = {};
+    int prof_launches[kIgemmVariants] = {};
 };
 
 namespace lwg {
@@ -294,6 +296,7 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     a.Cin = L.cin_pad;
     a.cin_log2 = ilog2(L.cin_pad);
     a.w = L.w;
+    a.zeros = g->zeros;
     a.y = raw;
     a.ldy = L.cout;
     a.Cout = L.cout;
@@ -308,23 +311,26 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     }
     a.mtiles = N * a.Hm * a.Wm / kConvBM;
     a.partials = L.has_norm ? g->partials : nullptr;
-    // tile width: 64 channels keeps >= 2 workgroups per CU on the 32x32 trunk (batch 8: 512 tiles on 256 CUs)
-    const long tiles128 = (long)a.mtiles * (L.cout / 128 > 0 ? L.cout / 128 : 1) * L.nphase;
-    const int bn = (L.cout % 128 == 0 && tiles128 >= 2 * 256) ? 128 : 64;
+    // tile width: 128 channels once that still gives every CU a workgroup (the 32x32 trunk at batch 8 is exactly 256
+    // tiles), else 64 for more, smaller tiles (small batches)
+    const long tiles128 = (long)a.mtiles * (L.cout / 128) * L.nphase;
+    const int bn = (L.cout % 128 == 0 && tiles128 >= 256) ? 128 : 64;
 
     hipEvent_t e1 = nullptr;
     if (g->profile) {
         const int rc = prof_begin(g, st, &e1);
         if (rc != LWG_OK) return rc;
     }
-    int rc = launch_conv_igemm(a, bn, st);
+    int variant = 0;
+    int rc = launch_conv_igemm(a, bn, st, &variant);
     if (rc != LWG_OK) return rc;
     if (g->profile) {
         LWG_HIP(hipEventRecord(e1, st));
         double k_alg = 0;
         for (int p = 0; p < L.nphase; ++p) k_alg += (double)L.ph[p].ntaps * L.cin;
-        g->prof_flops += 2.0 * N * a.Hm * a.Wm * (double)L.cout * k_alg;
-        g->prof_launches += 1;
+        g->prof_flops[variant] += 2.0 * N * a.Hm * a.Wm * (double)L.cout * k_alg;
+        g->prof_launches[variant] += 1;
+        g->ev_variant.push_back(variant);
     }
     if (L.has_norm) {
         rc = launch_in_finalize(g->partials, L.nphase, a.mtiles, N, L.cout, L.gamma, L.beta, kInEps, g->ss, st);
@@ -542,6 +548,11 @@ int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, int conv
         rc = dev_alloc(&p, B * (size_t)(cd << kNDown) * 2);
         g->ss = reinterpret_cast<float2 *>(p);
     }
+    if (rc == LWG_OK) rc = dev_alloc(&g->zeros, 64);
+    if (rc == LWG_OK && hipMemset(g->zeros, 0, 64 * sizeof(float)) != hipSuccess) {
+        set_error("hipMemset of the zero page failed");
+        rc = LWG_ERR_HIP;
+    }
     if (rc != LWG_OK) {
         lwg_generator_destroy(g);
         return rc;
@@ -565,6 +576,7 @@ void lwg_generator_destroy(lwg_generator *g)
         for (auto p : k) fr(p);
     fr(g->partials);
     fr(g->ss);
+    fr(g->zeros);
     for (auto e : g->ev_pool) (void)hipEventDestroy(e);
     delete g;
 }
@@ -726,27 +738,41 @@ int lwg_generator_profile(lwg_generator *g, int enable)
     LWG_REQUIRE(g, "profile: NULL handle");
     g->profile = enable != 0;
     g->ev_used = 0;
-    g->prof_flops = 0.0;
-    g->prof_launches = 0;
+    g->ev_variant.clear();
+    for (int v = 0; v < kIgemmVariants; ++v) {
+        g->prof_flops[v] = 0.0;
+        g->prof_launches[v] = 0;
+    }
     return LWG_OK;
 }
 
-int lwg_generator_profile_read(lwg_generator *g, int *launches, double *total_ms, double *total_flops)
+int lwg_generator_profile_variants(void) { return kIgemmVariants; }
+
+const char *lwg_generator_profile_variant_name(int variant)
+{
+    return variant >= 0 && variant < kIgemmVariants ? kIgemmVariantNames[variant] : "";
+}
+
+int lwg_generator_profile_read(lwg_generator *g, int variant, int *launches, double *total_ms, double *total_flops)
 {
     LWG_REQUIRE(g && launches && total_ms && total_flops, "profile_read: NULL argument");
+    LWG_REQUIRE(variant >= -1 && variant < kIgemmVariants, "profile_read: variant %d out of range", variant);
     double ms = 0.0;
     for (size_t i = 0; i + 1 < g->ev_used; i += 2) {
+        if (variant >= 0 && g->ev_variant[i / 2] != variant) continue;
         LWG_HIP(hipEventSynchronize(g->ev_pool[i + 1]));
         float t = 0.f;
         LWG_HIP(hipEventElapsedTime(&t, g->ev_pool[i], g->ev_pool[i + 1]));
         ms += t;
     }
-    *launches = g->prof_launches;
+    *launches = 0;
+    *total_flops = 0.0;
+    for (int v = 0; v < kIgemmVariants; ++v)
+        if (variant < 0 || v == variant) {
+            *launches += g->prof_launches[v];
+            *total_flops += g->prof_flops[v];
+        }
     *total_ms = ms;
-    *total_flops = g->prof_flops;
-    g->ev_used = 0;
-    g->prof_flops = 0.0;
-    g->prof_launches = 0;
     return LWG_OK;
 }
 

@@ -307,8 +307,19 @@ class ImpersonatorGenerator(NetworkBase):
     def profile(self, enable=True):
         _lib.check(_lib.load().lwg_generator_profile(self._ensure_handle(1), int(enable)))
 
-    def profile_read(self):
+    def profile_read(self, variant=-1):
+        """(launches, total_ms, algorithmic_flops) of the bracketed conv launches: all kernels (variant=-1) or one."""
         n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
-        _lib.check(_lib.load().lwg_generator_profile_read(self._ensure_handle(1), ctypes.byref(n), ctypes.byref(ms),
+        _lib.check(_lib.load().lwg_generator_profile_read(self._ensure_handle(1), variant, ctypes.byref(n), ctypes.byref(ms),
                                                           ctypes.byref(fl)))
         return n.value, ms.value, fl.value
+
+    def profile_table(self):
+        """{kernel name as rocprofv3 prints it: (launches, total_ms, flops)} for every variant that ran."""
+        lib = _lib.load()
+        out = {}
+        for v in range(lib.lwg_generator_profile_variants()):
+            n, ms, fl = self.profile_read(v)
+            if n:
+                out[lib.lwg_generator_profile_variant_name(v).decode()] = (n, ms, fl)
+        return out

@@ -175,12 +175,17 @@ LWG_API int lwg_generator_swap(lwg_generator *g, const float *tsf_inputs, int la
  * Copies min(n_floats, buffer size) floats. */
 LWG_API int lwg_generator_peek(lwg_generator *g, int which, float *dst, size_t n_floats, lwg_stream_t stream);
 
-/* Kernel timing for bench.py's roofline: when enabled, every launch of the implicit-GEMM conv kernel is
- * bracketed by HIP events on the launch stream.  read() synchronises those events and returns the launch
- * count, their summed duration and the algorithmic FLOPs (2*M*N*K of the convolution, zero padding
- * included as the reference's cuDNN would count it) they covered, then clears the record. */
+/* Kernel timing for bench.py's roofline: when enabled, every launch of an implicit-GEMM conv kernel is bracketed by
+ * HIP events on the launch stream.  The conv runs as one of lwg_generator_profile_variants() kernel instantiations
+ * (names as rocprofv3 prints them: lwg_generator_profile_variant_name).  read() synchronises the events and returns,
+ * for one variant (or all of them with variant = -1), the launch count, the summed duration and the algorithmic
+ * FLOPs (2*M*N*K of the convolution with its real taps and channels; zero padding counted as cuDNN would count it,
+ * the kernel's own K/channel padding not counted).  profile(enable) clears the record. */
 LWG_API int lwg_generator_profile(lwg_generator *g, int enable);
-LWG_API int lwg_generator_profile_read(lwg_generator *g, int *launches, double *total_ms, double *total_flops);
+LWG_API int lwg_generator_profile_variants(void);
+LWG_API const char *lwg_generator_profile_variant_name(int variant);
+LWG_API int lwg_generator_profile_read(lwg_generator *g, int variant, int *launches, double *total_ms,
+                                       double *total_flops);
 
 #ifdef __cplusplus
 }

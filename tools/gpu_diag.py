@@ -52,6 +52,7 @@ def main():
     G.profile(True)
     G.inference(enc, rs, out["tsf_inputs"], out["T"], bg_img=bg)
     n, ms, fl = G.profile_read()
+    res['by_kernel'] = {k: (v[0], round(v[1], 3), round(v[2] / v[1] / 1e9, 1)) for k, v in G.profile_table().items()}
     G.profile(False)
     res["igemm_launches"], res["igemm_ms"], res["igemm_tflops"] = n, ms, fl / ms / 1e9
     res["fps"] = bs / ((res["transfer_ms"] + res["inference_ms"]) / 1e3)
