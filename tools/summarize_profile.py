@@ -1,0 +1,62 @@
+"""Turns rocprofv3 CSV output into the small tracked summaries under profiles/ (development aid).
+
+    python tools/summarize_profile.py stats  <kernel_stats.csv> <out.md> [bench.json]
+    python tools/summarize_profile.py pmc    <counter_collection.csv> <kernel_trace.csv> <out.md>
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"namespace\)::(\w+(<[^>]*>)?)", name)
+    return m.group(1) if m else name[:70]
+
+
+def stats(path, out, bench=None):
+    rows = list(csv.DictReader(open(path)))
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline\n\n")
+        if bench:
+            f.write("bench.py line of the same code (un-profiled run):\n\n```json\n%s\n```\n\n" % open(bench).read().strip())
+        f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in rows[:22]:
+            f.write("| `%s` | %s | %.3f | %.1f | %.2f |\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                            float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+
+
+def pmc(counters, trace, out):
+    disp = collections.OrderedDict()
+    for r in csv.DictReader(open(counters)):
+        d = disp.setdefault(r["Dispatch_Id"], {"name": short(r["Kernel_Name"]), "grid": r["Grid_Size"]})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace))}
+    agg = collections.OrderedDict()
+    for k, d in disp.items():
+        if "igemm" not in d["name"]:
+            continue
+        a = agg.setdefault((d["name"], d["grid"]), collections.defaultdict(float))
+        a["n"] += 1
+        a["ns"] += dur.get(k, 0)
+        for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CU_CYCLES"):
+            a[c] += d.get(c, 0.0)
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE (own pass) -- bench.py --steps 2\n\n"
+                "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs\n"
+                "(GRBM_GUI_ACTIVE is summed over the 8 XCDs; effective clock = that / 8 / duration).  Counter passes serialise\n"
+                "kernels and run slower than the un-profiled bench.\n\n"
+                "| kernel | grid (threads) | launches | avg us | eff. clock GHz | MFMA busy / SIMD-cycles |\n|---|---|---|---|---|---|\n")
+        for (name, grid), a in agg.items():
+            cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+            util = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc) if cyc else 0.0
+            f.write("| `%s` | %s | %d | %.1f | %.2f | %.3f |\n" % (name, grid, a["n"], a["ns"] / a["n"] / 1e3,
+                                                                cyc / a["ns"] if a["ns"] else 0, util))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
