@@ -48,7 +48,8 @@ _PROTOS = {
     "lwg_generator_src_feature_shape": (_i, [_vp, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     "lwg_generator_encode_src": (_i, [_vp, _vp, _c.POINTER(_vp), _vp]),
     "lwg_generator_inference": (_i, [_vp, _vp, _i, _vp, _i, _c.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp, _vp]),
-    "lwg_generator_swap": (_i, [_vp, _vp, _i, _vp, _vp, _i, _c.POINTER(_vp), _c.POINTER(_vp), _i, _vp, _vp, _vp]),
+    "lwg_generator_swap": (_i, [_vp, _vp, _i, _vp, _vp, _i, _c.POINTER(_vp), _c.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp,
+                                _vp]),
     "lwg_generator_peek": (_i, [_vp, _i, _vp, _sz, _vp]),
     "lwg_generator_profile": (_i, [_vp, _i]),
     "lwg_generator_profile_variants": (_i, []),

@@ -691,14 +691,15 @@ int lwg_generator_inference(lwg_generator *g, const float *tsf_inputs, int layou
 
 int lwg_generator_swap(lwg_generator *g, const float *tsf_inputs, int layout, const float *T12, const float *T21,
                        int bs, const float *const *feats12_nhwc, const float *const *feats21_nhwc, int align_corners,
-                       float *color, float *mask, lwg_stream_t stream)
+                       float *color, float *mask, const float *bg, int bg_bs, float *pred, lwg_stream_t stream)
 {
     int rc = check_ready(g, bs);
     if (rc != LWG_OK) return rc;
     LWG_REQUIRE(tsf_inputs && T12 && T21 && feats12_nhwc && feats21_nhwc, "swap: NULL argument");
+    LWG_REQUIRE(!pred || (bg && (bg_bs == 1 || bg_bs == bs)), "swap: pred needs bg with batch 1 or %d", bs);
     const float *const Ts[2] = {T12, T21};
     const float *const *fs[2] = {feats12_nhwc, feats21_nhwc};
-    return run_tsf(g, tsf_inputs, layout, Ts, fs, 2, bs, align_corners, color, mask, nullptr, 0, nullptr, as_stream(stream));
+    return run_tsf(g, tsf_inputs, layout, Ts, fs, 2, bs, align_corners, color, mask, bg, bg_bs, pred, as_stream(stream));
 }
 
 int lwg_generator_peek(lwg_generator *g, int which, float *dst, size_t n_floats, lwg_stream_t stream)

@@ -13,6 +13,7 @@ def default_opt(batch_size=8, image_size=256, **over):
         image_size=image_size, tex_size=3, repeat_num=6, map_name='uv_seg', gen_name='impersonator',
         batch_size=batch_size, bg_model='ORIGINAL', bg_ks=13, ft_ks=3, only_vis=False, has_detector=False,
         front_warp=False, load_path='', load_epoch=-1, smpl_model='', hmr_model='', align_corners=False,
+        bg_replace=False, swap_part='body', uv_mapping='', part_info='',
         is_train=False)
     for k, v in over.items():
         setattr(opt, k, v)
@@ -33,9 +34,11 @@ def synthetic_smpls(num_frames, seed=0):
     return np.concatenate([cam, pose, shape], 1).astype(np.float32)
 
 
-def build_synthetic_imitator(batch_size=8, seed=0, image_size=256, affine="identity", opt=None):
+def build_synthetic_imitator(batch_size=8, seed=0, image_size=256, affine="identity", opt=None, model="imitator"):
     """Returns (imitator, src_smpl (85,), src_img (3,H,W) in [-1,1], bg_img (3,H,W))."""
     from .models.imitator import Imitator
+    from .models.swapper import Swapper
+    from .models.viewer import Viewer
     from .networks.batch_smpl import HumanModelRecovery, synthetic_smpl_params
     from .networks.generator import ImpersonatorGenerator
     from .utils.nmr import SMPLRenderer
@@ -51,7 +54,13 @@ def build_synthetic_imitator(batch_size=8, seed=0, image_size=256, affine="ident
     sd = synthetic.random_state_dict(shapes, seed=seed, affine=affine)
     gen.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     hmr = HumanModelRecovery(smpl_params=synthetic_smpl_params(seed))
-    imitator = Imitator(opt, hmr=hmr, render=render, generator=gen)
+    if model == "swapper":
+        part_fn, part_faces = synthetic.part_map_fn(rest, faces)
+        imitator = Swapper(opt, hmr=hmr, render=render, generator=gen, part_fn=part_fn, part_faces=part_faces)
+    elif model == "viewer":
+        imitator = Viewer(opt, hmr=hmr, render=render, generator=gen)
+    else:
+        imitator = Imitator(opt, hmr=hmr, render=render, generator=gen)
     src_smpl = synthetic_smpls(1, seed=seed + 1)[0]
     src_smpl[3:75] = 0.0
     src_img = synthetic.smooth_image(seed + 11, (1, 3, image_size, image_size))[0]

@@ -11,6 +11,12 @@ class ModelsFactory(object):
         if model_name == 'imitator':
             from .imitator import Imitator
             return Imitator(*args, **kwargs)
+        if model_name == 'swapper':
+            from .swapper import Swapper
+            return Swapper(*args, **kwargs)
+        if model_name == 'viewer':
+            from .viewer import Viewer
+            return Viewer(*args, **kwargs)
         raise ValueError("Model %s is not part of the MI355X Imitator.forward path" % model_name)
 
 

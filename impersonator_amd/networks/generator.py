@@ -243,8 +243,10 @@ class ImpersonatorGenerator(NetworkBase):
         return (color, mask) if bg_img is None else (pred, color, mask)
 
     @torch.no_grad()
-    def swap(self, tsf_inputs, src_encoder_outs12, src_encoder_outs21, src_resnet_outs12, src_resnet_outs21, T12, T21):
-        """generator.py:245-275."""
+    def swap(self, tsf_inputs, src_encoder_outs12, src_encoder_outs21, src_resnet_outs12, src_resnet_outs21, T12, T21,
+             bg_img=None):
+        """generator.py:245-275 -> (tsf_img, tsf_mask); with `bg_img` (extension) the blend of models/swapper.py:269
+        is fused and (pred, tsf_img, tsf_mask) is returned."""
         self._need_cuda(tsf_inputs, T12, T21)
         bs = tsf_inputs.shape[0]
         h = self._ensure_handle(bs)
@@ -255,10 +257,15 @@ class ImpersonatorGenerator(NetworkBase):
         s = self.image_size
         color = torch.empty((bs, 3, s, s), device=x.device, dtype=torch.float32)
         mask = torch.empty((bs, 1, s, s), device=x.device, dtype=torch.float32)
+        pred = bg = None
+        if bg_img is not None:
+            bg = bg_img.float().contiguous()
+            pred = torch.empty_like(color)
         _lib.check(_lib.load().lwg_generator_swap(h, _lib.ptr(x), layout, _lib.ptr(T12), _lib.ptr(T21), bs,
                                                   _lib.ptr_array(f12), _lib.ptr_array(f21), int(self.align_corners),
-                                                  _lib.ptr(color), _lib.ptr(mask), _lib.stream_ptr()))
-        return color, mask
+                                                  _lib.ptr(color), _lib.ptr(mask), _lib.ptr(bg),
+                                                  0 if bg is None else bg.shape[0], _lib.ptr(pred), _lib.stream_ptr()))
+        return (color, mask) if bg_img is None else (pred, color, mask)
 
     @torch.no_grad()
     def resize_trans(self, x, T):

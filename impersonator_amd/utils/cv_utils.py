@@ -29,3 +29,14 @@ def save_cv2_img(img, path, image_size=None, normalize=False):
         img = np.asarray(Image.fromarray(img).resize((image_size, image_size), Image.BILINEAR))
     Image.fromarray(img).save(path)
     return img
+
+
+def euler2matrix(rt):
+    """utils/cv_utils.py:333-353: R = Rz @ Ry @ Rx from euler angles (3,)."""
+    cx, sx = np.cos(rt[0]), np.sin(rt[0])
+    cy, sy = np.cos(rt[1]), np.sin(rt[1])
+    cz, sz = np.cos(rt[2]), np.sin(rt[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=np.float32)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=np.float32)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=np.float32)
+    return np.dot(Rz, np.dot(Ry, Rx))

@@ -98,3 +98,20 @@ def create_mapping(map_name, mapping_path='assets/pretrains/mapper.txt',
     if contain_bg:
         map_fn = np.concatenate([map_fn, bg], axis=0)
     return map_fn.astype(np.float32)
+
+
+def get_part_face_ids(part_type, mapping_path='assets/pretrains/mapper.txt',
+                      part_info='assets/pretrains/smpl_part_info.json', fill_back=False):
+    """utils/mesh.py:424-445 for part_type == 'par': {part name: face ids}, names sorted."""
+    if part_type != 'par':
+        raise ValueError('part type {} not supported'.format(part_type))
+    nf = get_f2vts(mapping_path, fill_back=fill_back).shape[0]
+    with open(part_info, 'r') as reader:
+        parts = json.load(reader)
+    out = {}
+    for name in sorted(parts.keys()):
+        faces = list(parts[name]['face'])
+        if fill_back:
+            faces = faces + [f + nf // 2 for f in faces]
+        out[name] = faces
+    return out

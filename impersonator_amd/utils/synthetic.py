@@ -112,6 +112,21 @@ def front_map_fn(rest, faces):
     return tab
 
 
+def part_map_fn(rest, faces, num_parts=10):
+    """Stand-in for `create_mapping('par', ...)` / `get_part_face_ids('par')` (utils/mesh.py:247-345): `num_parts`
+    contiguous ring bands along the body axis, part 0 at the top (the 'head').  Returns the (nf+1, num_parts+1)
+    one-hot table with its background row and the list of face-id lists."""
+    bary_y = rest[faces.astype(np.int64)].mean(1)[:, 1]
+    order = np.argsort(-bary_y, kind="stable")
+    nf = faces.shape[0]
+    part_of = np.empty(nf, np.int64)
+    part_of[order] = (np.arange(nf) * num_parts) // nf
+    tab = np.zeros((nf + 1, num_parts + 1), np.float32)
+    tab[np.arange(nf), part_of] = 1.0
+    tab[-1, -1] = 1.0
+    return tab, [np.nonzero(part_of == i)[0].tolist() for i in range(num_parts)]
+
+
 def image(seed, shape=(1, 3, 256, 256)):
     """U(-1,1) image-like tensor (source image / background stand-in)."""
     rng = np.random.default_rng(seed)

@@ -162,11 +162,12 @@ LWG_API int lwg_generator_inference(lwg_generator *g, const float *tsf_inputs, i
                                     const float *const *feats_nhwc, int align_corners, float *color, float *mask,
                                     const float *bg, int bg_bs, float *pred, lwg_stream_t stream);
 
-/* ImpersonatorGenerator.swap (generator.py:245-275): two warped sources per level. */
+/* ImpersonatorGenerator.swap (generator.py:245-275): two warped sources per level; optional fused blend
+ * pred = mask*bg + (1-mask)*color of Swapper.forward (models/swapper.py:261-271), bg/pred as in inference. */
 LWG_API int lwg_generator_swap(lwg_generator *g, const float *tsf_inputs, int layout, const float *T12,
                                const float *T21, int bs, const float *const *feats12_nhwc,
                                const float *const *feats21_nhwc, int align_corners, float *color, float *mask,
-                               lwg_stream_t stream);
+                               const float *bg, int bg_bs, float *pred, lwg_stream_t stream);
 
 /* Test hook: copies an internal scratch buffer (device to device) after inference/swap/encode_src.
  * which: 0..2 = concat buffers cat[l] (bs, is>>l, is>>l, 2*conv_dim<<l)  [skip half | decoder half],
