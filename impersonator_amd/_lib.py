@@ -50,6 +50,11 @@ _PROTOS = {
     "lwg_generator_inference": (_i, [_vp, _vp, _i, _vp, _i, _c.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "lwg_generator_swap": (_i, [_vp, _vp, _i, _vp, _vp, _i, _c.POINTER(_vp), _c.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp,
                                 _vp]),
+    "lwg_inpaint_create": (_i, [_c.POINTER(_vp), _i, _i]),
+    "lwg_inpaint_destroy": (None, [_vp]),
+    "lwg_inpaint_load_weight": (_i, [_vp, _c.c_char_p, _vp, _c.POINTER(_c.c_int64), _i]),
+    "lwg_inpaint_missing_weights": (_i, [_vp]),
+    "lwg_inpaint_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lwg_generator_peek": (_i, [_vp, _i, _vp, _sz, _vp]),
     "lwg_generator_profile": (_i, [_vp, _i]),
     "lwg_generator_profile_variants": (_i, []),

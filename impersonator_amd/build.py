@@ -25,6 +25,7 @@ SOURCES = [
     ("smpl.hip", []),
     ("conv.hip", []),
     ("generator.hip", []),
+    ("inpaint.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
 

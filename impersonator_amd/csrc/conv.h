@@ -17,7 +17,7 @@ struct ConvPhase {
 
 // One convolution expressed as (up to 4) implicit GEMMs:  Y[m][co] = sum_k A[m][k] * Wt[co][k],
 //   m -> (image, hm, wm) over an Hm x Wm grid per image, k -> (tap, ci),
-//   A[m][k] = X[image][hm*stride - pad + kh][wm*stride - pad + kw][ci]   (0 outside the image).
+//   A[m][k] = X[image][hm*stride - pad + kh*dil][wm*stride - pad + kw*dil][ci]   (0 outside the image).
 // A stride-2 transposed conv is 4 such GEMMs (one per output parity) with 1/2/2/4 taps and pad 0.
 struct ConvArgs {
     const float *x; int ldx;        // input NHWC, pixel stride in floats (>= Cin: reads a channel slice of a wider buffer)
@@ -27,6 +27,7 @@ struct ConvArgs {
     float *y; int ldy;              // raw (pre-norm) output NHWC
     int Ho, Wo, Cout;
     int Hm, Wm, stride, pad, os;
+    int dil;                        // dilation (>= 1): tap (kh,kw) reads hm*stride - pad + kh*dil
     float2 *partials;               // [nphase][mtiles][Cout] per-tile (mean, M2) of the raw output, or null
     int mtiles;                     // N*Hm*Wm / kConvBM
     int nphase;

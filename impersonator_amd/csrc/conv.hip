@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
         amask[j] = 0ull;
         if (!SMALL_CIN) {
             for (int t = 0, kh = 0, kw = 0; t < ph.ntaps; ++t) {
-                const bool ok = (unsigned)(hi0[j] + kh) < (unsigned)a.H && (unsigned)(wi0[j] + kw) < (unsigned)a.W;
+                const bool ok = (unsigned)(hi0[j] + kh * a.dil) < (unsigned)a.H && (unsigned)(wi0[j] + kw * a.dil) < (unsigned)a.W;
                 amask[j] |= (unsigned long long)ok << t;
                 if (++kw == ph.KW) { kw = 0; ++kh; }
             }
@@ -168,15 +168,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
             const int kg = kt * BK + kq * 4;
             const int tap = kg >> a.cin_log2;
             const int kh = tap / ph.KW, kw = tap - kh * ph.KW;
-            toff = (kh * a.W + kw) * a.ldx + (kg & cin_mask) - kq * 4;  // aoff already carries the lane's kq*4
+            toff = (kh * a.W + kw) * a.dil * a.ldx + (kg & cin_mask) - kq * 4;  // aoff already carries the lane's kq*4
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool ok = tap < ph.ntaps && (unsigned)(hi0[j] + kh) < (unsigned)a.H &&
-                                (unsigned)(wi0[j] + kw) < (unsigned)a.W;
+                const bool ok = tap < ph.ntaps && (unsigned)(hi0[j] + kh * a.dil) < (unsigned)a.H &&
+                                (unsigned)(wi0[j] + kw * a.dil) < (unsigned)a.W;
                 rvalid |= (unsigned)ok << j;
             }
         } else {
-            toff = (s_kh * a.W + s_kw) * a.ldx + s_ci0;
+            toff = (s_kh * a.W + s_kw) * a.dil * a.ldx + s_ci0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) rvalid |= (unsigned)((amask[j] >> s_tap) & 1ull) << j;
             s_ci0 += BK;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
         aoff[j] = (hi0 * a.W + wi0) * a.ldx + src_col * 4;
         unsigned m = 0;
         for (int t = 0, kh = 0, kw = 0; t < ph.ntaps; ++t) {
-            const bool ok = (unsigned)(hi0 + kh) < (unsigned)a.H && (unsigned)(wi0 + kw) < (unsigned)a.W;
+            const bool ok = (unsigned)(hi0 + kh * a.dil) < (unsigned)a.H && (unsigned)(wi0 + kw * a.dil) < (unsigned)a.W;
             m |= (unsigned)ok << t;
             if (++kw == ph.KW) { kw = 0; ++kh; }
         }
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
         if (p < 4) {
             const unsigned sa = __builtin_amdgcn_readfirstlane(
                 lds_base + (unsigned)((slot * STAGE + (wave * 4 + p) * 8 * BK) * 4));
-            const int toff = (s_kh * a.W + s_kw) * a.ldx + s_ci0;
+            const int toff = (s_kh * a.W + s_kw) * a.dil * a.ldx + s_ci0;
             const float *src = ((amask[p] >> s_tap) & 1u) ? xin + (aoff[p] + toff) : a.zeros;
             dma16(src, sa);
         } else {
@@ -685,6 +685,7 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cout=%d not a multiple of the %d-channel tile", a.Cout, bn);
     if ((a.Hm * a.Wm) % BM != 0 || a.mtiles * BM != a.N * a.Hm * a.Wm)
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: %dx%d output grid per image is not a multiple of %d pixels", a.Hm, a.Wm, BM);
+    if (a.dil < 1) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: dilation must be >= 1");
     if ((1 << a.cin_log2) != a.Cin || a.Cin < 4 || (a.ldx & 3))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d must be a power of two >= 4 with a 16-byte aligned pixel stride", a.Cin);
     for (int p = 0; p < a.nphase; ++p)

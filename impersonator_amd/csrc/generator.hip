@@ -301,6 +301,7 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     a.ldy = L.cout;
     a.Cout = L.cout;
     a.nphase = L.nphase;
+    a.dil = 1;
     for (int p = 0; p < L.nphase; ++p) a.ph[p] = L.ph[p];
     if (L.transposed) {
         a.Hm = H; a.Wm = W; a.stride = 1; a.pad = 0; a.os = 2; a.Ho = 2 * H; a.Wo = 2 * W;

@@ -45,7 +45,7 @@ class Imitator(BaseModel):
         elif getattr(opt, 'bg_model', 'ORIGINAL') != 'ORIGINAL':
             self.bgnet = self._create_bgnet()
         else:
-            self.bgnet = None  # bg_model == 'ORIGINAL' would run generator.bg_model (BGNet): not on this path yet
+            self.bgnet = None  # bg_model == 'ORIGINAL' would run generator.bg_model (BGNet), which this build does not cover
         self.hmr = (hmr if hmr is not None else self._create_hmr()).cuda()
         if render is None:
             render = SMPLRenderer(image_size=opt.image_size, tex_size=opt.tex_size, has_front=opt.front_warp,
@@ -57,8 +57,11 @@ class Imitator(BaseModel):
                                       "Imitator.forward() path")
 
     def _create_bgnet(self):
-        raise NotImplementedError("InpaintSANet (networks/inpaintor.py) runs once per source and is the next row of the "
-                                  "hot-path scope table; pass bg_img to personalize() or inject bgnet=")
+        """imitator.py:48-52: InpaintSANet(c_dim=4) with the deepfillv2 checkpoint."""
+        net = NetworksFactory.get_by_name('deepfillv2', c_dim=4, image_size=self._opt.image_size)
+        self._load_params(net, self._opt.bg_model, need_module=False)
+        net.eval()
+        return net.cuda()
 
     def _create_generator(self):
         opt = self._opt
@@ -128,7 +131,7 @@ class Imitator(BaseModel):
         elif self.bgnet is not None:
             src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)
         else:
-            raise NotImplementedError("no background network: pass bg_img (see _create_bgnet)")
+            raise NotImplementedError("bg_model ORIGINAL (BGNet) is not covered: use the InpaintSANet checkpoint or pass bg_img")
 
         ft_mask = 1 - util.morph(src_info['cond'][:, -1:, :, :], ks=opt.ft_ks, mode='erode')
         src_inputs = torch.cat([img * ft_mask, src_info['cond']], dim=1)

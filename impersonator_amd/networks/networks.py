@@ -30,4 +30,7 @@ class NetworksFactory(object):
         if network_name == 'impersonator':
             from .generator import ImpersonatorGenerator
             return ImpersonatorGenerator(*args, **kwargs)
+        if network_name == 'deepfillv2':
+            from .inpaintor import InpaintSANet
+            return InpaintSANet(*args, **kwargs)
         raise ValueError("Network %s is not part of the MI355X Imitator.forward path" % network_name)

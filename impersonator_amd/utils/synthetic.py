@@ -170,3 +170,29 @@ def random_state_dict(shapes, seed=0, affine="random"):
         else:
             raise ValueError("unexpected parameter %s %s" % (key, shape))
     return out
+
+
+def random_inpaintor_state_dict(shapes, seed=0):
+    """Seeded InpaintSANet weights for (key, shape) pairs in state_dict order: kaiming-normal convs
+    (networks/inpaintor.py:30-32), small biases, non-trivial BatchNorm statistics and attention gain so that every
+    term of the gated layers is exercised."""
+    rng = np.random.default_rng(seed + 31337)
+    out = {}
+    for key, shape in shapes:
+        shape = tuple(int(s) for s in shape)
+        if key.endswith("num_batches_tracked"):
+            out[key] = np.zeros(shape, np.int64)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            out[key] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(math.sqrt(2.0 / fan_in)))
+        elif key.endswith("running_var"):
+            out[key] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif key.endswith("running_mean"):
+            out[key] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1))
+        elif key.endswith("gamma"):
+            out[key] = np.full(shape, 0.7, np.float32)
+        elif key.endswith("batch_norm2d.weight"):
+            out[key] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        else:   # conv biases, BatchNorm bias
+            out[key] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1))
+    return out

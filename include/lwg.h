@@ -169,6 +169,26 @@ LWG_API int lwg_generator_swap(lwg_generator *g, const float *tsf_inputs, int la
                                const float *const *feats21_nhwc, int align_corners, float *color, float *mask,
                                const float *bg, int bg_bs, float *pred, lwg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Background inpaintor: replaces what PyTorch dispatches for InpaintSANet(c_dim=4) in eval mode
+ * (networks/inpaintor.py:110-202): 35 gated convolutions with folded BatchNorm, nearest x2 up-sampling,
+ * one self-attention over (image_size/4)^2 tokens, mask compositing and clamps.  Runs once per source image
+ * (models/imitator.py:124-125), batch 1.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lwg_inpaint lwg_inpaint;
+LWG_API int lwg_inpaint_create(lwg_inpaint **out, int c_dim, int image_size);
+LWG_API void lwg_inpaint_destroy(lwg_inpaint *g);
+/* state_dict entries in PyTorch layout (HOST memory), e.g. "coarse_net.3.mask_conv2d.weight" (128,64,4,4),
+ * "refine_upsample_net.2.conv2d.batch_norm2d.running_var" (64,), "refine_attn.gamma" (1,);
+ * "...num_batches_tracked" is accepted and ignored. */
+LWG_API int lwg_inpaint_load_weight(lwg_inpaint *g, const char *key, const float *data_host, const int64_t *shape,
+                                    int ndim);
+LWG_API int lwg_inpaint_missing_weights(const lwg_inpaint *g);
+/* InpaintSANet.forward(imgs, masks) (inpaintor.py:178-202): imgs (1,3,is,is), masks (1,1,is,is) ->
+ * coarse_x [optional], x (refined, clamped), comp_imgs = x*masks + imgs*(1-masks) [optional], all (1,3,is,is). */
+LWG_API int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, float *coarse_x, float *x,
+                                float *comp_imgs, lwg_stream_t stream);
+
 /* Test hook: copies an internal scratch buffer (device to device) after inference/swap/encode_src.
  * which: 0..2 = concat buffers cat[l] (bs, is>>l, is>>l, 2*conv_dim<<l)  [skip half | decoder half],
  *        3 = residual trunk output (bs, is/8, is/8, 8*conv_dim), 4..5 = skipper outputs 0..1,

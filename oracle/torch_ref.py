@@ -230,3 +230,66 @@ def source_p2verts(f2verts):
 
 def state_dict_from_numpy(sd_np):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+
+
+# --------------------------------------------------------------------------- background inpaintor (a16)
+# (in_ch, out_ch, kernel, stride, dilation, up2x, activation) per gated layer of InpaintSANet(c_dim)
+# (networks/inpaintor.py:110-176); padding = get_pad(...) reduces to dilation*(k-1)//2 for stride 1 and 1 for k4/s2.
+def inpaint_layers(c_dim=4, cnum=32):
+    c = cnum
+    coarse = [(c_dim, c, 5, 1, 1, 0, 1), (c, 2 * c, 4, 2, 1, 0, 1), (2 * c, 2 * c, 3, 1, 1, 0, 1),
+              (2 * c, 4 * c, 4, 2, 1, 0, 1), (4 * c, 4 * c, 3, 1, 1, 0, 1), (4 * c, 4 * c, 3, 1, 1, 0, 1),
+              (4 * c, 4 * c, 3, 1, 2, 0, 1), (4 * c, 4 * c, 3, 1, 4, 0, 1), (4 * c, 4 * c, 3, 1, 8, 0, 1),
+              (4 * c, 4 * c, 3, 1, 16, 0, 1), (4 * c, 4 * c, 3, 1, 1, 0, 1), (4 * c, 4 * c, 3, 1, 1, 0, 1),
+              (4 * c, 2 * c, 3, 1, 1, 1, 1), (2 * c, 2 * c, 3, 1, 1, 0, 1), (2 * c, c, 3, 1, 1, 1, 1),
+              (c, c // 2, 3, 1, 1, 0, 1), (c // 2, 3, 3, 1, 1, 0, 0)]
+    refine_conv = [(c_dim, c, 5, 1, 1, 0, 1), (c, c, 4, 2, 1, 0, 1), (c, 2 * c, 3, 1, 1, 0, 1),
+                   (2 * c, 2 * c, 4, 2, 1, 0, 1), (2 * c, 4 * c, 3, 1, 1, 0, 1), (4 * c, 4 * c, 3, 1, 1, 0, 1),
+                   (4 * c, 4 * c, 3, 1, 1, 0, 1), (4 * c, 4 * c, 3, 1, 2, 0, 1), (4 * c, 4 * c, 3, 1, 4, 0, 1),
+                   (4 * c, 4 * c, 3, 1, 8, 0, 1), (4 * c, 4 * c, 3, 1, 16, 0, 1)]
+    refine_up = [(4 * c, 4 * c, 3, 1, 1, 0, 1), (4 * c, 4 * c, 3, 1, 1, 0, 1), (4 * c, 2 * c, 3, 1, 1, 1, 1),
+                 (2 * c, 2 * c, 3, 1, 1, 0, 1), (2 * c, c, 3, 1, 1, 1, 1), (c, c // 2, 3, 1, 1, 0, 1),
+                 (c // 2, 3, 3, 1, 1, 0, 0)]
+    return coarse, refine_conv, refine_up
+
+
+def _gated(x, sd, prefix, spec):
+    """GatedConv2dWithActivation / GatedDeConv2dWithActivation in eval mode (networks/inpaintor.py:12-68)."""
+    cin, cout, k, stride, dil, up, act = spec
+    if up:
+        x = F.interpolate(x, scale_factor=2)
+        prefix = prefix + ".conv2d"
+    pad = 1 if (k == 4 and stride == 2) else dil * (k - 1) // 2
+    f = F.conv2d(x, sd[prefix + ".conv2d.weight"], sd[prefix + ".conv2d.bias"], stride, pad, dil)
+    g = F.conv2d(x, sd[prefix + ".mask_conv2d.weight"], sd[prefix + ".mask_conv2d.bias"], stride, pad, dil)
+    y = (F.leaky_relu(f, 0.2) if act else f) * torch.sigmoid(g)
+    return F.batch_norm(y, sd[prefix + ".batch_norm2d.running_mean"], sd[prefix + ".batch_norm2d.running_var"],
+                        sd[prefix + ".batch_norm2d.weight"], sd[prefix + ".batch_norm2d.bias"], False, 0.0, 1e-5)
+
+
+def _self_attention(x, sd, p):
+    """SelfAttention (networks/inpaintor.py:71-107)."""
+    b, c, w, h = x.shape
+    q = F.conv2d(x, sd[p + ".query_conv.weight"], sd[p + ".query_conv.bias"]).view(b, -1, w * h).permute(0, 2, 1)
+    k = F.conv2d(x, sd[p + ".key_conv.weight"], sd[p + ".key_conv.bias"]).view(b, -1, w * h)
+    attn = torch.softmax(torch.bmm(q, k), dim=-1)
+    v = F.conv2d(x, sd[p + ".value_conv.weight"], sd[p + ".value_conv.bias"]).view(b, -1, w * h)
+    out = torch.bmm(v, attn.permute(0, 2, 1)).view(b, c, w, h)
+    return sd[p + ".gamma"] * out + x
+
+
+def inpaint_forward(sd, imgs, masks, c_dim=4):
+    """InpaintSANet.forward (networks/inpaintor.py:178-202) -> (coarse_x, x, comp_imgs)."""
+    coarse, refine_conv, refine_up = inpaint_layers(c_dim)
+    x = torch.cat([imgs * (1 - masks) + masks, masks], dim=1)
+    for i, spec in enumerate(coarse):
+        x = _gated(x, sd, "coarse_net.%d" % i, spec)
+    coarse_x = torch.clamp(x, -1., 1.)
+    x = torch.cat([imgs * (1 - masks) + coarse_x * masks, masks], dim=1)
+    for i, spec in enumerate(refine_conv):
+        x = _gated(x, sd, "refine_conv_net.%d" % i, spec)
+    x = _self_attention(x, sd, "refine_attn")
+    for i, spec in enumerate(refine_up):
+        x = _gated(x, sd, "refine_upsample_net.%d" % i, spec)
+    x = torch.clamp(x, -1., 1.)
+    return coarse_x, x, x * masks + imgs * (1 - masks)

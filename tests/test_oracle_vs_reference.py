@@ -83,3 +83,21 @@ def test_golden_frame_is_reproduced_by_the_oracle():
     assert np.array_equal(fr["fim"].numpy(), g["fim"])
     assert np.array_equal(fr["wim"].numpy()[g["fim"] >= 0], g["wim_covered"])
     assert np.abs(fr["T"].numpy() - g["T"]).max() <= 1e-6
+
+
+def test_inpaintor_restatement_matches_reference(ref):
+    from impersonator_amd.networks.inpaintor import InpaintSANet
+    from impersonator_amd.utils import synthetic
+    net = ref.inpaintor.InpaintSANet(c_dim=4).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert shapes == [(k, tuple(v.shape)) for k, v in InpaintSANet(c_dim=4).state_dict().items()]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.random_inpaintor_state_dict(shapes, 0).items()}
+    net.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 256, 256, generator=gen) * 2 - 1
+    mask = (torch.rand(1, 1, 256, 256, generator=gen) > 0.6).float()
+    with torch.no_grad():
+        a = net(img, mask)
+        b = torch_ref.inpaint_forward(sd, img, mask)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-6)

@@ -52,7 +52,7 @@ int main(int argc, char **argv)
         a.x = x; a.ldx = s.Cin; a.N = s.N; a.H = s.H; a.W = s.H; a.Cin = s.Cin;
         a.cin_log2 = 0; while ((1 << a.cin_log2) < s.Cin) ++a.cin_log2;
         a.w = w; a.zeros = zeros; a.y = y; a.ldy = s.Cout; a.Ho = Ho; a.Wo = Ho; a.Cout = s.Cout;
-        a.Hm = Ho; a.Wm = Ho; a.stride = s.stride; a.pad = pad; a.os = 1;
+        a.Hm = Ho; a.Wm = Ho; a.stride = s.stride; a.pad = pad; a.os = 1; a.dil = 1;
         a.partials = part; a.mtiles = mtiles; a.nphase = 1;
         a.ph[0].KH = a.ph[0].KW = s.k; a.ph[0].ntaps = s.k * s.k; a.ph[0].Kpad = K; a.ph[0].w_off = 0;
         const double flop = 2.0 * s.N * Ho * Ho * (double)s.Cout * K;
