@@ -31,6 +31,7 @@ struct ConvArgs {
     float2 *partials;               // [nphase][mtiles][Cout] per-tile (mean, M2) of the raw output, or null
     int mtiles;                     // N*Hm*Wm / kConvBM
     int nphase;
+    int fuse_phases;                // 1: one workgroup per tile walks all phases (balanced transposed conv)
     ConvPhase ph[4];
 };
 

@@ -37,8 +37,8 @@ constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B align
 
 // Shared epilogue: raw output store + per-tile InstanceNorm statistics.
 template <int BN, int WM, int WN>
-__device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, f32x16 (&acc)[WM][WN], float *smem,
-                                               int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0)
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, int phase, f32x16 (&acc)[WM][WN],
+                                               float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0)
 {
     // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rsel = 4 * (lane >> 5);
@@ -92,7 +92,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                 const float d = p.x - mean;
                 m2 += p.y + 32.f * d * d;
             }
-            a.partials[((size_t)blockIdx.z * a.mtiles + blockIdx.x) * a.Cout + n0 + tid] = make_float2(mean, m2);
+            a.partials[((size_t)phase * a.mtiles + blockIdx.x) * a.Cout + n0 + tid] = make_float2(mean, m2);
         }
     }
 }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     if (kt + 1 < nk) stage_body(kt++, yes{}, no{});
     stage_body(kt, no{}, no{});
 
-    igemm_epilogue<BN, WM, WN>(a, ph, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    igemm_epilogue<BN, WM, WN>(a, ph, blockIdx.z, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -327,12 +327,19 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
 
-    const ConvPhase ph = a.ph[blockIdx.z];
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int hw_m = a.Hm * a.Wm;
     const int img = m0 / hw_m;
     const int rem0 = m0 - img * hw_m;
+
+    // A transposed conv is four sub-pixel phases with 1/2/2/4 taps.  Launched with gridDim.z == 1 (a.fuse_phases) one
+    // workgroup walks all of them for its tile, so every workgroup carries the same 9 taps of work instead of the
+    // 4-tap phase finishing long after the 1-tap one.
+    const int pz0 = a.fuse_phases ? 0 : (int)blockIdx.z;
+    const int pz1 = a.fuse_phases ? a.nphase : pz0 + 1;
+    for (int pz = pz0; pz < pz1; ++pz) {
+    const ConvPhase ph = a.ph[pz];
 
     // ---- DMA geometry: wave w, instruction j moves tile rows (w*4 + j)*8 .. +7; lane -> (row = lane>>3, slot = lane&7)
     const int lr = lane >> 3, ls = lane & 7;
@@ -502,7 +509,9 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
         stage_body(kt, slot, no{});
         if (++slot == NS) slot = 0;
     }
-    igemm_epilogue<BN, WM, WN>(a, ph, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    __syncthreads();   // the statistics scratch aliases the ring: finish reading it before the next phase's DMA
+    }  // phase loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -691,7 +700,7 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
     for (int p = 0; p < a.nphase; ++p)
         if (a.ph[p].Kpad % BK != 0 || a.ph[p].Kpad < a.ph[p].ntaps * a.Cin)
             LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: bad padded K=%d for %d taps x %d channels", a.ph[p].Kpad, a.ph[p].ntaps, a.Cin);
-    const dim3 grid(a.mtiles, a.Cout / bn, a.nphase);
+    const dim3 grid(a.mtiles, a.Cout / bn, a.fuse_phases ? 1 : a.nphase);
     const size_t lds = (size_t)2 * (BM + bn) * LDK * sizeof(float);
     // the 128-channel tile needs 72 KiB of LDS: above the 64 KiB default, well inside gfx950's 160 KiB per CU
     static bool lds_opt_in = false;
@@ -727,6 +736,7 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
     }
     const long nblocks = (long)grid.x * grid.y * grid.z;
     const bool use_dma = !small_cin && a.zeros && (bn == 64 || nblocks <= ncu);
+    if (a.fuse_phases && !use_dma) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: fused phases need the DMA-fed kernel (Cin >= 32, 64-channel tile)");
     if (use_dma) {
         // DMA-fed 3-stage ring: (BM + bn) * 32 floats per stage
         const size_t lds_dma = (size_t)3 * (BM + bn) * BK * sizeof(float);

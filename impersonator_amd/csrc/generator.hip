@@ -313,9 +313,14 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     a.mtiles = N * a.Hm * a.Wm / kConvBM;
     a.partials = L.has_norm ? g->partials : nullptr;
     // tile width: 128 channels once that still gives every CU a workgroup (the 32x32 trunk at batch 8 is exactly 256
-    // tiles), else 64 for more, smaller tiles (small batches)
+    // tiles), else 64 for more, smaller tiles (small batches).  Transposed convs: 64-channel tiles with the four
+    // phases walked inside the workgroup (equal work per workgroup).
     const long tiles128 = (long)a.mtiles * (L.cout / 128) * L.nphase;
-    const int bn = (L.cout % 128 == 0 && tiles128 >= 256) ? 128 : 64;
+    int bn = (L.cout % 128 == 0 && tiles128 >= 256) ? 128 : 64;
+    if (L.transposed) {
+        bn = 64;
+        a.fuse_phases = 1;
+    }
 
     hipEvent_t e1 = nullptr;
     if (g->profile) {
