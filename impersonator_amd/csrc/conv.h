@@ -15,6 +15,24 @@ struct ConvPhase {
     int oy0, ox0;      // output pixel = (hm*os + oy0, wm*os + ox0)
 };
 
+// Split-bf16 format (precision 1).  An fp32 value v is carried as two bf16 terms hi = bf16(v), lo = bf16(v - hi)
+// (16 significand bits, |v - hi - lo| <= 2^-17 |v|).  A run of 32 consecutive values (32 channels of a pixel / 32
+// reduction entries of a weight row) occupies the same 128 bytes it would as fp32: [hi x32 | lo x32].  Pixel strides,
+// channel-slice offsets (multiples of 32) and weight offsets are therefore identical in both formats, the async
+// global->LDS copy moves the same 16-byte chunks, and a product is evaluated as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (bf16 x bf16 is exact in fp32; only lo*lo, ~2^-18, is dropped).
+inline void split_bf16_groups(const float *src, size_t n, float *dst_opaque)   // host helper, n % 32 == 0
+{
+    __bf16 *d = reinterpret_cast<__bf16 *>(dst_opaque);
+    for (size_t g = 0; g < n; g += 32)
+        for (int e = 0; e < 32; ++e) {
+            const float v = src[g + e];
+            const __bf16 hi = (__bf16)v;
+            d[2 * g + e] = hi;
+            d[2 * g + 32 + e] = (__bf16)(v - (float)hi);
+        }
+}
+
 // One convolution expressed as (up to 4) implicit GEMMs:  Y[m][co] = sum_k A[m][k] * Wt[co][k],
 //   m -> (image, hm, wm) over an Hm x Wm grid per image, k -> (tap, ci),
 //   A[m][k] = X[image][hm*stride - pad + kh*dil][wm*stride - pad + kw*dil][ci]   (0 outside the image).
@@ -23,6 +41,8 @@ struct ConvArgs {
     const float *x; int ldx;        // input NHWC, pixel stride in floats (>= Cin: reads a channel slice of a wider buffer)
     int N, H, W, Cin, cin_log2;
     const float *w;
+    const float *w_split;           // w in the split-bf16 format below (same offsets, opaque 4-byte units), or null
+    int precision;                  // 0: exact fp32 MFMA on x / w;  1: bf16x3 on SPLIT x / w_split
     const float *zeros;             // >= 16 bytes of zeros (source of out-of-image taps on the DMA path), may be null
     float *y; int ldy;              // raw (pre-norm) output NHWC
     int Ho, Wo, Cout;
@@ -36,7 +56,9 @@ struct ConvArgs {
 };
 
 // bn = 64 or 128 output channels per workgroup tile.  *variant (optional) receives which kernel instantiation ran:
-enum { kIgemmReg64 = 0, kIgemmReg128 = 1, kIgemmSmallCin = 2, kIgemmDma64 = 3, kIgemmDma128 = 4, kIgemmVariants = 5 };
+enum { kIgemmReg64 = 0, kIgemmReg128 = 1, kIgemmSmallCin = 2, kIgemmDma64 = 3, kIgemmDma128 = 4, kIgemmBf16x3_64 = 5,
+       kIgemmBf16x3_128 = 6, kIgemmVariants = 7 };
+inline bool igemm_variant_is_bf16x3(int v) { return v == kIgemmBf16x3_64 || v == kIgemmBf16x3_128; }
 extern const char *const kIgemmVariantNames[kIgemmVariants];
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant = nullptr);
 
@@ -51,6 +73,7 @@ struct ApplyArgs {
     int relu;
     float *dst; int ld_dst;         // destination NHWC slice (channel offset already applied)
     const float *res; int ld_res;   // optional residual added after the norm (ResidualBlock)
+    int split;                      // 1: dst is written, and res read, in the split-bf16 format (C, offsets % 32 == 0)
     int nwarp;                      // 0..2 Liquid-Warping-Block terms added after the activation
     const float *warp_src[2];       // source features NHWC (warp_n, H, W, C)
     int warp_n[2];                  // 1 (shared source) or N
@@ -58,6 +81,9 @@ struct ApplyArgs {
     int align_corners;
 };
 int launch_apply(const ApplyArgs &a, hipStream_t st);
+
+// in-place split-bf16 -> fp32 of n floats (n % 32 == 0): the test hook's view of a split activation buffer
+int launch_unsplit(float *buf, size_t n, hipStream_t st);
 
 // 7x7 regression heads on the 64-channel decoder output: color = tanh(conv), mask = sigmoid(conv),
 // pred = mask*bg + (1-mask)*color (models/imitator.py:331). x is the RAW skipper output with its

@@ -30,6 +30,7 @@ namespace lwg {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#pragma clang diagnostic ignored "-Winline-asm"   // "m0 is reserved": the DMA asm below sets m0 itself before each use
 
 constexpr int BM = kConvBM;
 constexpr int BK = kConvBK;
@@ -309,8 +310,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 //   * zero padding: a tap outside the image makes the lane read from a 16-byte zero buffer instead;
 //   * synchronisation is a raw s_barrier plus counted vmcnt: at the end of iteration t every wave waits until only
 //     its DMAs of stage t+2 are outstanding (=> stage t+1 has landed), then the barrier publishes it.
-template <int BN, int WM, int WN, int DBG = 0, int NS = 3>
-__global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
+//
+// SPLIT = true is the bf16x3 form of the same kernel (conv.h, "split-bf16 format"): activations and weights arrive as
+// [hi x32 | lo x32] bf16 groups occupying the very 128-byte rows the fp32 kernel moves, so addressing, swizzle, ring
+// and synchronisation are shared and only the fragment reads / MFMAs differ: 16-B column 2*kb + (lane>>5) of a row is
+// the hi operand of k-block kb (8 bf16 per lane = one v_mfma_f32_32x32x16_bf16 operand), column 4 + 2*kb + (lane>>5)
+// the lo operand; a stage is 2 k-blocks x 3 products per 32x32 tile.  The matrix pipe works 5.3x faster per tile than
+// in fp32, so the DMA pieces are spread one behind every 2-3 MFMAs.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+template <int BN, int WM, int WN, int DBG, int NS, bool SPLIT, int BARQ = 3>
+__device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
 {
     constexpr int WAVES_N = BN / (32 * WN);
     constexpr int WAVES_M = BM / (32 * WM);
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
 #pragma unroll
     for (int j = 0; j < B_ROWS; ++j) {
         const int row = (wave * B_ROWS + j) * 8 + lr;
-        wsrc[j] = a.w + ph.w_off + (size_t)(n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4;
+        wsrc[j] = (SPLIT ? a.w_split : a.w) + ph.w_off + (size_t)(n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4;
     }
 
     // The DMA is issued from inline asm on purpose: hipcc treats a compiler-visible global_load_lds as a pending LDS
@@ -375,30 +386,85 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
     // m0 carries the wave-uniform LDS byte address of the 1 KiB chunk; it is saved/restored around the instruction.
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     auto dma16 = [&](const float *gsrc, unsigned lds_byte) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %2\n\t"
+        asm volatile("s_mov_b32 m0, %1\n\t"
                      "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
+                     "global_load_lds_dwordx4 %0, off"
+                     :
                      : "v"(gsrc), "s"(lds_byte)
-                     : "memory");
+                     : "memory", "m0");
     };
+    // wave-uniform LDS byte offsets of this wave's first A / weight chunk inside a stage
+    const unsigned wave_a = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * 4 * 8 * BK * 4));
+    const unsigned wave_b = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((BM * BK + wave * B_ROWS * 8 * BK) * 4));
     int s_tap = 0, s_kh = 0, s_kw = 0, s_ci0 = 0;   // scalar walk over (tap, channel slice)
     // One DMA instruction occupies the wave's issue port for ~60 cycles; a stage needs LPS of them.  They are issued
     // ONE AT A TIME, each behind a chain of four MFMAs (256 cycles of matrix-pipe work already queued), never
     // back to back: piece p < 4 moves A chunk p, piece p >= 4 moves weight chunk p-4 of stage `kt` into ring slot `slot`.
+    // SPLIT addressing (bf16x3: the matrix pipe leaves ~5 issue slots per MFMA, address VALU has to go): every DMA is
+    // "wave-uniform 64-bit base + per-lane unsigned 32-bit byte offset" (saddr form).  The base walks the channel slice
+    // (and the weight row) by 128 B per stage in SGPRs; the lane offsets cur[] only change when the tap changes (once
+    // per Cin/32 stages), and a lane whose tap falls outside the image points at a run of zeros that the caller placed
+    // behind the tensor (a.zeros: >= Cin*4 bytes, above a.x, within 4 GiB), so the channel walk needs no select.
+    unsigned cur[4] = {0, 0, 0, 0}, wvoff[B_ROWS];
+    const unsigned zoff_b = (unsigned)((const char *)a.zeros - (const char *)xin);
+    unsigned s_ci_b = 0;
+    // both bases are wave-uniform; readfirstlane pins them to SGPRs for the "s" asm operand
+    auto uniform_ptr = [](const void *p) {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+    };
+    const char *w_base = uniform_ptr((SPLIT ? a.w_split : a.w) + ph.w_off);
+    const char *x_base = uniform_ptr(xin);
+    auto retap = [&]() {
+        const int tapoff = (s_kh * a.W + s_kw) * a.dil * a.ldx;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) cur[p] = ((amask[p] >> s_tap) & 1u) ? (unsigned)((aoff[p] + tapoff) * 4) : zoff_b;
+    };
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < B_ROWS; ++j) {
+            const int row = (wave * B_ROWS + j) * 8 + lr;
+            wvoff[j] = (unsigned)(((n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4) * 4);
+        }
+        retap();
+    }
+    auto dma16s = [&](unsigned voff, const char *sbase, unsigned lds_byte) {
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(voff), "s"(sbase), "s"(lds_byte)
+                     : "memory", "m0");
+    };
     auto dma_piece = [&](int p, int kt, int slot) {
+        const unsigned slot_byte = (unsigned)(slot * STAGE * 4);
+        if constexpr (SPLIT) {
+            if (p < 4) {
+                dma16s(cur[p], x_base + s_ci_b, wave_a + slot_byte + (unsigned)(p * 8 * BK * 4));
+            } else {
+                dma16s(wvoff[p - 4], w_base + (size_t)kt * (BK * 4), wave_b + slot_byte + (unsigned)((p - 4) * 8 * BK * 4));
+            }
+            if (p == LPS - 1) {
+                s_ci_b += BK * 4;
+                if (s_ci_b == (unsigned)a.Cin * 4) {
+                    asm volatile("; next tap" ::: "memory");   // keeps this rare path a real (wave-uniform) branch
+                    s_ci_b = 0;
+                    ++s_tap;
+                    if (++s_kw == ph.KW) { s_kw = 0; ++s_kh; }
+                    retap();
+                }
+            }
+            return;
+        }
         if (p < 4) {
-            const unsigned sa = __builtin_amdgcn_readfirstlane(
-                lds_base + (unsigned)((slot * STAGE + (wave * 4 + p) * 8 * BK) * 4));
+            const unsigned sa = wave_a + slot_byte + (unsigned)(p * 8 * BK * 4);
             const int toff = (s_kh * a.W + s_kw) * a.dil * a.ldx + s_ci0;
             const float *src = ((amask[p] >> s_tap) & 1u) ? xin + (aoff[p] + toff) : a.zeros;
             dma16(src, sa);
         } else {
-            const unsigned sb = __builtin_amdgcn_readfirstlane(
-                lds_base + (unsigned)((slot * STAGE + BM * BK + (wave * B_ROWS + (p - 4)) * 8 * BK) * 4));
+            const unsigned sb = wave_b + slot_byte + (unsigned)((p - 4) * 8 * BK * 4);
             dma16(wsrc[p - 4] + kt * BK, sb);
         }
         if (p == LPS - 1) {
@@ -428,12 +494,88 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
 #pragma unroll
     for (int k8 = 0; k8 < BK / 8; ++k8) fcol[k8] = (((2 * k8 + (lane >> 5)) ^ fsw) * 4);
 
+    // SPLIT: fragments of k-block kb of ring slot `slot` (hi: 16-B column 2*kb + (lane>>5), lo: 4 + that)
+    auto load_frags = [&](int slot, int kb, float4 (&xh)[WM], float4 (&xl)[WM], float4 (&yh)[WN], float4 (&yl)[WN]) {
+        const float *As = smem + slot * STAGE + a_row;
+        const float *Bs = smem + slot * STAGE + b_row;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            xh[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + fcol[kb]);
+            xl[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + fcol[2 + kb]);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            yh[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + fcol[kb]);
+            yl[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + fcol[2 + kb]);
+        }
+    };
+    float4 fr_ah[WM], fr_al[WM], fr_bh[WN], fr_bl[WN];   // SPLIT: k-block-0 fragments of the stage about to run
+#pragma unroll
+    for (int i = 0; i < WM; ++i) fr_ah[i] = fr_al[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) fr_bh[j] = fr_bl[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
     // iteration kt: MFMAs of stage kt from ring slot `slot`, DMA pieces of stage kt+2 (if any) in their shadow
-    auto stage_body = [&](int kt, int slot, auto do_dma) {
+    // `slot_c` is an int (fp32 kernel) or a std::integral_constant (SPLIT: every LDS address becomes an immediate)
+    auto stage_body = [&](int kt, auto slot_c, auto do_dma) {
+        const int slot = slot_c;
         const float *As = smem + slot * STAGE + a_row;
         const float *Bs = smem + slot * STAGE + b_row;
         int slot2 = slot + (NS - 1);
         if (slot2 >= NS) slot2 -= NS;
+        if constexpr (SPLIT) {
+            // One stage = Q MFMAs: k-block 0 (fragments fr0, fetched during the PREVIOUS stage) then k-block 1 (fr1,
+            // fetched at the top of this one).  The stage barrier sits in the middle of the MFMA stream, before MFMA QB,
+            // not at the end: behind it the k-block-0 fragments of the NEXT stage are fetched while the remaining
+            // MFMAs run, so no LDS latency is exposed at the stage boundary (with 32-cycle MFMAs that latency was
+            // ~40% of the stage).  By MFMA QB every wave has issued and consumed all reads of this slot (lgkmcnt(0)),
+            // so the pieces issued after the barrier may overwrite the slot consumed one stage earlier.
+            constexpr int Q = 6 * WM * WN, TILES = WM * WN;
+            static_assert(Q % LPS == 0, "DMA pieces must spread evenly over the MFMAs of a stage");
+            constexpr int QP = Q / LPS;
+            static_assert(NS >= 3 && BARQ >= 1 && BARQ <= 3, "ring depth / barrier position");
+            constexpr int QB = Q * BARQ / 4;            // barrier before this MFMA
+            constexpr int ISSUED = QB / QP;             // pieces of this stage already issued at the barrier
+            float4 f1ah[WM], f1al[WM], f1bh[WN], f1bl[WN];
+            float4 nxah[WM], nxal[WM], nxbh[WN], nxbl[WN];
+            if (!(DBG & 8)) load_frags(slot, 1, f1ah, f1al, f1bh, f1bl);
+            int slot1 = slot + 1;
+            if (slot1 == NS) slot1 = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int kb = q / (Q / 2), r = q % (Q / 2);
+                const int t = r / TILES, i = (r / WN) % WM, j = r % WN;   // cross terms first, hi*hi last
+                if (q == QB) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // stage kt+1 must have landed for every wave: only younger pieces may still be in flight
+                    if (decltype(do_dma)::value) {
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 3) * LPS + ISSUED) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    }
+                    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (!(DBG & 8)) load_frags(slot1, 0, nxah, nxal, nxbh, nxbl);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float4 a4 = kb == 0 ? (t == 0 ? fr_al[i] : fr_ah[i]) : (t == 0 ? f1al[i] : f1ah[i]);
+                const float4 b4 = kb == 0 ? (t == 1 ? fr_bl[j] : fr_bh[j]) : (t == 1 ? f1bl[j] : f1bh[j]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a4),
+                                                                    __builtin_bit_cast(bf16x8_t, b4), acc[i][j], 0, 0, 0);
+                if (decltype(do_dma)::value && q % QP == QP - 1 && !(DBG & 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_piece(q / QP, kt + (NS - 1), slot2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!(DBG & 8)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) { fr_ah[i] = nxah[i]; fr_al[i] = nxal[i]; }
+#pragma unroll
+                for (int j = 0; j < WN; ++j) { fr_bh[j] = nxbh[j]; fr_bl[j] = nxbl[j]; }
+            }
+            return;
+        } else {
         float4 af[WM], bf[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + fcol[0]);
@@ -470,6 +612,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
                 for (int j = 0; j < WN; ++j) bf[j] = bn4[j];
             }
         }
+        }
         // stage kt+1 must have landed (for every wave) before anyone reads it: only this iteration's own pieces
         // (stage kt+2) may still be in flight
         if (decltype(do_dma)::value) {
@@ -482,7 +625,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
-    static_assert(LPS <= (BK / 8) * WM * WN, "not enough MFMA chains to hide the DMA pieces of a stage");
+    static_assert(SPLIT || LPS <= (BK / 8) * WM * WN, "not enough MFMA chains to hide the DMA pieces of a stage");
 
     const int nk = ph.Kpad / BK;
     // prologue: NS-1 stages in flight, the first one must have landed
@@ -499,19 +642,57 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (SPLIT) load_frags(0, 0, fr_ah, fr_al, fr_bh, fr_bl);
 
     int slot = 0, kt = 0;
-    for (; kt + (NS - 1) < nk; ++kt) {
-        stage_body(kt, slot, yes{});
-        if (++slot == NS) slot = 0;
-    }
-    for (; kt < nk; ++kt) {
-        stage_body(kt, slot, no{});
-        if (++slot == NS) slot = 0;
+    if constexpr (SPLIT) {
+        // whole turns of the ring with compile-time slots, then the remaining stages through a slot dispatch
+        static_assert(NS == 3 || NS == 4, "ring depth");
+        for (; kt + 2 * (NS - 1) < nk; kt += NS) {
+            stage_body(kt, std::integral_constant<int, 0>{}, yes{});
+            stage_body(kt + 1, std::integral_constant<int, 1>{}, yes{});
+            stage_body(kt + 2, std::integral_constant<int, 2>{}, yes{});
+            if constexpr (NS == 4) stage_body(kt + 3, std::integral_constant<int, 3>{}, yes{});
+        }
+        auto run_stage = [&](int k, int sl, auto do_dma) {
+            if (sl == 0) stage_body(k, std::integral_constant<int, 0>{}, do_dma);
+            else if (sl == 1) stage_body(k, std::integral_constant<int, 1>{}, do_dma);
+            else if (NS == 3 || sl == 2) stage_body(k, std::integral_constant<int, 2>{}, do_dma);
+            else stage_body(k, std::integral_constant<int, NS - 1>{}, do_dma);
+        };
+        for (; kt + (NS - 1) < nk; ++kt) {
+            run_stage(kt, slot, yes{});
+            if (++slot == NS) slot = 0;
+        }
+        for (; kt < nk; ++kt) {
+            run_stage(kt, slot, no{});
+            if (++slot == NS) slot = 0;
+        }
+    } else {
+        for (; kt + (NS - 1) < nk; ++kt) {
+            stage_body(kt, slot, yes{});
+            if (++slot == NS) slot = 0;
+        }
+        for (; kt < nk; ++kt) {
+            stage_body(kt, slot, no{});
+            if (++slot == NS) slot = 0;
+        }
     }
     igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
     __syncthreads();   // the statistics scratch aliases the ring: finish reading it before the next phase's DMA
     }  // phase loop
+}
+
+template <int BN, int WM, int WN, int DBG = 0, int NS = 3>
+__global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
+{
+    igemm_dma_body<BN, WM, WN, DBG, NS, false>(a);
+}
+
+template <int BN, int WM, int WN, int DBG = 0, int NS = 3, int BARQ = 3>
+__global__ __launch_bounds__(256) void conv_igemm_dma_bf16x3(const ConvArgs a)
+{
+    igemm_dma_body<BN, WM, WN, DBG, NS, true, BARQ>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,8 +775,18 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a)
     if (a.relu) {
         y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
     }
+    // split-bf16 format: channels c..c+3 of a 32-channel group are 8 bytes of hi at 2*(c&31) and 8 of lo 64 B further
+    const int soff = (c >> 5) * 32 + ((c & 31) >> 1);   // float (4-byte) units
     if (a.res) {
-        const float4 r = ld4(a.res + pix * a.ld_res + c);
+        float4 r;
+        if (a.split) {
+            const bf16x4_t h = *reinterpret_cast<const bf16x4_t *>(a.res + pix * a.ld_res + soff);
+            const bf16x4_t l = *reinterpret_cast<const bf16x4_t *>(a.res + pix * a.ld_res + soff + 16);
+            r = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                            (float)h[3] + (float)l[3]);
+        } else {
+            r = ld4(a.res + pix * a.ld_res + c);
+        }
         y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
     }
     for (int k = 0; k < a.nwarp; ++k) {
@@ -610,7 +801,37 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a)
         y.x += wsum.x; y.y += wsum.y; y.z += wsum.z; y.w += wsum.w;
     }
     (void)pn;
-    *reinterpret_cast<float4 *>(a.dst + pix * a.ld_dst + c) = y;
+    if (a.split) {
+        bf16x4_t h, l;
+        h[0] = (__bf16)y.x; h[1] = (__bf16)y.y; h[2] = (__bf16)y.z; h[3] = (__bf16)y.w;
+        l[0] = (__bf16)(y.x - (float)h[0]); l[1] = (__bf16)(y.y - (float)h[1]);
+        l[2] = (__bf16)(y.z - (float)h[2]); l[3] = (__bf16)(y.w - (float)h[3]);
+        *reinterpret_cast<bf16x4_t *>(a.dst + pix * a.ld_dst + soff) = h;
+        *reinterpret_cast<bf16x4_t *>(a.dst + pix * a.ld_dst + soff + 16) = l;
+    } else {
+        *reinterpret_cast<float4 *>(a.dst + pix * a.ld_dst + c) = y;
+    }
+}
+
+// one thread per 32-value group, in place: [hi x32 | lo x32] bf16 -> 32 floats
+__global__ __launch_bounds__(256) void unsplit_kernel(float *buf, size_t ngroups)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    float4 raw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) raw[i] = ld4(buf + g * 32 + i * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // raw[i] = hi of values 8i..8i+7, raw[4+i] = lo
+        const bf16x8_t h = __builtin_bit_cast(bf16x8_t, raw[i]);
+        const bf16x8_t l = __builtin_bit_cast(bf16x8_t, raw[4 + i]);
+        float4 o0 = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                                (float)h[3] + (float)l[3]);
+        float4 o1 = make_float4((float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6],
+                                (float)h[7] + (float)l[7]);
+        *reinterpret_cast<float4 *>(buf + g * 32 + i * 8) = o0;
+        *reinterpret_cast<float4 *>(buf + g * 32 + i * 8 + 4) = o1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,7 +907,8 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 
 const char *const kIgemmVariantNames[kIgemmVariants] = {
     "conv_igemm_f32<64, 1, 2, false, 0>", "conv_igemm_f32<128, 2, 2, false, 0>", "conv_igemm_f32<64, 1, 2, true, 0>",
-    "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>"};
+    "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>",
+    "conv_igemm_dma_bf16x3<64, 1, 2, 0, 3>", "conv_igemm_dma_bf16x3<128, 2, 2, 0, 3>"};
 
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
 {
@@ -715,6 +937,41 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         lds_opt_in = true;
     }
     const bool small_cin = a.Cin < BK;
+    if (a.precision == 1) {
+        // bf16x3 on split operands: DMA-fed ring of (BM + bn) 128-byte rows per stage
+        if (small_cin || !a.w_split || !a.zeros || (a.ldx & 31) || (a.Cin & 31))
+            LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: the bf16x3 path needs split weights and Cin, pixel stride multiples of 32");
+        // lane offsets are unsigned 32-bit bytes from the image base: the zero run must sit above the whole input
+        // tensor and within reach of its first image (see igemm_dma_body)
+        {
+            const char *x_end = reinterpret_cast<const char *>(a.x + (size_t)a.N * a.H * a.W * a.ldx);
+            const char *z = reinterpret_cast<const char *>(a.zeros);
+            if (z < x_end || (size_t)(z - reinterpret_cast<const char *>(a.x)) + (size_t)a.Cin * 4 > 0xffffffffull)
+                LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: the bf16x3 path needs its zero run behind the input tensor, within 4 GiB");
+            for (int p = 0; p < a.nphase; ++p)
+                if ((size_t)a.Cout * a.ph[p].Kpad * 4 > 0xffffffffull)
+                    LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: weight matrix too large for 32-bit lane offsets");
+        }
+        const size_t lds3 = (size_t)3 * (BM + bn) * BK * sizeof(float);
+        static bool opt16 = false;
+        if (!opt16) {
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_bf16x3<64, 1, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 64) * BK * (int)sizeof(float)));
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_bf16x3<128, 2, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 128) * BK * (int)sizeof(float)));
+            opt16 = true;
+        }
+        for (int p = 0; p < a.nphase; ++p)
+            if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the bf16x3 path");
+        if (bn == 64) {
+            conv_igemm_dma_bf16x3<64, 1, 2><<<grid, 256, lds3, st>>>(a);
+        } else {
+            conv_igemm_dma_bf16x3<128, 2, 2><<<grid, 256, lds3, st>>>(a);
+        }
+        if (variant) *variant = bn == 64 ? kIgemmBf16x3_64 : kIgemmBf16x3_128;
+        LWG_LAUNCH_CHECK("conv_igemm_dma_bf16x3");
+        return LWG_OK;
+    }
     if (small_cin && bn != 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d < %d is only built for the 64-channel tile", a.Cin, BK);
     // Kernel choice (tools/igemm_bench.hip, warm clocks, TFLOP/s): the 64-channel tile runs best DMA-fed (118-122 vs
     // 115-120); the 128-channel tile runs best DMA-fed when the grid is a single round of one workgroup per CU
@@ -803,9 +1060,32 @@ static void launch_dma_dbg(const ConvArgs &a, int bn, hipStream_t st)
         conv_igemm_dma_f32<128, 2, 2, DBG><<<grid, 256, lds, st>>>(a);
     }
 }
+template <int DBG, int NS, int BARQ = 3>
+static void launch_split_dbg(const ConvArgs &a, int bn, hipStream_t st)
+{
+    const dim3 grid(a.mtiles, a.Cout / bn, a.nphase);
+    const size_t lds = (size_t)NS * (BM + bn) * BK * sizeof(float);
+    if (bn == 64) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_bf16x3<64, 1, 2, DBG, NS, BARQ>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv_igemm_dma_bf16x3<64, 1, 2, DBG, NS, BARQ><<<grid, 256, lds, st>>>(a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_bf16x3<128, 2, 2, DBG, NS, BARQ>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv_igemm_dma_bf16x3<128, 2, 2, DBG, NS, BARQ><<<grid, 256, lds, st>>>(a);
+    }
+}
 int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
 {
     switch (dbg) {
+        case 200: launch_split_dbg<0, 3>(a, bn, st); break;
+        case 201: launch_split_dbg<1, 3>(a, bn, st); break;
+        case 204: launch_split_dbg<4, 3>(a, bn, st); break;
+        case 208: launch_split_dbg<8, 3>(a, bn, st); break;
+        case 213: launch_split_dbg<13, 3>(a, bn, st); break;
+        case 240: launch_split_dbg<0, 4>(a, bn, st); break;
+        case 230: launch_split_dbg<0, 3, 2>(a, bn, st); break;
+        case 241: launch_split_dbg<0, 4, 2>(a, bn, st); break;
         case 0: launch_dbg<0>(a, bn, st); break;
         case 1: launch_dbg<1>(a, bn, st); break;
         case 3: launch_dbg<3>(a, bn, st); break;
@@ -851,9 +1131,21 @@ int launch_apply(const ApplyArgs &a, hipStream_t st)
 {
     if ((a.C & 3) || (a.ld_dst & 3) || (a.res && (a.ld_res & 3)))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "apply: channel counts/strides must be multiples of 4 (C=%d)", a.C);
+    if (a.split && ((a.C & 31) || (a.ld_dst & 31) || ((uintptr_t)a.dst & 127) ||
+                    (a.res && ((a.ld_res & 31) || ((uintptr_t)a.res & 127)))))
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "apply: split-bf16 buffers need 32-channel granularity (C=%d)", a.C);
     const long total = (long)a.N * a.H * a.W * (a.C >> 2);
     apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(a);
     LWG_LAUNCH_CHECK("apply_kernel");
+    return LWG_OK;
+}
+
+int launch_unsplit(float *buf, size_t n, hipStream_t st)
+{
+    if (n % 32) LWG_FAIL(LWG_ERR_INVALID_ARG, "unsplit: %zu floats is not a whole number of 32-value groups", n);
+    if (!n) return LWG_OK;
+    unsplit_kernel<<<(unsigned)ceil_div((long)(n / 32), 256), 256, 0, st>>>(buf, n / 32);
+    LWG_LAUNCH_CHECK("unsplit_kernel");
     return LWG_OK;
 }
 

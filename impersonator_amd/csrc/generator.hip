@@ -31,6 +31,7 @@ struct Layer {
     bool transposed = false, has_norm = true;
     // device weights: conv [cout][kpad]; transposed: four phase matrices back to back
     float *w = nullptr;
+    float *w_split = nullptr;         // the same matrices in the split-bf16 format (conv.h), Cin >= 32 layers only
     ConvPhase ph[4];
     int nphase = 1;
     float *gamma = nullptr, *beta = nullptr;
@@ -66,7 +67,11 @@ struct lwg_generator {
     float2 *partials = nullptr;
     float2 *ss = nullptr;             // scale/shift [max_batch][8cd]
     float *zeros = nullptr;           // 256 B of zeros: source of out-of-image taps for the DMA-fed conv kernel
+    size_t cat_floats[kNDown] = {}, trunk_floats = 0, sk_floats[kNDown] = {};   // payload sizes (zero tails follow)
     int trunk_out = 0;                // which trunk buffer holds the residual trunk's output
+    int precision = 1;                // tsf-stream conv arithmetic: 0 exact fp32 MFMA, 1 bf16x3 split (default)
+    bool split = false;               // activation format of the pass being enqueued (split-bf16 when true)
+    bool last_split = false;          // ... of the last tsf pass (what peek finds in the buffers)
 
     // profiling of the implicit-GEMM kernel
     bool profile = false;
@@ -83,6 +88,16 @@ namespace {
 int dev_alloc(float **p, size_t floats)
 {
     LWG_HIP(hipMalloc(reinterpret_cast<void **>(p), floats * sizeof(float)));
+    return LWG_OK;
+}
+
+// Activation buffer that feeds a conv: kZeroTail floats of zeros sit right behind it.  The bf16x3 kernel addresses
+// out-of-image taps with 32-bit lane offsets from the image base and needs a zero run of >= Cin*4 bytes it can reach.
+constexpr size_t kZeroTail = 1024;
+int act_alloc(float **p, size_t floats)
+{
+    LWG_HIP(hipMalloc(reinterpret_cast<void **>(p), (floats + kZeroTail) * sizeof(float)));
+    LWG_HIP(hipMemset(*p + floats, 0, kZeroTail * sizeof(float)));
     return LWG_OK;
 }
 
@@ -137,6 +152,10 @@ int alloc_layer(Layer &L)
     int rc = dev_alloc(&L.w, L.w_floats);
     if (rc != LWG_OK) return rc;
     LWG_HIP(hipMemset(L.w, 0, L.w_floats * sizeof(float)));
+    if (L.cin_pad >= kConvBK) {
+        LWG_HIP(hipMalloc(reinterpret_cast<void **>(&L.w_split), L.w_floats * sizeof(float)));
+        LWG_HIP(hipMemset(L.w_split, 0, L.w_floats * sizeof(float)));
+    }
     if (L.has_norm) {
         if ((rc = dev_alloc(&L.gamma, L.cout)) != LWG_OK) return rc;
         if ((rc = dev_alloc(&L.beta, L.cout)) != LWG_OK) return rc;
@@ -147,6 +166,8 @@ int alloc_layer(Layer &L)
 void free_layer(Layer &L)
 {
     if (L.w) (void)hipFree(L.w);
+    if (L.w_split) (void)hipFree(L.w_split);
+    L.w_split = nullptr;
     if (L.gamma) (void)hipFree(L.gamma);
     if (L.beta) (void)hipFree(L.beta);
     L.w = L.gamma = L.beta = nullptr;
@@ -189,6 +210,20 @@ void free_stream(StreamNet &s)
     s.heads_w = nullptr;
 }
 
+// device copy of a re-laid-out weight matrix, plus the same matrix in the split-bf16 format (every Kpad is a
+// multiple of 32, so the 32-value groups never straddle a row)
+int upload_matrix(Layer &L, const std::vector<float> &h)
+{
+    LWG_HIP(hipMemcpy(L.w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (L.w_split) {
+        std::vector<float> sp(h.size());
+        split_bf16_groups(h.data(), h.size(), sp.data());
+        LWG_HIP(hipMemcpy(L.w_split, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    L.got_w = true;
+    return LWG_OK;
+}
+
 // PyTorch Conv2d weight (cout, cin, k, k) -> [cout][(kh*k+kw)*cin_pad + ci], zero padded to Kpad
 int upload_conv(Layer &L, const float *w, const int64_t *shape, int ndim, const char *key)
 {
@@ -200,9 +235,7 @@ int upload_conv(Layer &L, const float *w, const int64_t *shape, int ndim, const 
         for (int ci = 0; ci < L.cin; ++ci)
             for (int t = 0; t < L.k * L.k; ++t)
                 h[(size_t)co * p.Kpad + (size_t)t * L.cin_pad + ci] = w[((size_t)co * L.cin + ci) * L.k * L.k + t];
-    LWG_HIP(hipMemcpy(L.w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-    L.got_w = true;
-    return LWG_OK;
+    return upload_matrix(L, h);
 }
 
 // PyTorch ConvTranspose2d weight (cin, cout, 3, 3); out(oy) = sum in(iy) w[ky] with oy = 2*iy - 1 + ky.
@@ -226,9 +259,7 @@ int upload_convT(Layer &L, const float *w, const int64_t *shape, int ndim, const
                                 w[(((size_t)ci * L.cout + co) * 3 + ky) * 3 + kx];
                 }
         }
-    LWG_HIP(hipMemcpy(L.w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-    L.got_w = true;
-    return LWG_OK;
+    return upload_matrix(L, h);
 }
 
 int upload_vec(float *dst, int n, bool *flag, const float *src, const int64_t *shape, int ndim, const char *key)
@@ -283,6 +314,18 @@ int prof_begin(lwg_generator *g, hipStream_t st, hipEvent_t *e1)
     return LWG_OK;
 }
 
+// the zero run behind the handle-owned activation buffer `x` points into (null for anything else)
+const float *zero_tail_of(const lwg_generator *g, const float *x)
+{
+    for (int l = 0; l < kNDown; ++l) {
+        if (g->cat[l] && x >= g->cat[l] && x < g->cat[l] + g->cat_floats[l]) return g->cat[l] + g->cat_floats[l];
+        if (g->sk[l] && x >= g->sk[l] && x < g->sk[l] + g->sk_floats[l]) return g->sk[l] + g->sk_floats[l];
+    }
+    for (int i = 0; i < 3; ++i)
+        if (g->trunk[i] && x >= g->trunk[i] && x < g->trunk[i] + g->trunk_floats) return g->trunk[i] + g->trunk_floats;
+    return nullptr;
+}
+
 // one normalised conv layer: conv -> statistics -> (caller applies)
 int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, int H, int W, float *raw,
              hipStream_t st)
@@ -296,7 +339,13 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     a.Cin = L.cin_pad;
     a.cin_log2 = ilog2(L.cin_pad);
     a.w = L.w;
+    a.w_split = L.w_split;
+    a.precision = (g->split && L.w_split) ? 1 : 0;   // the 7x7 stem (Cin 6, fp32 NHWC8 input) stays on the fp32 kernel
     a.zeros = g->zeros;
+    if (a.precision == 1) {
+        a.zeros = zero_tail_of(g, x);
+        if (!a.zeros) LWG_FAIL(LWG_ERR_STATE, "bf16x3 conv input is not one of the handle's activation buffers");
+    }
     a.y = raw;
     a.ldy = L.cout;
     a.Cout = L.cout;
@@ -372,6 +421,7 @@ int run_apply(lwg_generator *g, int N, int H, int W, int C, bool relu, float *ds
         a.warp_T[k] = warps[k].T;
     }
     a.align_corners = align;
+    a.split = g->split ? 1 : 0;
     return launch_apply(a, st);
 }
 
@@ -428,6 +478,7 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
     const StreamNet &s = g->tsf;
     const int is = g->is, cd = g->cd;
     int rc;
+    g->split = g->last_split = g->precision == 1;   // every activation buffer of this pass is in that format
     for (int k = 0; k < nsets; ++k)
         for (int l = 1; l <= kNDown; ++l)
             if ((rc = lwg_resize_flow(T[k], bs, is, is, is >> l, is >> l, g->tscale[k][l - 1], st)) != LWG_OK) return rc;
@@ -529,11 +580,11 @@ int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, int conv
     const int cd = conv_dim;
     if (rc == LWG_OK) rc = dev_alloc(&g->x0, B * P * 8);
     if (rc == LWG_OK) rc = dev_alloc(&g->raw, B * P * cd);
-    for (int l = 0; l < kNDown && rc == LWG_OK; ++l) rc = dev_alloc(&g->cat[l], B * (P >> (2 * l)) * (size_t)(2 * (cd << l)));
-    for (int i = 0; i < 3 && rc == LWG_OK; ++i) rc = dev_alloc(&g->trunk[i], B * (P >> (2 * kNDown)) * (size_t)(cd << kNDown));
+    for (int l = 0; l < kNDown && rc == LWG_OK; ++l) rc = act_alloc(&g->cat[l], g->cat_floats[l] = B * (P >> (2 * l)) * (size_t)(2 * (cd << l)));
+    for (int i = 0; i < 3 && rc == LWG_OK; ++i) rc = act_alloc(&g->trunk[i], g->trunk_floats = B * (P >> (2 * kNDown)) * (size_t)(cd << kNDown));
     for (int i = 0; i + 1 < kNDown && rc == LWG_OK; ++i) {
         const int lvl = kNDown - 1 - i;
-        rc = dev_alloc(&g->sk[i], B * (P >> (2 * lvl)) * (size_t)(cd << lvl));
+        rc = act_alloc(&g->sk[i], g->sk_floats[i] = B * (P >> (2 * lvl)) * (size_t)(cd << lvl));
     }
     for (int k = 0; k < 2; ++k)
         for (int l = 1; l <= kNDown && rc == LWG_OK; ++l) rc = dev_alloc(&g->tscale[k][l - 1], B * (P >> (2 * l)) * 2);
@@ -663,6 +714,8 @@ int lwg_generator_encode_src(lwg_generator *g, const float *src_inputs_nchw, flo
     LWG_REQUIRE(src_inputs_nchw && feats_nhwc, "encode_src: NULL argument");
     for (int i = 0; i < kNDown + 1 + g->repeat; ++i) LWG_REQUIRE(feats_nhwc[i], "encode_src: feats_nhwc[%d] is NULL", i);
     hipStream_t st = as_stream(stream);
+    // once per source, and its outputs are fp32 tensors handed to the caller (the LWB gathers read them): always fp32
+    g->split = false;
     const float *x0 = nullptr;
     if ((rc = pack_input(g, src_inputs_nchw, 0, 1, g->src_dim, st, &x0)) != LWG_OK) return rc;
     const float *x = x0;
@@ -715,6 +768,7 @@ int lwg_generator_peek(lwg_generator *g, int which, float *dst, size_t n_floats,
     const int cd = g->cd;
     const float *src = nullptr;
     size_t cap = 0;
+    const bool act = which >= 0 && which <= 5;   // activation buffers: in the split-bf16 format after a bf16x3 pass
     if (which >= 0 && which < kNDown) {
         src = g->cat[which];
         cap = B * (P >> (2 * which)) * (size_t)(2 * (cd << which));
@@ -737,6 +791,15 @@ int lwg_generator_peek(lwg_generator *g, int which, float *dst, size_t n_floats,
     }
     const size_t n = n_floats < cap ? n_floats : cap;
     LWG_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    if (act && g->last_split) return launch_unsplit(dst, n - n % 32, as_stream(stream));
+    return LWG_OK;
+}
+
+int lwg_generator_set_precision(lwg_generator *g, int mode)
+{
+    LWG_REQUIRE(g, "set_precision: NULL handle");
+    LWG_REQUIRE(mode == 0 || mode == 1, "set_precision: mode must be 0 (fp32) or 1 (bf16x3), got %d", mode);
+    g->precision = mode;
     return LWG_OK;
 }
 

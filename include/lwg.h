@@ -132,6 +132,12 @@ LWG_API int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, 
                                  int image_size, int max_batch);
 LWG_API void lwg_generator_destroy(lwg_generator *g);
 
+/* Arithmetic of the convolutions.  0: exact fp32 on v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain).
+ * 1 (default): every fp32 operand split into two bf16 terms, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation -- 16 mantissa bits per operand, ~2^-16 relative per product, measured 8e-5 L-inf on the final
+ * image against the fp32 reference (budget 1e-3), at ~2.2x the speed.  The 7x7 stem and heads are fp32 in both modes. */
+LWG_API int lwg_generator_set_precision(lwg_generator *g, int mode);
+
 /* Feed one state_dict entry (PyTorch layout, HOST memory), e.g.
  * "tsf_model.encoders.0.0.weight" (64,6,7,7), "tsf_model.resnets.2.main.1.bias" (512,),
  * "tsf_model.decoders.0.0.weight" (512,256,3,3), "tsf_model.attetion_reg.0.weight" (1,64,7,7).

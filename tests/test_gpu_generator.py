@@ -12,21 +12,35 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 TOL_IMAGE = 1e-3     # BASELINE.json north_star: per-pixel L-inf vs the reference
-TOL_FEATURE = 2e-4   # intermediate activations (O(1) magnitude after InstanceNorm)
+# intermediate activations (O(1) magnitude after InstanceNorm), per conv arithmetic: exact fp32 MFMA, and the
+# default split-bf16 three-product mode (16 mantissa bits per operand; same 1e-3 bound on the image)
+TOL_FEATURES = {"fp32": 2e-4, "bf16x3": 6e-4}
+_ORACLE = {}
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    """One generator + oracle state shared by the tests of this module (the CPU oracle takes seconds)."""
+@pytest.fixture(scope="module", params=["fp32", "bf16x3"])
+def ctx(request):
+    """One generator per precision mode + oracle state shared by the tests of this module (the CPU oracle takes
+    seconds and is computed once for both modes)."""
+    c = dict(_oracle_ctx())
     from impersonator_amd.networks.generator import ImpersonatorGenerator
+    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, max_batch=2, precision=request.param)
+    G.load_state_dict(c["sd"])
+    c["G"] = G.cuda()
+    c["precision"] = request.param
+    c["tol_feature"] = TOL_FEATURES[request.param]
+    yield c
+    G.release()
+
+
+def _oracle_ctx():
+    if _ORACLE:
+        return _ORACLE
     from impersonator_amd.utils.nmr import SMPLRenderer
     torch.set_num_threads(max(1, torch.get_num_threads()))
     s = helpers.scene()
     sd_np = helpers.generator_state_dict(seed=0, affine="random")
     sd = torch_ref.state_dict_from_numpy(sd_np)
-    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, max_batch=2)
-    G.load_state_dict(sd)
-    G = G.cuda()
     r = SMPLRenderer(image_size=256, faces=s["faces"], map_fn=s["map_fn"]).cuda()
 
     faces_t = helpers.t(s["faces"])
@@ -40,8 +54,9 @@ def ctx():
                                   helpers.t(s["map_fn"]))
     with torch.no_grad():
         o_enc, o_res = torch_ref.encode_src(sd, src_inputs)
-    return dict(s=s, sd=sd, G=G, r=r, p2v=p2v, src_img=src_img, bg_img=bg_img, src_inputs=src_inputs, fr=fr,
-                o_enc=o_enc, o_res=o_res)
+    _ORACLE.update(s=s, sd=sd, r=r, p2v=p2v, src_img=src_img, bg_img=bg_img, src_inputs=src_inputs, fr=fr,
+                   o_enc=o_enc, o_res=o_res)
+    return _ORACLE
 
 
 def test_encode_src_every_level(ctx):
@@ -50,10 +65,10 @@ def test_encode_src_every_level(ctx):
     for i, (a, b) in enumerate(zip(enc + res, ctx["o_enc"] + ctx["o_res"])):
         assert tuple(a.shape) == tuple(b.shape)
         d, where = helpers.maxdiff(a, b)
-        assert d <= TOL_FEATURE * max(1.0, float(b.abs().max())), ("feature %d" % i, d, where)
+        assert d <= ctx["tol_feature"] * max(1.0, float(b.abs().max())), ("feature %d" % i, d, where)
     g = helpers.golden("frame_golden.npz")
     for a, st in zip(enc, g["src_enc_stat"]):
-        assert abs(float(a.double().mean()) - st[0]) < 1e-5 and abs(float((a.double() ** 2).mean()) - st[2]) < 1e-4
+        assert abs(float(a.double().mean()) - st[0]) < 2e-5 and abs(float((a.double() ** 2).mean()) - st[2]) < 1e-4
 
 
 def test_inference_matches_oracle_and_reference_golden(ctx):
@@ -104,10 +119,10 @@ def test_trunk_and_decoder_checkpoints(ctx):
         c = 64 << l
         cat = G.peek(l, (bs, 256 >> l, 256 >> l, 2 * c))
         d, where = helpers.maxdiff(cat[..., :c].permute(0, 3, 1, 2), encs[l])
-        assert d <= TOL_FEATURE * max(1.0, float(encs[l].abs().max())), ("tsf encoder", l, d, where)
+        assert d <= ctx["tol_feature"] * max(1.0, float(encs[l].abs().max())), ("tsf encoder", l, d, where)
     trunk = G.peek(3, (bs, 32, 32, 512)).permute(0, 3, 1, 2)
     d, where = helpers.maxdiff(trunk, x)
-    assert d <= 5 * TOL_FEATURE * max(1.0, float(x.abs().max())), ("trunk", d, where)
+    assert d <= 5 * ctx["tol_feature"] * max(1.0, float(x.abs().max())), ("trunk", d, where)
 
 
 def test_batch_composition_is_independent(ctx):
@@ -154,7 +169,8 @@ def test_swap_two_sources(ctx):
 def test_align_corners_true_mode(ctx):
     """Hazard H1: torch-1.2 semantics (align_corners=True) are selectable at run time."""
     from impersonator_amd.networks.generator import ImpersonatorGenerator
-    G2 = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, max_batch=1, align_corners=True)
+    G2 = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, max_batch=1, align_corners=True,
+                               precision=ctx["precision"])
     G2.load_state_dict(ctx["sd"])
     G2 = G2.cuda()
     fr = ctx["fr"]

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DLWG_IGEMM_BENCH tools/igemm_bench.hip impersonator_amd/csrc/capi.hip -o tools/_build/igemm_bench
 // Times the production kernel and its ablation variants (see the DBG template parameter in conv.hip) on the layer
 // shapes of the tsf stream at batch 8, so that a change to the main loop is judged in one GPU call.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -23,7 +24,7 @@ int main(int argc, char **argv)
         {"skip2 128->64 @256 (bn64)", 8, 256, 128, 64, 3, 1, 64},
         {"enc3 256->512 s2 @64 (bn64)", 8, 64, 256, 512, 3, 2, 64},
     };
-    const int dbgs[] = {0, 100, 0, 100, 101};
+    const int dbgs[] = {100, 200, 230, 240, 241, 201, 204, 213, 200};
     hipStream_t st;
     hipStreamCreate(&st);
     hipEvent_t e0, e1;
@@ -48,7 +49,21 @@ int main(int argc, char **argv)
         for (auto &v : hw) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.02f;
         hipMemcpy(x, hx.data(), xin * 4, hipMemcpyHostToDevice);
         hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+        // split-bf16 copies of both operands for the bf16x3 variants (dbg >= 200)
+        float *xs, *ws;
+        hipMalloc(&xs, xin * 4 + 4096);   // + the zero run the bf16x3 kernel wants behind its input
+        hipMemset(xs + xin, 0, 4096);
+        hipMalloc(&ws, hw.size() * 4);
+        {
+            std::vector<float> t(xin);
+            split_bf16_groups(hx.data(), xin, t.data());
+            hipMemcpy(xs, t.data(), xin * 4, hipMemcpyHostToDevice);
+            t.resize(hw.size());
+            split_bf16_groups(hw.data(), hw.size(), t.data());
+            hipMemcpy(ws, t.data(), hw.size() * 4, hipMemcpyHostToDevice);
+        }
         ConvArgs a = {};
+        a.w_split = ws;
         a.x = x; a.ldx = s.Cin; a.N = s.N; a.H = s.H; a.W = s.H; a.Cin = s.Cin;
         a.cin_log2 = 0; while ((1 << a.cin_log2) < s.Cin) ++a.cin_log2;
         a.w = w; a.zeros = zeros; a.y = y; a.ldy = s.Cout; a.Ho = Ho; a.Wo = Ho; a.Cout = s.Cout;
@@ -60,6 +75,8 @@ int main(int argc, char **argv)
         for (int i = 0; i < 300; ++i) launch_conv_igemm_dbg(a, s.bn, 100, st);   // ~100 ms: let the clocks settle
         hipStreamSynchronize(st);
         for (int dbg : dbgs) {
+            a.x = dbg >= 200 ? xs : x;
+            a.zeros = dbg >= 200 ? xs + xin : zeros;
             for (int i = 0; i < 3; ++i) launch_conv_igemm_dbg(a, s.bn, dbg, st);
             hipEventRecord(e0, st);
             for (int i = 0; i < reps; ++i) launch_conv_igemm_dbg(a, s.bn, dbg, st);
@@ -67,10 +84,29 @@ int main(int argc, char **argv)
             hipEventSynchronize(e1);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            printf("  dbg%-2d %6.1f TF", dbg, flop * reps / (ms * 1e-3) / 1e12);
+            printf("  d%-3d %6.1f", dbg, flop * reps / (ms * 1e-3) / 1e12);
+        }
+        {   // sanity: bf16x3 result against the fp32 kernel's
+            std::vector<float> y0(yout), y1(yout);
+            a.x = x;
+            a.zeros = zeros;
+            launch_conv_igemm_dbg(a, s.bn, 100, st);
+            hipStreamSynchronize(st);
+            hipMemcpy(y0.data(), y, yout * 4, hipMemcpyDeviceToHost);
+            a.x = xs;
+            a.zeros = xs + xin;
+            launch_conv_igemm_dbg(a, s.bn, 200, st);
+            hipStreamSynchronize(st);
+            hipMemcpy(y1.data(), y, yout * 4, hipMemcpyDeviceToHost);
+            double md = 0, mx = 0;
+            for (size_t i = 0; i < yout; ++i) {
+                md = fmax(md, fabs((double)y0[i] - y1[i]));
+                mx = fmax(mx, fabs((double)y0[i]));
+            }
+            printf("  |d|max %.2e of %.2f", md, mx);
         }
         printf("\n");
-        hipFree(x); hipFree(w); hipFree(y); hipFree(part); hipFree(zeros);
+        hipFree(xs); hipFree(ws); hipFree(x); hipFree(w); hipFree(y); hipFree(part); hipFree(zeros);
     }
     return 0;
 }
