@@ -310,17 +310,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 //   * zero padding: a tap outside the image makes the lane read from a 16-byte zero buffer instead;
 //   * synchronisation is a raw s_barrier plus counted vmcnt: at the end of iteration t every wave waits until only
 //     its DMAs of stage t+2 are outstanding (=> stage t+1 has landed), then the barrier publishes it.
-//
-// SPLIT = true is the bf16x3 form of the same kernel (conv.h, "split-bf16 format"): activations and weights arrive as
-// [hi x32 | lo x32] bf16 groups occupying the very 128-byte rows the fp32 kernel moves, so addressing, swizzle, ring
-// and synchronisation are shared and only the fragment reads / MFMAs differ: 16-B column 2*kb + (lane>>5) of a row is
-// the hi operand of k-block kb (8 bf16 per lane = one v_mfma_f32_32x32x16_bf16 operand), column 4 + 2*kb + (lane>>5)
-// the lo operand; a stage is 2 k-blocks x 3 products per 32x32 tile.  The matrix pipe works 5.3x faster per tile than
-// in fp32, so the DMA pieces are spread one behind every 2-3 MFMAs.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
-template <int BN, int WM, int WN, int DBG, int NS, bool SPLIT, int BARQ = 3>
+template <int BN, int WM, int WN, int DBG, int NS>
 __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
 {
     constexpr int WAVES_N = BN / (32 * WN);
@@ -347,7 +340,9 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
     // A transposed conv is four sub-pixel phases with 1/2/2/4 taps.  Launched with gridDim.z == 1 (a.fuse_phases) one
     // workgroup walks all of them for its tile, so every workgroup carries the same 9 taps of work instead of the
     // 4-tap phase finishing long after the 1-tap one.
-    const int pz0 = a.fuse_phases ? 0 : (int)blockIdx.z;
+    // Unfused, the phases are separate workgroups; blockIdx.z counts down the phase index because the last phase has
+    // the most taps and the dispatcher hands out z = 0 first (longest job first).
+    const int pz0 = a.fuse_phases ? 0 : a.nphase - 1 - (int)blockIdx.z;
     const int pz1 = a.fuse_phases ? a.nphase : pz0 + 1;
     for (int pz = pz0; pz < pz1; ++pz) {
     const ConvPhase ph = a.ph[pz];
@@ -377,7 +372,7 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
 #pragma unroll
     for (int j = 0; j < B_ROWS; ++j) {
         const int row = (wave * B_ROWS + j) * 8 + lr;
-        wsrc[j] = (SPLIT ? a.w_split : a.w) + ph.w_off + (size_t)(n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4;
+        wsrc[j] = a.w + ph.w_off + (size_t)(n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4;
     }
 
     // The DMA is issued from inline asm on purpose: hipcc treats a compiler-visible global_load_lds as a pending LDS
@@ -400,64 +395,8 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
     // One DMA instruction occupies the wave's issue port for ~60 cycles; a stage needs LPS of them.  They are issued
     // ONE AT A TIME, each behind a chain of four MFMAs (256 cycles of matrix-pipe work already queued), never
     // back to back: piece p < 4 moves A chunk p, piece p >= 4 moves weight chunk p-4 of stage `kt` into ring slot `slot`.
-    // SPLIT addressing (bf16x3: the matrix pipe leaves ~5 issue slots per MFMA, address VALU has to go): every DMA is
-    // "wave-uniform 64-bit base + per-lane unsigned 32-bit byte offset" (saddr form).  The base walks the channel slice
-    // (and the weight row) by 128 B per stage in SGPRs; the lane offsets cur[] only change when the tap changes (once
-    // per Cin/32 stages), and a lane whose tap falls outside the image points at a run of zeros that the caller placed
-    // behind the tensor (a.zeros: >= Cin*4 bytes, above a.x, within 4 GiB), so the channel walk needs no select.
-    unsigned cur[4] = {0, 0, 0, 0}, wvoff[B_ROWS];
-    const unsigned zoff_b = (unsigned)((const char *)a.zeros - (const char *)xin);
-    unsigned s_ci_b = 0;
-    // both bases are wave-uniform; readfirstlane pins them to SGPRs for the "s" asm operand
-    auto uniform_ptr = [](const void *p) {
-        const unsigned long long v = (unsigned long long)p;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
-    };
-    const char *w_base = uniform_ptr((SPLIT ? a.w_split : a.w) + ph.w_off);
-    const char *x_base = uniform_ptr(xin);
-    auto retap = [&]() {
-        const int tapoff = (s_kh * a.W + s_kw) * a.dil * a.ldx;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) cur[p] = ((amask[p] >> s_tap) & 1u) ? (unsigned)((aoff[p] + tapoff) * 4) : zoff_b;
-    };
-    if constexpr (SPLIT) {
-#pragma unroll
-        for (int j = 0; j < B_ROWS; ++j) {
-            const int row = (wave * B_ROWS + j) * 8 + lr;
-            wvoff[j] = (unsigned)(((n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4) * 4);
-        }
-        retap();
-    }
-    auto dma16s = [&](unsigned voff, const char *sbase, unsigned lds_byte) {
-        asm volatile("s_mov_b32 m0, %2\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %0, %1"
-                     :
-                     : "v"(voff), "s"(sbase), "s"(lds_byte)
-                     : "memory", "m0");
-    };
     auto dma_piece = [&](int p, int kt, int slot) {
         const unsigned slot_byte = (unsigned)(slot * STAGE * 4);
-        if constexpr (SPLIT) {
-            if (p < 4) {
-                dma16s(cur[p], x_base + s_ci_b, wave_a + slot_byte + (unsigned)(p * 8 * BK * 4));
-            } else {
-                dma16s(wvoff[p - 4], w_base + (size_t)kt * (BK * 4), wave_b + slot_byte + (unsigned)((p - 4) * 8 * BK * 4));
-            }
-            if (p == LPS - 1) {
-                s_ci_b += BK * 4;
-                if (s_ci_b == (unsigned)a.Cin * 4) {
-                    asm volatile("; next tap" ::: "memory");   // keeps this rare path a real (wave-uniform) branch
-                    s_ci_b = 0;
-                    ++s_tap;
-                    if (++s_kw == ph.KW) { s_kw = 0; ++s_kh; }
-                    retap();
-                }
-            }
-            return;
-        }
         if (p < 4) {
             const unsigned sa = wave_a + slot_byte + (unsigned)(p * 8 * BK * 4);
             const int toff = (s_kh * a.W + s_kw) * a.dil * a.ldx + s_ci0;
@@ -494,88 +433,12 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
 #pragma unroll
     for (int k8 = 0; k8 < BK / 8; ++k8) fcol[k8] = (((2 * k8 + (lane >> 5)) ^ fsw) * 4);
 
-    // SPLIT: fragments of k-block kb of ring slot `slot` (hi: 16-B column 2*kb + (lane>>5), lo: 4 + that)
-    auto load_frags = [&](int slot, int kb, float4 (&xh)[WM], float4 (&xl)[WM], float4 (&yh)[WN], float4 (&yl)[WN]) {
-        const float *As = smem + slot * STAGE + a_row;
-        const float *Bs = smem + slot * STAGE + b_row;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            xh[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + fcol[kb]);
-            xl[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + fcol[2 + kb]);
-        }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            yh[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + fcol[kb]);
-            yl[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + fcol[2 + kb]);
-        }
-    };
-    float4 fr_ah[WM], fr_al[WM], fr_bh[WN], fr_bl[WN];   // SPLIT: k-block-0 fragments of the stage about to run
-#pragma unroll
-    for (int i = 0; i < WM; ++i) fr_ah[i] = fr_al[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < WN; ++j) fr_bh[j] = fr_bl[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-
     // iteration kt: MFMAs of stage kt from ring slot `slot`, DMA pieces of stage kt+2 (if any) in their shadow
-    // `slot_c` is an int (fp32 kernel) or a std::integral_constant (SPLIT: every LDS address becomes an immediate)
-    auto stage_body = [&](int kt, auto slot_c, auto do_dma) {
-        const int slot = slot_c;
+    auto stage_body = [&](int kt, int slot, auto do_dma) {
         const float *As = smem + slot * STAGE + a_row;
         const float *Bs = smem + slot * STAGE + b_row;
         int slot2 = slot + (NS - 1);
         if (slot2 >= NS) slot2 -= NS;
-        if constexpr (SPLIT) {
-            // One stage = Q MFMAs: k-block 0 (fragments fr0, fetched during the PREVIOUS stage) then k-block 1 (fr1,
-            // fetched at the top of this one).  The stage barrier sits in the middle of the MFMA stream, before MFMA QB,
-            // not at the end: behind it the k-block-0 fragments of the NEXT stage are fetched while the remaining
-            // MFMAs run, so no LDS latency is exposed at the stage boundary (with 32-cycle MFMAs that latency was
-            // ~40% of the stage).  By MFMA QB every wave has issued and consumed all reads of this slot (lgkmcnt(0)),
-            // so the pieces issued after the barrier may overwrite the slot consumed one stage earlier.
-            constexpr int Q = 6 * WM * WN, TILES = WM * WN;
-            static_assert(Q % LPS == 0, "DMA pieces must spread evenly over the MFMAs of a stage");
-            constexpr int QP = Q / LPS;
-            static_assert(NS >= 3 && BARQ >= 1 && BARQ <= 3, "ring depth / barrier position");
-            constexpr int QB = Q * BARQ / 4;            // barrier before this MFMA
-            constexpr int ISSUED = QB / QP;             // pieces of this stage already issued at the barrier
-            float4 f1ah[WM], f1al[WM], f1bh[WN], f1bl[WN];
-            float4 nxah[WM], nxal[WM], nxbh[WN], nxbl[WN];
-            if (!(DBG & 8)) load_frags(slot, 1, f1ah, f1al, f1bh, f1bl);
-            int slot1 = slot + 1;
-            if (slot1 == NS) slot1 = 0;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int kb = q / (Q / 2), r = q % (Q / 2);
-                const int t = r / TILES, i = (r / WN) % WM, j = r % WN;   // cross terms first, hi*hi last
-                if (q == QB) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    // stage kt+1 must have landed for every wave: only younger pieces may still be in flight
-                    if (decltype(do_dma)::value) {
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 3) * LPS + ISSUED) : "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    }
-                    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (!(DBG & 8)) load_frags(slot1, 0, nxah, nxal, nxbh, nxbl);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const float4 a4 = kb == 0 ? (t == 0 ? fr_al[i] : fr_ah[i]) : (t == 0 ? f1al[i] : f1ah[i]);
-                const float4 b4 = kb == 0 ? (t == 1 ? fr_bl[j] : fr_bh[j]) : (t == 1 ? f1bl[j] : f1bh[j]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a4),
-                                                                    __builtin_bit_cast(bf16x8_t, b4), acc[i][j], 0, 0, 0);
-                if (decltype(do_dma)::value && q % QP == QP - 1 && !(DBG & 1)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    dma_piece(q / QP, kt + (NS - 1), slot2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (!(DBG & 8)) {
-#pragma unroll
-                for (int i = 0; i < WM; ++i) { fr_ah[i] = nxah[i]; fr_al[i] = nxal[i]; }
-#pragma unroll
-                for (int j = 0; j < WN; ++j) { fr_bh[j] = nxbh[j]; fr_bl[j] = nxbl[j]; }
-            }
-            return;
-        } else {
         float4 af[WM], bf[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + fcol[0]);
@@ -612,7 +475,6 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
                 for (int j = 0; j < WN; ++j) bf[j] = bn4[j];
             }
         }
-        }
         // stage kt+1 must have landed (for every wave) before anyone reads it: only this iteration's own pieces
         // (stage kt+2) may still be in flight
         if (decltype(do_dma)::value) {
@@ -625,7 +487,7 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
-    static_assert(SPLIT || LPS <= (BK / 8) * WM * WN, "not enough MFMA chains to hide the DMA pieces of a stage");
+    static_assert(LPS <= (BK / 8) * WM * WN, "not enough MFMA chains to hide the DMA pieces of a stage");
 
     const int nk = ph.Kpad / BK;
     // prologue: NS-1 stages in flight, the first one must have landed
@@ -642,41 +504,15 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if constexpr (SPLIT) load_frags(0, 0, fr_ah, fr_al, fr_bh, fr_bl);
 
     int slot = 0, kt = 0;
-    if constexpr (SPLIT) {
-        // whole turns of the ring with compile-time slots, then the remaining stages through a slot dispatch
-        static_assert(NS == 3 || NS == 4, "ring depth");
-        for (; kt + 2 * (NS - 1) < nk; kt += NS) {
-            stage_body(kt, std::integral_constant<int, 0>{}, yes{});
-            stage_body(kt + 1, std::integral_constant<int, 1>{}, yes{});
-            stage_body(kt + 2, std::integral_constant<int, 2>{}, yes{});
-            if constexpr (NS == 4) stage_body(kt + 3, std::integral_constant<int, 3>{}, yes{});
-        }
-        auto run_stage = [&](int k, int sl, auto do_dma) {
-            if (sl == 0) stage_body(k, std::integral_constant<int, 0>{}, do_dma);
-            else if (sl == 1) stage_body(k, std::integral_constant<int, 1>{}, do_dma);
-            else if (NS == 3 || sl == 2) stage_body(k, std::integral_constant<int, 2>{}, do_dma);
-            else stage_body(k, std::integral_constant<int, NS - 1>{}, do_dma);
-        };
-        for (; kt + (NS - 1) < nk; ++kt) {
-            run_stage(kt, slot, yes{});
-            if (++slot == NS) slot = 0;
-        }
-        for (; kt < nk; ++kt) {
-            run_stage(kt, slot, no{});
-            if (++slot == NS) slot = 0;
-        }
-    } else {
-        for (; kt + (NS - 1) < nk; ++kt) {
-            stage_body(kt, slot, yes{});
-            if (++slot == NS) slot = 0;
-        }
-        for (; kt < nk; ++kt) {
-            stage_body(kt, slot, no{});
-            if (++slot == NS) slot = 0;
-        }
+    for (; kt + (NS - 1) < nk; ++kt) {
+        stage_body(kt, slot, yes{});
+        if (++slot == NS) slot = 0;
+    }
+    for (; kt < nk; ++kt) {
+        stage_body(kt, slot, no{});
+        if (++slot == NS) slot = 0;
     }
     igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
     __syncthreads();   // the statistics scratch aliases the ring: finish reading it before the next phase's DMA
@@ -686,13 +522,247 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
 template <int BN, int WM, int WN, int DBG = 0, int NS = 3>
 __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
 {
-    igemm_dma_body<BN, WM, WN, DBG, NS, false>(a);
+    igemm_dma_body<BN, WM, WN, DBG, NS>(a);
 }
 
-template <int BN, int WM, int WN, int DBG = 0, int NS = 3, int BARQ = 3>
-__global__ __launch_bounds__(256) void conv_igemm_dma_bf16x3(const ConvArgs a)
+// ------------------------------------------------------------------------------------------------
+// conv_igemm_bf16x3: the bf16x3 implicit GEMM (conv.h, "split-bf16 format") -- DMA-fed ring like conv_igemm_dma_f32,
+// same 128-B rows, swizzle, ring and epilogue -- built around what a 32-cycle MFMA leaves room for (one wave per SIMD
+// hides about five other instructions per MFMA):
+//   * fragments: 16-B column 2*kb + (lane>>5) of a row is the hi operand of k-block kb (8 bf16 per lane = one
+//     v_mfma_f32_32x32x16_bf16 operand), column 4 + 2*kb + (lane>>5) the lo operand; a stage is 2 k-blocks x 3
+//     products (lo*hi, hi*lo, hi*hi) per 32x32 tile, tiles walked inside each product so that consecutive MFMAs never
+//     share an accumulator;
+//   * every DMA is "SGPR base + 32-bit lane offset": the base walks the channel slice / weight row by 128 B per stage,
+//     the lane offsets change only with the tap (a real, wave-uniform branch), padding taps point at the zero run
+//     behind the input tensor (a.zeros).  No address VALU in the steady state.
+//   * ring slots are compile-time (whole turns of the ring unrolled): every LDS address is an immediate.
+//   * the stage barrier sits 3/4 into the MFMA stream; behind it the next stage's first fragments are fetched under
+//     the remaining MFMAs.
+// Measured dead ends (tools/igemm_bench.hip): eight waves splitting the two k-blocks of a stage (two per SIMD, partial
+// tiles added through LDS) 343 vs 409 TFLOP/s; 4-slot ring =; barrier at 1/2 instead of 3/4 =.  rocprofv3: LDS 18% busy,
+// no bank conflicts; the matrix pipe is 49% busy at a power-limited 2.1-2.2 GHz (a pure MFMA loop on random operands
+// reaches 80% of the 2.5 PFLOP/s dense peak on this part, tools/mfma_peak.hip).
+template <int BN, int WM, int WN, int NS = 3, int DBG = 0>
+__global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
 {
-    igemm_dma_body<BN, WM, WN, DBG, NS, true, BARQ>(a);
+    constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BM / (32 * WM);
+    static_assert(WAVES_M * WAVES_N == 4 && NS >= 3, "wave layout");
+    constexpr int A_CH = 4, B_CH = BN / 32;               // 1-KiB DMA chunks (8 rows x 128 B) per wave per stage
+    constexpr int LPS = A_CH + B_CH;
+    constexpr int STAGE = (BM + BN) * BK;                 // floats (4-byte units) per ring slot
+    constexpr int TILES = WM * WN;
+    constexpr int Q = 6 * TILES;                          // MFMAs of a wave per stage
+    static_assert(Q % LPS == 0, "DMA pieces must spread evenly over the MFMAs of a stage");
+    constexpr int QP = Q / LPS;
+    constexpr int QB = Q * 3 / 4;                         // stage barrier before this MFMA
+    constexpr int ISSUED = QB / QP;                       // pieces of the stage already issued by then
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int hw_m = a.Hm * a.Wm, img = m0 / hw_m, rem0 = m0 - img * hw_m;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    auto uniform_ptr = [](const void *p) {   // wave-uniform pointer pinned to SGPRs (the "s" asm operand below)
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+    };
+    // compiler-invisible on purpose (see conv_igemm_dma_f32): completion is tracked with counted vmcnt
+    auto dma16 = [&](unsigned voff, const char *sbase, unsigned lds_byte) {
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(voff), "s"(sbase), "s"(lds_byte)
+                     : "memory", "m0");
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    // unfused phases: blockIdx.z counts the phase index down (most taps first, see conv_igemm_dma_f32)
+    const int pz0 = a.fuse_phases ? 0 : a.nphase - 1 - (int)blockIdx.z;
+    const int pz1 = a.fuse_phases ? a.nphase : pz0 + 1;
+    for (int pz = pz0; pz < pz1; ++pz) {
+    const ConvPhase ph = a.ph[pz];
+
+    // ---- DMA geometry: chunk c of a stage = tile rows 8c .. 8c+7; lane -> (row = lane>>3, 16-B slot = lane&7);
+    //      the source column is swizzled, (lane&7) ^ ((row>>1)&7), the LDS image is linear (conflict-free b128 reads)
+    const int lr = lane >> 3, ls = lane & 7;
+    int aoff[A_CH];
+    unsigned amask[A_CH];
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+        const int row = (wave * A_CH + j) * 8 + lr;
+        const int rem = rem0 + row;
+        const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
+        const int hi0 = hm * a.stride - a.pad, wi0 = wm * a.stride - a.pad;
+        aoff[j] = (hi0 * a.W + wi0) * a.ldx + (ls ^ ((row >> 1) & 7)) * 4;
+        unsigned m = 0;
+        for (int t = 0, kh = 0, kw = 0; t < ph.ntaps; ++t) {
+            const bool ok = (unsigned)(hi0 + kh * a.dil) < (unsigned)a.H && (unsigned)(wi0 + kw * a.dil) < (unsigned)a.W;
+            m |= (unsigned)ok << t;
+            if (++kw == ph.KW) { kw = 0; ++kh; }
+        }
+        amask[j] = m;
+    }
+    const float *xin = a.x + (size_t)img * a.H * a.W * a.ldx;
+    const char *x_base = uniform_ptr(xin);
+    const char *w_base = uniform_ptr(a.w_split + ph.w_off);
+    const unsigned zoff_b = (unsigned)((const char *)a.zeros - (const char *)xin);
+    unsigned wvoff[B_CH], cur[A_CH];
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+        const int row = (wave * B_CH + j) * 8 + lr;
+        wvoff[j] = (unsigned)(((n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4) * 4);
+    }
+    int s_tap = 0, s_kh = 0, s_kw = 0;
+    unsigned s_ci_b = 0;
+    auto retap = [&]() {
+        const int tapoff = (s_kh * a.W + s_kw) * a.dil * a.ldx;
+#pragma unroll
+        for (int p = 0; p < A_CH; ++p) cur[p] = ((amask[p] >> s_tap) & 1u) ? (unsigned)((aoff[p] + tapoff) * 4) : zoff_b;
+    };
+    retap();
+    const unsigned wave_a = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * A_CH * 8 * BK * 4));
+    const unsigned wave_b = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((BM * BK + wave * B_CH * 8 * BK) * 4));
+    // piece p of stage kt into ring slot `slot`: p < A_CH activation chunks, then the weight chunks
+    auto dma_piece = [&](int p, int kt, int slot) {
+        const unsigned slot_byte = (unsigned)(slot * STAGE * 4);
+        if (p < A_CH) {
+            dma16(cur[p], x_base + s_ci_b, wave_a + slot_byte + (unsigned)(p * 8 * BK * 4));
+        } else {
+            dma16(wvoff[p - A_CH], w_base + (size_t)kt * (BK * 4), wave_b + slot_byte + (unsigned)((p - A_CH) * 8 * BK * 4));
+        }
+        if (p == LPS - 1) {
+            s_ci_b += BK * 4;
+            if (s_ci_b == (unsigned)a.Cin * 4) {
+                asm volatile("; next tap" ::: "memory");   // keeps this rare path a real (wave-uniform) branch
+                s_ci_b = 0;
+                ++s_tap;
+                if (++s_kw == ph.KW) { s_kw = 0; ++s_kh; }
+                retap();
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragments: row = base + (lane&31); hi operand of k-block kb = 16-B column 2*kb + (lane>>5), lo = 4 + that
+    const int frow = lane & 31, fsw = (frow >> 1) & 7;
+    const int a_row = (wave_m * 32 * WM + frow) * BK;
+    const int b_row = BM * BK + (wave_n * 32 * WN + frow) * BK;
+    int fcol[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fcol[c] = (((2 * c + (lane >> 5)) ^ fsw) * 4);
+    struct Frags { float4 ah[WM], al[WM], bh[WN], bl[WN]; };
+    auto load_frags = [&](int slot, int kb, Frags &f) {
+        const float *As = smem + slot * STAGE + a_row;
+        const float *Bs = smem + slot * STAGE + b_row;
+        const int ch = fcol[kb], cl = fcol[2 + kb];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            f.ah[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + ch);
+            f.al[i] = *reinterpret_cast<const float4 *>(As + i * 32 * BK + cl);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            f.bh[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + ch);
+            f.bl[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + cl);
+        }
+    };
+    Frags fr;   // k-block-0 fragments of the stage about to run (fetched during the previous stage)
+
+    auto stage_body = [&](int kt, auto slot_c, auto do_dma) {
+        constexpr int slot = decltype(slot_c)::value;
+        constexpr int slot1 = (slot + 1) % NS, slot2 = (slot + NS - 1) % NS;
+        Frags f1, nx;
+        if (!(DBG & 8)) load_frags(slot, 1, f1);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int kb = q / (3 * TILES), r = q % (3 * TILES);
+            const int t = r / TILES, i = (r / WN) % WM, j = r % WN;   // cross terms first, hi*hi last
+            if (q == QB) {
+                __builtin_amdgcn_sched_barrier(0);
+                // stage kt+1 must have landed for every wave (only younger pieces may be in flight) and every wave
+                // must be done reading this slot's predecessor before the pieces issued below overwrite it
+                if (decltype(do_dma)::value) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 3) * LPS + ISSUED) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+                if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!(DBG & 8)) load_frags(slot1, 0, nx);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const Frags &f = kb == 0 ? fr : f1;
+            const float4 a4 = t == 0 ? f.al[i] : f.ah[i];
+            const float4 b4 = t == 1 ? f.bl[j] : f.bh[j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a4),
+                                                                __builtin_bit_cast(bf16x8_t, b4), acc[i][j], 0, 0, 0);
+            if (decltype(do_dma)::value && q % QP == QP - 1 && !(DBG & 1)) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_piece(q / QP, kt + (NS - 1), slot2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(DBG & 8)) fr = nx;
+    };
+
+    const int nk = ph.Kpad / BK;
+    // prologue: NS-1 stages in flight, the first one landed
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) {
+#pragma unroll
+            for (int p = 0; p < LPS; ++p) dma_piece(p, st, st);
+        }
+    if (nk >= NS - 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(0, 0, fr);
+
+    // whole turns of the ring with compile-time slots, the remaining stages through a slot dispatch
+    int kt = 0, slot = 0;
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    for (; kt + 2 * (NS - 1) < nk; kt += NS) {
+        stage_body(kt, std::integral_constant<int, 0>{}, yes{});
+        stage_body(kt + 1, std::integral_constant<int, 1>{}, yes{});
+        stage_body(kt + 2, std::integral_constant<int, 2>{}, yes{});
+        if constexpr (NS == 4) stage_body(kt + 3, std::integral_constant<int, 3>{}, yes{});
+    }
+    auto run_stage = [&](int k, int sl, auto do_dma) {
+        if (sl == 0) stage_body(k, std::integral_constant<int, 0>{}, do_dma);
+        else if (sl == 1) stage_body(k, std::integral_constant<int, 1>{}, do_dma);
+        else if (NS == 3 || sl == 2) stage_body(k, std::integral_constant<int, 2>{}, do_dma);
+        else stage_body(k, std::integral_constant<int, NS - 1>{}, do_dma);
+    };
+    for (; kt + (NS - 1) < nk; ++kt) {
+        run_stage(kt, slot, yes{});
+        if (++slot == NS) slot = 0;
+    }
+    for (; kt < nk; ++kt) {
+        run_stage(kt, slot, no{});
+        if (++slot == NS) slot = 0;
+    }
+
+    igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    __syncthreads();   // scratch aliases the ring: done with it before the next phase's DMA
+    }  // phase loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -908,7 +978,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 const char *const kIgemmVariantNames[kIgemmVariants] = {
     "conv_igemm_f32<64, 1, 2, false, 0>", "conv_igemm_f32<128, 2, 2, false, 0>", "conv_igemm_f32<64, 1, 2, true, 0>",
     "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>",
-    "conv_igemm_dma_bf16x3<64, 1, 2, 0, 3>", "conv_igemm_dma_bf16x3<128, 2, 2, 0, 3>"};
+    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2, 3, 0>"};
 
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
 {
@@ -955,21 +1025,21 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         const size_t lds3 = (size_t)3 * (BM + bn) * BK * sizeof(float);
         static bool opt16 = false;
         if (!opt16) {
-            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_bf16x3<64, 1, 2>),
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<64, 1, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 64) * BK * (int)sizeof(float)));
-            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_bf16x3<128, 2, 2>),
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<128, 2, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 128) * BK * (int)sizeof(float)));
             opt16 = true;
         }
         for (int p = 0; p < a.nphase; ++p)
             if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the bf16x3 path");
         if (bn == 64) {
-            conv_igemm_dma_bf16x3<64, 1, 2><<<grid, 256, lds3, st>>>(a);
+            conv_igemm_bf16x3<64, 1, 2><<<grid, 256, lds3, st>>>(a);
         } else {
-            conv_igemm_dma_bf16x3<128, 2, 2><<<grid, 256, lds3, st>>>(a);
+            conv_igemm_bf16x3<128, 2, 2><<<grid, 256, lds3, st>>>(a);
         }
         if (variant) *variant = bn == 64 ? kIgemmBf16x3_64 : kIgemmBf16x3_128;
-        LWG_LAUNCH_CHECK("conv_igemm_dma_bf16x3");
+        LWG_LAUNCH_CHECK("conv_igemm_bf16x3");
         return LWG_OK;
     }
     if (small_cin && bn != 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d < %d is only built for the 64-channel tile", a.Cin, BK);
@@ -1060,32 +1130,29 @@ static void launch_dma_dbg(const ConvArgs &a, int bn, hipStream_t st)
         conv_igemm_dma_f32<128, 2, 2, DBG><<<grid, 256, lds, st>>>(a);
     }
 }
-template <int DBG, int NS, int BARQ = 3>
-static void launch_split_dbg(const ConvArgs &a, int bn, hipStream_t st)
+template <int NS, int DBG>
+static void launch_k_dbg(const ConvArgs &a, int bn, hipStream_t st)
 {
     const dim3 grid(a.mtiles, a.Cout / bn, a.nphase);
     const size_t lds = (size_t)NS * (BM + bn) * BK * sizeof(float);
     if (bn == 64) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_bf16x3<64, 1, 2, DBG, NS, BARQ>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<64, 1, 2, NS, DBG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        conv_igemm_dma_bf16x3<64, 1, 2, DBG, NS, BARQ><<<grid, 256, lds, st>>>(a);
+        conv_igemm_bf16x3<64, 1, 2, NS, DBG><<<grid, 256, lds, st>>>(a);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_bf16x3<128, 2, 2, DBG, NS, BARQ>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<128, 2, 2, NS, DBG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        conv_igemm_dma_bf16x3<128, 2, 2, DBG, NS, BARQ><<<grid, 256, lds, st>>>(a);
+        conv_igemm_bf16x3<128, 2, 2, NS, DBG><<<grid, 256, lds, st>>>(a);
     }
 }
 int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
 {
     switch (dbg) {
-        case 200: launch_split_dbg<0, 3>(a, bn, st); break;
-        case 201: launch_split_dbg<1, 3>(a, bn, st); break;
-        case 204: launch_split_dbg<4, 3>(a, bn, st); break;
-        case 208: launch_split_dbg<8, 3>(a, bn, st); break;
-        case 213: launch_split_dbg<13, 3>(a, bn, st); break;
-        case 240: launch_split_dbg<0, 4>(a, bn, st); break;
-        case 230: launch_split_dbg<0, 3, 2>(a, bn, st); break;
-        case 241: launch_split_dbg<0, 4, 2>(a, bn, st); break;
+        case 200: launch_k_dbg<3, 0>(a, bn, st); break;
+        case 201: launch_k_dbg<3, 1>(a, bn, st); break;   // no DMA
+        case 204: launch_k_dbg<3, 4>(a, bn, st); break;   // no barrier
+        case 213: launch_k_dbg<3, 13>(a, bn, st); break;  // MFMAs only
+        case 240: launch_k_dbg<4, 0>(a, bn, st); break;   // 4-slot ring
         case 0: launch_dbg<0>(a, bn, st); break;
         case 1: launch_dbg<1>(a, bn, st); break;
         case 3: launch_dbg<3>(a, bn, st); break;
