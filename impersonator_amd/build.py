@@ -24,6 +24,7 @@ SOURCES = [
     ("warp.hip", ["-ffp-contract=off"]),
     ("smpl.hip", []),
     ("conv.hip", []),
+    ("direct.hip", []),
     ("generator.hip", []),
     ("inpaint.hip", []),
 ]

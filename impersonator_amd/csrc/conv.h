@@ -1,5 +1,7 @@
 // Launch interface of the generator's device kernels (conv.hip). Host-side only.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace lwg {
@@ -57,10 +59,23 @@ struct ConvArgs {
 
 // bn = 64 or 128 output channels per workgroup tile.  *variant (optional) receives which kernel instantiation ran:
 enum { kIgemmReg64 = 0, kIgemmReg128 = 1, kIgemmSmallCin = 2, kIgemmDma64 = 3, kIgemmDma128 = 4, kIgemmBf16x3_64 = 5,
-       kIgemmBf16x3_128 = 6, kIgemmVariants = 7 };
-inline bool igemm_variant_is_bf16x3(int v) { return v == kIgemmBf16x3_64 || v == kIgemmBf16x3_128; }
+       kIgemmBf16x3_128 = 6, kDirectStemBf16x3 = 7, kIgemmVariants = 8 };
 extern const char *const kIgemmVariantNames[kIgemmVariants];
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant = nullptr);
+
+// The 7x7 stem (Cin 6 in an NHWC8 fp32 tensor -> 64 channels) as an LDS-resident direct convolution on the bf16x3
+// path (direct.hip).  `w` is the filter bank packed by stem_pack_weights; output and partials as launch_conv_igemm.
+constexpr int kStemWPitch = 57 * 16;               // bytes per output channel and plane: 7 rows x 8 taps x 16 B + 16 pad
+constexpr int kStemWBytes = 2 * 64 * kStemWPitch;  // hi plane, lo plane
+struct StemArgs {
+    const float *x; int N, H, W;    // NHWC8 fp32
+    const void *w;                  // device, kStemWBytes
+    float *y;                       // raw output NHWC (N,H,W,64)
+    float2 *partials;               // [N*H*W/128][64] or null
+};
+bool stem_bf16x3_supported(int H, int W, int cin_pad, int cout, int k, int stride, int pad);
+void stem_pack_weights(const float *w_oihw, int cin, std::vector<unsigned char> &out);
+int launch_stem_bf16x3(const StemArgs &a, hipStream_t st);
 
 // (mean, M2) partials -> per (image, channel) scale/shift of InstanceNorm2d(affine, eps) (biased variance)
 int launch_in_finalize(const float2 *partials, int nphase, int mtiles, int N, int C, const float *gamma,

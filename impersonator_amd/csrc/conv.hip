@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 const char *const kIgemmVariantNames[kIgemmVariants] = {
     "conv_igemm_f32<64, 1, 2, false, 0>", "conv_igemm_f32<128, 2, 2, false, 0>", "conv_igemm_f32<64, 1, 2, true, 0>",
     "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>",
-    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2, 3, 0>"};
+    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2, 3, 0>", "stem_bf16x3_kernel"};
 
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
 {

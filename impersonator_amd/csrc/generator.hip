@@ -32,6 +32,7 @@ struct Layer {
     // device weights: conv [cout][kpad]; transposed: four phase matrices back to back
     float *w = nullptr;
     float *w_split = nullptr;         // the same matrices in the split-bf16 format (conv.h), Cin >= 32 layers only
+    void *w_stem = nullptr;           // 7x7 stem only: filter bank packed for the direct bf16x3 kernel (direct.hip)
     ConvPhase ph[4];
     int nphase = 1;
     float *gamma = nullptr, *beta = nullptr;
@@ -155,6 +156,9 @@ int alloc_layer(Layer &L)
     if (L.cin_pad >= kConvBK) {
         LWG_HIP(hipMalloc(reinterpret_cast<void **>(&L.w_split), L.w_floats * sizeof(float)));
         LWG_HIP(hipMemset(L.w_split, 0, L.w_floats * sizeof(float)));
+    } else if (!L.transposed && stem_bf16x3_supported(kConvBM, kConvBM, L.cin_pad, L.cout, L.k, L.stride, L.pad)) {
+        LWG_HIP(hipMalloc(&L.w_stem, kStemWBytes));
+        LWG_HIP(hipMemset(L.w_stem, 0, kStemWBytes));
     }
     if (L.has_norm) {
         if ((rc = dev_alloc(&L.gamma, L.cout)) != LWG_OK) return rc;
@@ -167,7 +171,9 @@ void free_layer(Layer &L)
 {
     if (L.w) (void)hipFree(L.w);
     if (L.w_split) (void)hipFree(L.w_split);
+    if (L.w_stem) (void)hipFree(L.w_stem);
     L.w_split = nullptr;
+    L.w_stem = nullptr;
     if (L.gamma) (void)hipFree(L.gamma);
     if (L.beta) (void)hipFree(L.beta);
     L.w = L.gamma = L.beta = nullptr;
@@ -235,6 +241,11 @@ int upload_conv(Layer &L, const float *w, const int64_t *shape, int ndim, const 
         for (int ci = 0; ci < L.cin; ++ci)
             for (int t = 0; t < L.k * L.k; ++t)
                 h[(size_t)co * p.Kpad + (size_t)t * L.cin_pad + ci] = w[((size_t)co * L.cin + ci) * L.k * L.k + t];
+    if (L.w_stem) {
+        std::vector<unsigned char> packed;
+        stem_pack_weights(w, L.cin, packed);
+        LWG_HIP(hipMemcpy(L.w_stem, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    }
     return upload_matrix(L, h);
 }
 
@@ -384,7 +395,18 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
         if (rc != LWG_OK) return rc;
     }
     int variant = 0;
-    int rc = launch_conv_igemm(a, bn, st, &variant);
+    int rc;
+    if (g->split && L.w_stem && ldx == 8 && stem_bf16x3_supported(H, W, L.cin_pad, L.cout, L.k, L.stride, L.pad)) {
+        StemArgs s = {};
+        s.x = x; s.N = N; s.H = H; s.W = W;
+        s.w = L.w_stem;
+        s.y = raw;
+        s.partials = a.partials;
+        rc = launch_stem_bf16x3(s, st);
+        variant = kDirectStemBf16x3;
+    } else {
+        rc = launch_conv_igemm(a, bn, st, &variant);
+    }
     if (rc != LWG_OK) return rc;
     if (g->profile) {
         LWG_HIP(hipEventRecord(e1, st));
