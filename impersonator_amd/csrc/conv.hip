@@ -19,8 +19,8 @@
 // in_finalize : combines tile statistics per (image, channel) -> scale/shift.
 // apply       : y = act(x*scale+shift) (+ residual) (+ bilinear-warped source features), float4 over
 //               channels, writes straight into channel slices of the decoder's concat buffers (torch.cat is free).
-// heads       : direct 7x7 conv 64->3+1 on the vector ALU (N=4 outputs cannot feed a 32-wide MFMA tile),
-//               InstanceNorm+ReLU of its input folded into the halo load, tanh/sigmoid/blend fused.
+// heads       : direct 7x7 conv 64->3+1 on the vector ALU (N=4 outputs cannot feed a 32-wide MFMA tile), four pixels
+//               per thread, InstanceNorm+ReLU of its input folded into the halo load, tanh/sigmoid/blend fused.
 #include <type_traits>
 
 #include "conv.h"
@@ -905,30 +905,42 @@ __global__ __launch_bounds__(256) void unsplit_kernel(float *buf, size_t ngroups
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int HT_ROWS = 8, HT_COLS = 32;                // output tile per workgroup
-constexpr int HH = HT_ROWS + 6, HWD = HT_COLS + 6;      // halo tile
-constexpr int HPITCH = 20;                              // floats per halo pixel (16 channels + pad: conflict-free b128)
+// heads: thread = one image column x four consecutive rows of a 32x32 tile.  Channels are walked in chunks of 8 through
+// an LDS halo (38x38 pixels, 48-byte pitch: conflict-free b128 reads for lanes on adjacent columns).  For a fixed
+// (kx, 4-channel group) a thread fetches the ten halo rows its four pixels see once and reuses them over the seven
+// ky taps: one b128 activation read per 45 FMAs.  The chunk's weights sit in LDS too and are read as wave-wide
+// broadcasts (scalar loads of the weights, tried first, left the two resident waves per SIMD waiting on s_waitcnt:
+// the SGPR file cannot hold a prefetched (kx, group) block).  The compiler emits v_pk_fma_f32 for the output pairs.
+constexpr int HT = 32, HH = HT + 6;         // tile edge, halo edge
+constexpr int HPITCH = 12;                  // floats per halo pixel: 8 channels + 4 pad
+constexpr int HEADS_W = 49 * 8 * 4;         // weights of one 8-channel chunk: [tap][channel][output]
+constexpr int HEADS_LDS = (HH * HH * HPITCH + HEADS_W) * (int)sizeof(float);
 
 __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float halo[HH * HWD * HPITCH];
+    extern __shared__ __attribute__((aligned(16))) float halo[];
     const int tid = threadIdx.x;
-    const int tx = tid & 31, ty = tid >> 5;
+    const int tx = tid & 31, tg = tid >> 5;
     const int n = blockIdx.z;
-    const int y0 = blockIdx.y * HT_ROWS, x0 = blockIdx.x * HT_COLS;
+    const int y0 = blockIdx.y * HT, x0 = blockIdx.x * HT;
     const float *xin = a.x + (size_t)n * a.H * a.W * 64;
     const float2 *ss = a.scale_shift + (size_t)n * 64;
 
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    for (int chunk = 0; chunk < 4; ++chunk) {
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[r][o] = 0.f;
+
+    for (int chunk = 0; chunk < 8; ++chunk) {
         __syncthreads();
-        for (int i = tid; i < HH * HWD * 4; i += 256) {
-            const int pix = i >> 2, q = i & 3;
-            const int hy = pix / HWD, hx = pix - hy * HWD;
+        for (int i = tid; i < HH * HH * 2; i += 256) {
+            const int pix = i >> 1, half = i & 1;
+            const int hy = pix / HH, hx = pix - hy * HH;
             const int gy = y0 - 3 + hy, gx = x0 - 3 + hx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-                const int c = chunk * 16 + q * 4;
+                const int c = chunk * 8 + half * 4;
                 v = ld4(xin + ((size_t)gy * a.W + gx) * 64 + c);
                 const float4 s01 = ld4(reinterpret_cast<const float *>(ss + c));
                 const float4 s23 = ld4(reinterpret_cast<const float *>(ss + c + 2));
@@ -937,40 +949,65 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
                 v.z = fmaxf(v.z * s23.x + s23.y, 0.f);
                 v.w = fmaxf(v.w * s23.z + s23.w, 0.f);
             }
-            *reinterpret_cast<float4 *>(halo + pix * HPITCH + q * 4) = v;
+            *reinterpret_cast<float4 *>(halo + pix * HPITCH + half * 4) = v;
+        }
+        float *wl = halo + HH * HH * HPITCH;
+        for (int i = tid; i < 49 * 8; i += 256) {   // (tap, channel) -> 4 outputs
+            const int t = i >> 3, c = i & 7;
+            *reinterpret_cast<float4 *>(wl + i * 4) = ld4(a.wh + ((size_t)t * 64 + chunk * 8 + c) * 4);
         }
         __syncthreads();
-        for (int ky = 0; ky < 7; ++ky) {
+        for (int kx = 0; kx < 7; ++kx)
+            for (int q = 0; q < 2; ++q) {
+                // all LDS reads of the block up front (10 activation rows + 28 weight quads, ~150 VGPRs): one
+                // latency per 448 FMAs instead of one per 16
+                float4 hv[10], wq[7][4];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const float *lp = halo + ((ty + ky) * HWD + tx + kx) * HPITCH;
-                const float *wp = a.wh + ((size_t)(ky * 7 + kx) * 64 + chunk * 16) * 4;  // wave-uniform: scalar loads
+                for (int hr = 0; hr < 10; ++hr) hv[hr] = ld4(halo + ((tg * 4 + hr) * HH + tx + kx) * HPITCH + q * 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = ld4(lp + q * 4);
-                    const float *w = wp + q * 16;
-                    acc0 += v.x * w[0];  acc1 += v.x * w[1];  acc2 += v.x * w[2];  acc3 += v.x * w[3];
-                    acc0 += v.y * w[4];  acc1 += v.y * w[5];  acc2 += v.y * w[6];  acc3 += v.y * w[7];
-                    acc0 += v.z * w[8];  acc1 += v.z * w[9];  acc2 += v.z * w[10]; acc3 += v.z * w[11];
-                    acc0 += v.w * w[12]; acc1 += v.w * w[13]; acc2 += v.w * w[14]; acc3 += v.w * w[15];
+                for (int ky = 0; ky < 7; ++ky) {
+                    const float *wp = wl + ((ky * 7 + kx) * 8 + q * 4) * 4;   // same address in every lane: broadcast reads
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) wq[ky][ci] = ld4(wp + ci * 4);
                 }
+                __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from sinking the loads to their uses
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float4 v = hv[r + ky];
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int ci = 0; ci < 4; ++ci) {   // fma chains per output (pack into v_pk_fma_f32 over output pairs)
+                            const float4 w = wq[ky][ci];
+                            acc[r][0] = fmaf(vv[ci], w.x, acc[r][0]);
+                            acc[r][1] = fmaf(vv[ci], w.y, acc[r][1]);
+                            acc[r][2] = fmaf(vv[ci], w.z, acc[r][2]);
+                            acc[r][3] = fmaf(vv[ci], w.w, acc[r][3]);
+                        }
+                    }
+            }
+    }
+    const int ox = x0 + tx;
+    if (ox >= a.W) return;
+    const size_t hw = (size_t)a.H * a.W;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = y0 + tg * 4 + r;
+        if (oy >= a.H) break;
+        const size_t p = (size_t)oy * a.W + ox;
+        const float col[3] = {tanhf(acc[r][0]), tanhf(acc[r][1]), tanhf(acc[r][2])};
+        const float m = 1.f / (1.f + expf(-acc[r][3]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (a.color) a.color[((size_t)n * 3 + c) * hw + p] = col[c];
+            if (a.pred) {
+                const float b = a.bg[((size_t)(a.bg_bs > 1 ? n : 0) * 3 + c) * hw + p];
+                a.pred[((size_t)n * 3 + c) * hw + p] = m * b + (1.f - m) * col[c];
             }
         }
+        if (a.mask) a.mask[(size_t)n * hw + p] = m;
     }
-    const int oy = y0 + ty, ox = x0 + tx;
-    if (oy >= a.H || ox >= a.W) return;
-    const size_t hw = (size_t)a.H * a.W, p = (size_t)oy * a.W + ox;
-    const float col[3] = {tanhf(acc0), tanhf(acc1), tanhf(acc2)};
-    const float m = 1.f / (1.f + expf(-acc3));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (a.color) a.color[((size_t)n * 3 + c) * hw + p] = col[c];
-        if (a.pred) {
-            const float b = a.bg[((size_t)(a.bg_bs > 1 ? n : 0) * 3 + c) * hw + p];
-            a.pred[((size_t)n * 3 + c) * hw + p] = m * b + (1.f - m) * col[c];
-        }
-    }
-    if (a.mask) a.mask[(size_t)n * hw + p] = m;
 }
 
 }  // namespace
@@ -1219,8 +1256,14 @@ int launch_unsplit(float *buf, size_t n, hipStream_t st)
 int launch_heads(const HeadsArgs &a, hipStream_t st)
 {
     if (a.pred && !a.bg) LWG_FAIL(LWG_ERR_INVALID_ARG, "heads: pred requested without a background image");
-    const dim3 grid(ceil_div(a.W, HT_COLS), ceil_div(a.H, HT_ROWS), a.N);
-    heads_kernel<<<grid, 256, 0, st>>>(a);
+    static bool opt_in = false;
+    if (!opt_in) {
+        LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    HEADS_LDS));
+        opt_in = true;
+    }
+    const dim3 grid(ceil_div(a.W, HT), ceil_div(a.H, HT), a.N);
+    heads_kernel<<<grid, 256, HEADS_LDS, st>>>(a);
     LWG_LAUNCH_CHECK("heads_kernel");
     return LWG_OK;
 }
