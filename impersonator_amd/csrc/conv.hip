@@ -4,8 +4,11 @@
 // 68-184): Conv2d 7x7/3x3 (stride 1/2), ConvTranspose2d 3x3 s2, InstanceNorm2d(affine), ReLU, the residual
 // add, the Liquid Warping Block add (generator.py:283-295,303-320), torch.cat and the tanh/sigmoid heads.
 //
-// Layout: activations NHWC fp32 (channel-contiguous => the im2col row of a tap is one contiguous run).
+// Layout: activations NHWC (channel-contiguous => the im2col row of a tap is one contiguous run), fp32 or the
+// split-bf16 format of conv.h.
 //
+// conv_igemm_bf16x3 (default per-frame path): the implicit GEMM with every product evaluated as three bf16 MFMAs on
+//   split operands, DMA-fed; see the comment above the kernel.  direct.hip holds the 7x7 stem of that path.
 // conv_igemm_f32: implicit GEMM on the exact-fp32 matrix cores, v_mfma_f32_32x32x2_f32
 //   (64 FLOP/clk/SIMD, 157.3 TFLOP/s chip peak; results are an fp32 fmaf chain, no reduced precision).
 //   Workgroup tile 128 pixels x BN channels x 32 reduction, 4 waves, each wave a 32*WM x 32*WN block of

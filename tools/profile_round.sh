@@ -8,9 +8,9 @@ mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/$TAG/bench.json 2> $R/gpurun_out/$TAG/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats -o k -- \
-    python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/$TAG/stats.log 2>&1
+    python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode > $R/gpurun_out/$TAG/stats.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
-    -d $R/gpurun_out/$TAG/pmc -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/$TAG/pmc.log 2>&1
+    -d $R/gpurun_out/$TAG/pmc -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32-mode > $R/gpurun_out/$TAG/pmc.log 2>&1
 cd $R
 python tools/summarize_profile.py stats gpurun_out/$TAG/stats/k_kernel_stats.csv gpurun_out/$TAG/${TAG}_kernel_stats.md gpurun_out/$TAG/bench.json
 python tools/summarize_profile.py pmc gpurun_out/$TAG/pmc/p_counter_collection.csv gpurun_out/$TAG/pmc/p_kernel_trace.csv gpurun_out/$TAG/${TAG}_pmc_mfma.md

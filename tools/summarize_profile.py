@@ -18,7 +18,8 @@ def short(name):
 def stats(path, out, bench=None):
     rows = list(csv.DictReader(open(path)))
     with open(out, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline\n\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode\n"
+                "# (__amd_rocclr_copyBuffer rows are the one-time weight uploads of the setup, outside the timed steps)\n\n")
         if bench:
             f.write("bench.py line of the same code (un-profiled run):\n\n```json\n%s\n```\n\n" % open(bench).read().strip())
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
@@ -35,7 +36,7 @@ def pmc(counters, trace, out):
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace))}
     agg = collections.OrderedDict()
     for k, d in disp.items():
-        if "igemm" not in d["name"]:
+        if "igemm" not in d["name"] and "stem_bf16x3" not in d["name"]:
             continue
         a = agg.setdefault((d["name"], d["grid"]), collections.defaultdict(float))
         a["n"] += 1
