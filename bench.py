@@ -47,8 +47,11 @@ IMAGE_SIZE = 256
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--settle-ms", type=float, default=300.0,
+                   help="untimed steps before the warm-up until this much wall time has passed (DVFS: the first ~100 ms "
+                        "after idle run ~15%% slower); 0 disables")
     p.add_argument("--frames", type=int, default=1024, help="length of the synthetic reference sequence")
     p.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     p.add_argument("--no-roofline", action="store_true", help="skip the HIP-event pass over the conv kernel")
@@ -142,6 +145,11 @@ def main():
         tsf_inputs = imitator.transfer_params_by_smpl(smpls[s:e], "smooth", t=s)
         return imitator.forward(tsf_inputs, imitator.tsf_info["T"])
 
+    # clock settle (untimed, before the warm-up): a cold GPU ramps its clocks over the first ~100 ms of load
+    ts = time.perf_counter()
+    while (time.perf_counter() - ts) * 1e3 < args.settle_ms:
+        step(0)
+        torch.cuda.synchronize(dev)
     for i in range(args.warmup):
         step(i)
     sharding.barrier(dev)

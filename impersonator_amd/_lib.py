@@ -56,6 +56,16 @@ _PROTOS = {
     "lwg_inpaint_load_weight": (_i, [_vp, _c.c_char_p, _vp, _c.POINTER(_c.c_int64), _i]),
     "lwg_inpaint_missing_weights": (_i, [_vp]),
     "lwg_inpaint_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lwg_discriminator_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "lwg_discriminator_destroy": (None, [_vp]),
+    "lwg_discriminator_load_weight": (_i, [_vp, _c.c_char_p, _vp, _c.POINTER(_c.c_int64), _i]),
+    "lwg_discriminator_read_weight": (_i, [_vp, _c.c_char_p, _i, _vp, _c.c_size_t]),
+    "lwg_discriminator_num_params": (_i, [_vp, _c.POINTER(_c.c_size_t)]),
+    "lwg_discriminator_output_size": (_i, [_vp, _c.POINTER(_i)]),
+    "lwg_discriminator_forward": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "lwg_discriminator_backward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "lwg_discriminator_buffers": (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
+    "lwg_discriminator_adam_step": (_i, [_vp, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
     "lwg_generator_peek": (_i, [_vp, _i, _vp, _sz, _vp]),
     "lwg_generator_profile": (_i, [_vp, _i]),
     "lwg_generator_profile_variants": (_i, []),

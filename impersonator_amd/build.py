@@ -27,6 +27,7 @@ SOURCES = [
     ("direct.hip", []),
     ("generator.hip", []),
     ("inpaint.hip", []),
+    ("train.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
 

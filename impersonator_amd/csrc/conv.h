@@ -15,6 +15,7 @@ struct ConvPhase {
     int Kpad;          // padded reduction length (multiple of kConvBK)
     long w_off;        // float offset of this phase's [Cout][Kpad] matrix inside the layer's weights
     int oy0, ox0;      // output pixel = (hm*os + oy0, wm*os + ox0)
+    int iy0, ix0;      // general mode only: extra input offset of the phase's first tap (may be negative)
 };
 
 // Split-bf16 format (precision 1).  An fp32 value v is carried as two bf16 terms hi = bf16(v), lo = bf16(v - hi)
@@ -54,6 +55,13 @@ struct ConvArgs {
     int mtiles;                     // N*Hm*Wm / kConvBM
     int nphase;
     int fuse_phases;                // 1: one workgroup per tile walks all phases (balanced transposed conv)
+    // General mode (the training path's layers: PatchGAN 4x4 convs and their data gradients).  Lifts the "Hm*Wm is a
+    // multiple of 128" rule: M = N*Hm*Wm rows are tiled across images with a masked tail, phases may start at a
+    // negative input offset (ph.iy0/ix0), `bias` (per output channel, or null) is added in the epilogue, and
+    // `accumulate` adds into y instead of storing.  Register-staged fp32 kernel only; no fused statistics
+    // (partials must be null), mtiles = ceil(M / 128).
+    int general;
+    const float *bias;
     ConvPhase ph[4];
 };
 

@@ -103,7 +103,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
 
 // DBG is 0 in the product; tools/igemm_bench.hip instantiates ablation variants (timing only, results invalid):
 //   1 no global loads in the loop, 2 no LDS staging stores, 4 no barrier, 8 no fragment re-reads, 16 s_setprio around MFMAs
-template <int BN, int WM, int WN, bool SMALL_CIN, int DBG = 0>
+// GEN = true is the general mode of ConvArgs (rows tiled across images with a masked tail, per-phase input offsets,
+// bias epilogue, no statistics).
+template <int BN, int WM, int WN, bool SMALL_CIN, int DBG = 0, bool GEN = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 {
     constexpr int WAVES_N = BN / (32 * WN);
@@ -124,8 +126,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int hw_m = a.Hm * a.Wm;
-    const int img = m0 / hw_m;         // a tile never straddles two images (hw_m % BM == 0)
+    const int img = GEN ? 0 : m0 / hw_m;   // !GEN: a tile never straddles two images (hw_m % BM == 0)
     const int rem0 = m0 - img * hw_m;
+    const int m_total = a.N * hw_m;
 
     // ---- loader geometry: thread -> (row = tid/8 + 32*j, 16-byte column kq = tid%8)
     // Everything a stage load needs is reduced to: one int offset per row (pixel origin of the filter window),
@@ -137,11 +140,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     unsigned long long amask[4];   // !SMALL_CIN: bit t = tap t is inside the image for this row
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int rem = rem0 + lrow + 32 * j;
+        int rem = rem0 + lrow + 32 * j, im = 0;
+        bool inb = true;
+        if (GEN) {   // row -> (image, pixel); rows past the end of the batch read nothing
+            inb = rem < m_total;
+            rem = inb ? rem : 0;
+            im = rem / hw_m;
+            rem -= im * hw_m;
+        }
         const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
-        hi0[j] = hm * a.stride - a.pad;
-        wi0[j] = wm * a.stride - a.pad;
-        aoff[j] = (hi0[j] * a.W + wi0[j]) * a.ldx + kq * 4;
+        hi0[j] = hm * a.stride - a.pad + (GEN ? ph.iy0 : 0);
+        wi0[j] = wm * a.stride - a.pad + (GEN ? ph.ix0 : 0);
+        aoff[j] = ((im * a.H + hi0[j]) * a.W + wi0[j]) * a.ldx + kq * 4;
+        if (GEN && !inb) hi0[j] = -(1 << 28);   // every tap of this row tests as outside the image
         amask[j] = 0ull;
         if (!SMALL_CIN) {
             for (int t = 0, kh = 0, kw = 0; t < ph.ntaps; ++t) {
@@ -298,7 +309,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     if (kt + 1 < nk) stage_body(kt++, yes{}, no{});
     stage_body(kt, no{}, no{});
 
-    igemm_epilogue<BN, WM, WN>(a, ph, blockIdx.z, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    if constexpr (GEN) {
+        // raw output (+ bias), rows decoded one by one; C/D layout as in igemm_epilogue
+        const int col = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                if (m >= m_total) continue;
+                const int im = m / hw_m, rem = m - im * hw_m;
+                const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
+                const size_t opix = ((size_t)im * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
+                float *yo = a.y + opix * a.ldy + n0 + wave_n * 32 * WN + col;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int co = n0 + wave_n * 32 * WN + j * 32 + col;
+                    yo[j * 32] = acc[i][j][r] + (a.bias ? a.bias[co] : 0.f);
+                }
+            }
+    } else {
+        igemm_epilogue<BN, WM, WN>(a, ph, blockIdx.z, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -763,7 +795,17 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
         if (++slot == NS) slot = 0;
     }
 
-    igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    if (DBG & 32) {   // bench only: keep every MFMA alive without an epilogue
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+        if (keep == 123.456f) a.y[0] = 1.f;
+    }
     __syncthreads();   // scratch aliases the ring: done with it before the next phase's DMA
     }  // phase loop
 }
@@ -1024,8 +1066,10 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
 {
     if (a.Cout % bn != 0 || (bn != 64 && bn != 128))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cout=%d not a multiple of the %d-channel tile", a.Cout, bn);
-    if ((a.Hm * a.Wm) % BM != 0 || a.mtiles * BM != a.N * a.Hm * a.Wm)
+    if (!a.general && ((a.Hm * a.Wm) % BM != 0 || a.mtiles * BM != a.N * a.Hm * a.Wm))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: %dx%d output grid per image is not a multiple of %d pixels", a.Hm, a.Wm, BM);
+    if (a.general && (a.partials || a.fuse_phases || a.precision != 0 || a.mtiles != ceil_div((long)a.N * a.Hm * a.Wm, BM)))
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: general mode is fp32, unfused, without statistics, mtiles = ceil(M/128)");
     if (a.dil < 1) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: dilation must be >= 1");
     if ((1 << a.cin_log2) != a.Cin || a.Cin < 4 || (a.ldx & 3))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d must be a power of two >= 4 with a 16-byte aligned pixel stride", a.Cin);
@@ -1047,6 +1091,32 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         lds_opt_in = true;
     }
     const bool small_cin = a.Cin < BK;
+    if (a.general) {
+        static bool gen_opt_in = false;
+        if (!gen_opt_in) {
+            const int l64 = 2 * (BM + 64) * LDK * (int)sizeof(float), l128 = 2 * (BM + 128) * LDK * (int)sizeof(float);
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2, false, 0, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, l64));
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2, true, 0, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, l64));
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<128, 2, 2, false, 0, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, l128));
+            gen_opt_in = true;
+        }
+        if (small_cin && bn != 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d < %d is only built for the 64-channel tile", a.Cin, BK);
+        for (int p = 0; p < a.nphase; ++p)
+            if (a.ph[p].ntaps > 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 64 taps");
+        if (small_cin) {
+            conv_igemm_f32<64, 1, 2, true, 0, true><<<grid, 256, lds, st>>>(a);
+        } else if (bn == 64) {
+            conv_igemm_f32<64, 1, 2, false, 0, true><<<grid, 256, lds, st>>>(a);
+        } else {
+            conv_igemm_f32<128, 2, 2, false, 0, true><<<grid, 256, lds, st>>>(a);
+        }
+        if (variant) *variant = small_cin ? kIgemmSmallCin : (bn == 64 ? kIgemmReg64 : kIgemmReg128);
+        LWG_LAUNCH_CHECK("conv_igemm_f32 (general)");
+        return LWG_OK;
+    }
     if (a.precision == 1) {
         // bf16x3 on split operands: DMA-fed ring of (BM + bn) 128-byte rows per stage
         if (small_cin || !a.w_split || !a.zeros || (a.ldx & 31) || (a.Cin & 31))
@@ -1193,6 +1263,7 @@ int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
         case 204: launch_k_dbg<3, 4>(a, bn, st); break;   // no barrier
         case 213: launch_k_dbg<3, 13>(a, bn, st); break;  // MFMAs only
         case 240: launch_k_dbg<4, 0>(a, bn, st); break;   // 4-slot ring
+        case 232: launch_k_dbg<3, 32>(a, bn, st); break;  // no epilogue
         case 0: launch_dbg<0>(a, bn, st); break;
         case 1: launch_dbg<1>(a, bn, st); break;
         case 3: launch_dbg<3>(a, bn, st); break;

@@ -1,0 +1,717 @@
+// train.hip -- first slice of the training step: the PatchGAN discriminator update.
+//
+// Replaces, for the discriminator, what PyTorch autograd + cuDNN + torch.optim.Adam execute in the reference's
+// ImpersonatorTrainer._optimize_D (models/impersonator_trainer.py:396-411) on a PatchDiscriminator
+// (networks/discriminator.py:8-57: conv4x4 s2 + LeakyReLU, n-1 x [conv4x4 s2 + InstanceNorm + LeakyReLU],
+// conv4x4 s1 + InstanceNorm + LeakyReLU, conv4x4 s1 -> 1 channel) with the LSGAN targets of
+// _compute_loss_D (:413-414):  loss = mean((D(real) - 1)^2) + mean((D(fake) + 1)^2).
+//
+// Real and fake images run as ONE batch of 2N (InstanceNorm has no cross-sample statistics, so this is the same
+// arithmetic as two forward calls).  Forward convs and data gradients run on the fp32 MFMA implicit GEMM of conv.hip in
+// its general mode (a stride-2 conv's data gradient is a 4-phase transposed conv, a stride-1 conv's a conv with the
+// flipped kernel; both read weight matrices derived on the device from the master copy after every optimiser step);
+// the weight gradient is its own MFMA kernel below.  Parameters, gradients and Adam moments live in flat device
+// buffers in the forward-matrix layout [Cout][tap][Cin]; the gradient buffer is what a data-parallel job all-reduces
+// (27.8 MB for the reference's n_layers = 4, ndf = 64), through torch.distributed/RCCL on the Python side.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "conv.h"
+
+namespace lwg {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float kLeaky = 0.2f;
+constexpr float kEps = 1e-5f;
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// ---- InstanceNorm statistics: (mean, 1/sqrt(var + eps)) per (image, channel) of an NHWC tensor, biased variance.
+// grid (C/64, N), 256 threads = 4 pixel slices x 64 channels; double accumulation, fixed reduction order.
+__global__ __launch_bounds__(256) void in_stats_kernel(const float *__restrict__ x, int HW, int C, float2 *__restrict__ out)
+{
+    __shared__ double sh[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6, n = blockIdx.y;
+    const float *p = x + (size_t)n * HW * C + c;
+    double s = 0., q = 0.;
+    for (int i = slice; i < HW; i += 4) {
+        const double v = p[(size_t)i * C];
+        s += v;
+        q += v * v;
+    }
+    sh[0][slice][threadIdx.x & 63] = s;
+    sh[1][slice][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (slice == 0) {
+        const int l = threadIdx.x;
+        s = sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l];
+        q = sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l];
+        const double mean = s / HW, var = fmax(q / HW - mean * mean, 0.);
+        out[(size_t)n * C + c] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)kEps)));
+    }
+}
+
+// ---- activation: y = leaky((x - mean) * rstd) (stats != null) or leaky(x); float4 over channels
+__global__ __launch_bounds__(256) void d_act_kernel(const float *__restrict__ raw, const float2 *__restrict__ stats, int HW,
+                                                    int C, long total4, float *__restrict__ y)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const long e = i * 4;
+    const int c = (int)(e % C);
+    const int n = (int)(e / ((long)HW * C));
+    float4 v = ld4(raw + e);
+    float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (stats) {
+            const float2 s = stats[(size_t)n * C + c + k];
+            f[k] = (f[k] - s.x) * s.y;
+        }
+        f[k] = f[k] > 0.f ? f[k] : kLeaky * f[k];
+    }
+    *reinterpret_cast<float4 *>(y + e) = make_float4(f[0], f[1], f[2], f[3]);
+}
+
+// ---- LSGAN loss and its gradient on the 1-channel patch map (channel 0 of a Cp-channel NHWC tensor).
+// Images [0, N) are real (target +1), [N, 2N) fake (target -1).  One workgroup; fixed-order reduction.
+__global__ __launch_bounds__(256) void lsgan_kernel(const float *__restrict__ out, int N, int HW, int Cp,
+                                                    float *__restrict__ dout, float *__restrict__ loss)
+{
+    __shared__ double sh[256];
+    const int per_half = N * HW;
+    double acc = 0.;
+    for (int i = threadIdx.x; i < 2 * per_half; i += 256) {
+        const float y = i < per_half ? 1.f : -1.f;
+        const float d = out[(size_t)i * Cp] - y;
+        acc += (double)d * d;
+        float *g = dout + (size_t)i * Cp;
+        g[0] = 2.f * d / (float)per_half;
+        for (int c = 1; c < Cp; ++c) g[c] = 0.f;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(sh[0] / per_half);
+}
+
+// ---- backward of [InstanceNorm] + LeakyReLU.  g = dy * leaky'(y);  with norm:
+//      dx = rstd * (g - mean_hw(g) - xhat * mean_hw(g * xhat)),  xhat = (x - mean) * rstd.
+// pass 1: (sum g, sum g*xhat) per (image, channel); grid (C/64, N)
+__global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float *__restrict__ raw, const float *__restrict__ act,
+                                                            const float *__restrict__ dact, const float2 *__restrict__ stats,
+                                                            int HW, int C, float2 *__restrict__ sums)
+{
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, slice = threadIdx.x >> 6, n = blockIdx.y;
+    const size_t base = (size_t)n * HW * C + c;
+    const float2 st = stats[(size_t)n * C + c];
+    double s1 = 0., s2 = 0.;
+    for (int i = slice; i < HW; i += 4) {
+        const size_t o = base + (size_t)i * C;
+        const float g = dact[o] * (act[o] > 0.f ? 1.f : kLeaky);
+        s1 += g;
+        s2 += (double)g * ((raw[o] - st.x) * st.y);
+    }
+    sh[0][slice][cl] = s1;
+    sh[1][slice][cl] = s2;
+    __syncthreads();
+    if (slice == 0) {
+        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        sums[(size_t)n * C + c] = make_float2((float)(s1 / HW), (float)(s2 / HW));
+    }
+}
+// pass 2 (elementwise); stats == null: no norm, dx = g; act == null: no activation either (dx = dy)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ raw, const float *__restrict__ act,
+                                                      const float *__restrict__ dact, const float2 *__restrict__ stats,
+                                                      const float2 *__restrict__ sums, int HW, int C, long total,
+                                                      float *__restrict__ draw)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    float g = dact[e];
+    if (act) g *= act[e] > 0.f ? 1.f : kLeaky;
+    if (stats) {
+        const int c = (int)(e % C);
+        const int n = (int)(e / ((long)HW * C));
+        const float2 st = stats[(size_t)n * C + c], sm = sums[(size_t)n * C + c];
+        g = st.y * (g - sm.x - (raw[e] - st.x) * st.y * sm.y);
+    }
+    draw[e] = g;
+}
+
+// ---- column sums (bias gradient): out[c] = sum over P pixels of x[p][c].  Two deterministic stages.
+constexpr int CS_SLICES = 64;
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float *__restrict__ x, long P, int C, float *__restrict__ part)
+{
+    __shared__ double sh[4][64];
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, sub = threadIdx.x >> 6, slice = blockIdx.y;
+    const long per = (P + CS_SLICES - 1) / CS_SLICES, p0 = slice * per, p1 = p0 + per < P ? p0 + per : P;
+    double s = 0.;
+    for (long p = p0 + sub; p < p1; p += 4) s += x[(size_t)p * C + c];
+    sh[sub][cl] = s;
+    __syncthreads();
+    if (sub == 0) part[(size_t)slice * C + c] = (float)(sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
+}
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restrict__ part, int S, long n, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
+    out[i] = s;
+}
+
+// ---- weight gradient on the fp32 matrix cores:  dW[co][tap][ci] = sum_p dY[p][co] * X[pix(p, tap)][ci].
+// Both operands are "reduction index (pixel) x contiguous channels" in memory -- exactly what v_mfma_f32_32x32x2_f32
+// wants from one ds_read_b32 per lane (A: lane -> channel co, k = pixel pair; B: lane -> channel ci), so the tiles go
+// to LDS as loaded, no transpose.  Workgroup = 64 co x 64 ci of one tap over a slice of the pixels, four waves of
+// 32 x 32; the slices' partial results are summed in a fixed order by reduce_slices_kernel (deterministic).
+constexpr int WG_PX = 32, WG_PITCH = 64 + 4;
+__global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dy, int Cout, const float *__restrict__ x,
+                                                    int Cin, int N, int H, int W, int Ho, int Wo, int stride, int pad,
+                                                    long px_per_slice, float *__restrict__ out /* [slice][Cout][16][Cin] */)
+{
+    __shared__ __attribute__((aligned(16))) float sA[2][WG_PX][WG_PITCH], sB[2][WG_PX][WG_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+    const int tap = blockIdx.z & 15, slice = blockIdx.z >> 4;
+    const int kh = tap >> 2, kw = tap & 3;
+    const long P = (long)N * Ho * Wo;
+    const long p0 = slice * px_per_slice, p1 = p0 + px_per_slice < P ? p0 + px_per_slice : P;
+
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;     // loader: 32 pixel rows x 8 float4, two column halves
+    float4 ra[2], rb[2];
+    auto load = [&](long pc) {
+        const long p = pc + lrow;
+        ra[0] = ra[1] = rb[0] = rb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < p1) {
+            const float *d = dy + (size_t)p * Cout + co0 + lcol;
+            ra[0] = ld4(d);
+            ra[1] = ld4(d + 32);
+            const int n = (int)(p / ((long)Ho * Wo));
+            const int rem = (int)(p - (long)n * Ho * Wo);
+            const int oh = rem / Wo, ow = rem - oh * Wo;
+            const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                const float *s = x + (((size_t)n * H + ih) * W + iw) * Cin + ci0 + lcol;
+                if (ci0 + lcol < Cin) rb[0] = ld4(s);
+                if (ci0 + lcol + 32 < Cin) rb[1] = ld4(s + 32);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        *reinterpret_cast<float4 *>(&sA[buf][lrow][lcol]) = ra[0];
+        *reinterpret_cast<float4 *>(&sA[buf][lrow][lcol + 32]) = ra[1];
+        *reinterpret_cast<float4 *>(&sB[buf][lrow][lcol]) = rb[0];
+        *reinterpret_cast<float4 *>(&sB[buf][lrow][lcol + 32]) = rb[1];
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    int buf = 0;
+    if (p0 < p1) {
+        load(p0);
+        store(0);
+    }
+    __syncthreads();
+    for (long pc = p0; pc < p1; pc += WG_PX) {
+        const bool more = pc + WG_PX < p1;
+        if (more) load(pc + WG_PX);
+#pragma unroll
+        for (int kk = 0; kk < WG_PX / 2; ++kk) {
+            const float av = sA[buf][2 * kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float bv = sB[buf][2 * kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C/D layout: col = lane&31 -> ci, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co
+    const int ci = ci0 + wn * 32 + (lane & 31);
+    if (ci < Cin) {
+        float *o = out + (size_t)slice * Cout * 16 * Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            o[((size_t)co * 16 + tap) * Cin + ci] = acc[r];
+        }
+    }
+}
+
+// ---- data-gradient weight matrices from the master copy W[co][kh*4+kw][ci] (run after every optimiser step).
+// stride 1: one matrix [ci][kh'*4+kw'][co] = W[co][(3-kh')*4 + (3-kw')][ci]
+// stride 2: four phase matrices [ci][th*2+tw][co], phase (py,px): kh = py ? (th ? 0 : 2) : (th ? 1 : 3), same for kw
+__global__ __launch_bounds__(256) void dgrad_weights_kernel(const float *__restrict__ w, int Cout, int Cin, int stride,
+                                                            float *__restrict__ wd)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)Cout * 16 * Cin;
+    if (i >= total) return;
+    if (stride == 1) {
+        const int co = (int)(i % Cout);
+        const int t = (int)((i / Cout) % 16);
+        const int ci = (int)(i / ((long)Cout * 16));
+        const int kh = 3 - (t >> 2), kw = 3 - (t & 3);
+        wd[i] = w[((size_t)co * 16 + kh * 4 + kw) * Cin + ci];
+    } else {
+        const long per_phase = (long)Cin * 4 * Cout;
+        const int phase = (int)(i / per_phase);
+        const long j = i - phase * per_phase;
+        const int co = (int)(j % Cout);
+        const int t = (int)((j / Cout) % 4);
+        const int ci = (int)(j / ((long)Cout * 4));
+        const int py = phase >> 1, px = phase & 1, th = t >> 1, tw = t & 1;
+        const int kh = py ? (th ? 0 : 2) : (th ? 1 : 3);
+        const int kw = px ? (tw ? 0 : 2) : (tw ? 1 : 3);
+        wd[i] = w[((size_t)co * 16 + kh * 4 + kw) * Cin + ci];
+    }
+}
+
+// ---- Adam (torch.optim.Adam, no weight decay, no amsgrad)
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+
+// channel 0 of an NHWC tensor -> dense (N,1,H,W)
+__global__ __launch_bounds__(256) void take_channel0_kernel(const float *__restrict__ x, long P, int C, float *__restrict__ y)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) y[i] = x[(size_t)i * C];
+}
+
+struct DLayer {
+    int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, stride = 2;
+    bool norm = false, act = false;
+    int Hin = 0, Ho = 0;
+    size_t w_off = 0, b_off = 0, w_floats = 0;   // into the flat parameter / gradient / moment buffers
+    float *wd = nullptr;                         // data-gradient matrices (layers 1..)
+    float *raw = nullptr, *actv = nullptr;       // (2N, Ho, Ho, cout_pad): conv + bias; after norm/activation
+    float *draw = nullptr, *dact = nullptr;      // gradients wrt raw / wrt this layer's OUTPUT (dact of the last = d loss)
+    float2 *stats = nullptr, *sums = nullptr;    // [2N][cout_pad]
+    bool got_w = false, got_b = false;
+};
+
+}  // namespace
+}  // namespace lwg
+
+struct lwg_discriminator {
+    int input_nc = 0, ndf = 0, n_layers = 0, is = 0, max_batch = 0;
+    std::vector<lwg::DLayer> L;
+    size_t nparams = 0;
+    float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
+    float *x0 = nullptr;        // packed input (2N, is, is, cin_pad0)
+    float *part = nullptr;      // split-K / column-sum partials
+    size_t part_floats = 0;
+    float *loss = nullptr;      // device scalar
+    long step = 0;
+    bool wd_stale = true;
+};
+
+namespace lwg {
+namespace {
+
+int d_alloc(float **p, size_t floats)
+{
+    LWG_HIP(hipMalloc(reinterpret_cast<void **>(p), floats * sizeof(float)));
+    LWG_HIP(hipMemset(*p, 0, floats * sizeof(float)));
+    return LWG_OK;
+}
+
+ConvArgs base_args(const float *x, int ldx, int N, int H, int Cin, const float *w, float *y, int Cout)
+{
+    ConvArgs a = {};
+    a.x = x; a.ldx = ldx; a.N = N; a.H = H; a.W = H; a.Cin = Cin;
+    while ((1 << a.cin_log2) < Cin) ++a.cin_log2;
+    a.w = w; a.y = y; a.ldy = Cout; a.Cout = Cout;
+    a.dil = 1; a.general = 1;
+    return a;
+}
+
+// forward conv of layer l on `x` (2N images): raw = conv(x) + bias
+int d_conv_forward(lwg_discriminator *d, int l, const float *x, int B, hipStream_t st)
+{
+    const DLayer &L = d->L[l];
+    ConvArgs a = base_args(x, L.cin_pad, B, L.Hin, L.cin_pad, d->params + L.w_off, L.raw, L.cout_pad);
+    a.Hm = a.Wm = a.Ho = a.Wo = L.Ho;
+    a.stride = L.stride; a.pad = 1; a.os = 1;
+    a.bias = d->params + L.b_off;
+    a.nphase = 1;
+    a.ph[0] = ConvPhase{4, 4, 16, 16 * L.cin_pad, 0, 0, 0, 0, 0};
+    a.mtiles = ceil_div((long)B * L.Ho * L.Ho, kConvBM);
+    return launch_conv_igemm(a, L.cout_pad % 128 == 0 ? 128 : 64, st);
+}
+
+// data gradient of layer l: dact[l-1] = conv^T(draw[l])
+int d_conv_dgrad(lwg_discriminator *d, int l, int B, hipStream_t st)
+{
+    const DLayer &L = d->L[l];
+    float *dx = d->L[l - 1].dact;
+    ConvArgs a = base_args(L.draw, L.cout_pad, B, L.Ho, L.cout_pad, L.wd, dx, L.cin_pad);
+    if (L.stride == 1) {
+        a.Hm = a.Wm = a.Ho = a.Wo = L.Hin;
+        a.stride = 1; a.pad = 2; a.os = 1;
+        a.nphase = 1;
+        a.ph[0] = ConvPhase{4, 4, 16, 16 * L.cout_pad, 0, 0, 0, 0, 0};
+    } else {
+        a.Hm = a.Wm = L.Hin / 2; a.Ho = a.Wo = L.Hin;
+        a.stride = 1; a.pad = 0; a.os = 2;
+        a.nphase = 4;
+        for (int p = 0; p < 4; ++p) {
+            const int py = p >> 1, px = p & 1;
+            a.ph[p] = ConvPhase{2, 2, 4, 4 * L.cout_pad, (long)p * L.cin_pad * 4 * L.cout_pad, py, px, py ? 0 : -1, px ? 0 : -1};
+        }
+    }
+    a.mtiles = ceil_div((long)B * a.Hm * a.Wm, kConvBM);
+    return launch_conv_igemm(a, L.cin_pad % 128 == 0 ? 128 : 64, st);
+}
+
+int d_refresh_dgrad_weights(lwg_discriminator *d, hipStream_t st)
+{
+    for (size_t l = 1; l < d->L.size(); ++l) {
+        const DLayer &L = d->L[l];
+        const long total = (long)L.cout_pad * 16 * L.cin_pad;
+        dgrad_weights_kernel<<<ceil_div(total, 256), 256, 0, st>>>(d->params + L.w_off, L.cout_pad, L.cin_pad, L.stride, L.wd);
+        LWG_LAUNCH_CHECK("dgrad_weights_kernel");
+    }
+    d->wd_stale = false;
+    return LWG_OK;
+}
+
+int d_forward(lwg_discriminator *d, const float *x_nchw_a, const float *x_nchw_b, int n_each, hipStream_t st)
+{
+    const int B = x_nchw_b ? 2 * n_each : n_each;
+    const DLayer &L0 = d->L[0];
+    int rc = lwg_pack_nhwc(x_nchw_a, n_each, d->input_nc, d->is, d->is, L0.cin_pad, d->x0, st);
+    if (rc != LWG_OK) return rc;
+    if (x_nchw_b) {
+        rc = lwg_pack_nhwc(x_nchw_b, n_each, d->input_nc, d->is, d->is, L0.cin_pad,
+                           d->x0 + (size_t)n_each * d->is * d->is * L0.cin_pad, st);
+        if (rc != LWG_OK) return rc;
+    }
+    const float *x = d->x0;
+    for (size_t l = 0; l < d->L.size(); ++l) {
+        DLayer &L = d->L[l];
+        if ((rc = d_conv_forward(d, (int)l, x, B, st)) != LWG_OK) return rc;
+        const int HW = L.Ho * L.Ho;
+        if (L.norm) {
+            in_stats_kernel<<<dim3(L.cout_pad / 64, B), 256, 0, st>>>(L.raw, HW, L.cout_pad, L.stats);
+            LWG_LAUNCH_CHECK("in_stats_kernel");
+        }
+        if (L.act) {
+            const long total4 = (long)B * HW * L.cout_pad / 4;
+            d_act_kernel<<<ceil_div(total4, 256), 256, 0, st>>>(L.raw, L.norm ? L.stats : nullptr, HW, L.cout_pad, total4, L.actv);
+            LWG_LAUNCH_CHECK("d_act_kernel");
+            x = L.actv;
+        } else {
+            x = L.raw;
+        }
+    }
+    return LWG_OK;
+}
+
+int d_check(const lwg_discriminator *d, int bs)
+{
+    if (!d) LWG_FAIL(LWG_ERR_INVALID_ARG, "NULL discriminator handle");
+    if (bs <= 0 || bs > d->max_batch) LWG_FAIL(LWG_ERR_STATE, "batch %d outside 1..max_batch=%d", bs, d->max_batch);
+    for (size_t l = 0; l < d->L.size(); ++l)
+        if (!d->L[l].got_w || !d->L[l].got_b) LWG_FAIL(LWG_ERR_STATE, "discriminator layer %zu has no weights yet", l);
+    return LWG_OK;
+}
+
+// "model.<idx>.weight|bias" -> layer; sequence indices of the convs: 0, 2, 5, 8, ... (discriminator.py:29-49)
+int d_find(const lwg_discriminator *d, const char *key, int *layer, bool *is_bias)
+{
+    int idx = -1;
+    char what[16] = {0};
+    if (sscanf(key, "model.%d.%15s", &idx, what) != 2) return -1;
+    *is_bias = strcmp(what, "bias") == 0;
+    if (!*is_bias && strcmp(what, "weight") != 0) return -1;
+    int seq = 0;
+    for (size_t l = 0; l < d->L.size(); ++l) {
+        if (seq == idx) {
+            *layer = (int)l;
+            return 0;
+        }
+        seq += l == 0 ? 2 : 3;
+    }
+    return -1;
+}
+
+}  // namespace
+}  // namespace lwg
+
+using namespace lwg;
+
+extern "C" {
+
+int lwg_discriminator_create(lwg_discriminator **out, int input_nc, int ndf, int n_layers, int image_size, int max_batch)
+{
+    LWG_REQUIRE(out, "discriminator_create: NULL out");
+    LWG_REQUIRE(input_nc >= 1 && input_nc <= 8 && ndf == 64 && n_layers >= 1 && n_layers <= 5 && max_batch >= 1,
+                "discriminator_create: supported: input_nc <= 8, ndf = 64, 1 <= n_layers <= 5");
+    LWG_REQUIRE(image_size >= 32 && (image_size >> n_layers) >= 4 && image_size % (1 << n_layers) == 0,
+                "discriminator_create: image_size %d too small for %d stride-2 layers", image_size, n_layers);
+    lwg_discriminator *d = new lwg_discriminator();
+    d->input_nc = input_nc; d->ndf = ndf; d->n_layers = n_layers; d->is = image_size; d->max_batch = max_batch;
+    // discriminator.py:29-49
+    int H = image_size, cin = input_nc, mult = 1;
+    auto add = [&](int cout, int stride, bool norm, bool act) {
+        DLayer L;
+        L.cin = cin; L.cin_pad = cin < 8 ? 8 : cin; L.cout = cout; L.cout_pad = cout < 64 ? 64 : cout;
+        L.stride = stride; L.norm = norm; L.act = act;
+        L.Hin = H; L.Ho = stride == 2 ? H / 2 : H - 1;
+        d->L.push_back(L);
+        H = L.Ho;
+        cin = cout;
+    };
+    add(ndf, 2, false, true);
+    for (int n = 1; n < n_layers; ++n) {
+        mult = 1 << n; if (mult > 8) mult = 8;
+        add(ndf * mult, 2, true, true);
+    }
+    mult = 1 << n_layers; if (mult > 8) mult = 8;
+    add(ndf * mult, 1, true, true);
+    add(1, 1, false, false);
+    // a layer's input channel padding is the previous layer's output padding
+    for (size_t l = 1; l < d->L.size(); ++l) d->L[l].cin_pad = d->L[l - 1].cout_pad;
+
+    const size_t B = 2 * (size_t)max_batch;
+    size_t off = 0, part = 0;
+    int rc = LWG_OK;
+    for (size_t l = 0; l < d->L.size() && rc == LWG_OK; ++l) {
+        DLayer &L = d->L[l];
+        L.w_floats = (size_t)L.cout_pad * 16 * L.cin_pad;
+        L.w_off = off; off += L.w_floats;
+        L.b_off = off; off += L.cout_pad;
+        const size_t act = B * L.Ho * L.Ho * L.cout_pad;
+        rc = d_alloc(&L.raw, act);
+        if (rc == LWG_OK) rc = d_alloc(&L.draw, act);
+        if (rc == LWG_OK) rc = d_alloc(&L.dact, act);
+        if (rc == LWG_OK && L.act) rc = d_alloc(&L.actv, act);
+        if (rc == LWG_OK && L.norm) {
+            float *p = nullptr;
+            rc = d_alloc(&p, B * L.cout_pad * 2);
+            L.stats = reinterpret_cast<float2 *>(p);
+            if (rc == LWG_OK) rc = d_alloc(&p, B * L.cout_pad * 2);
+            L.sums = reinterpret_cast<float2 *>(p);
+        }
+        if (rc == LWG_OK && l > 0) rc = d_alloc(&L.wd, L.w_floats);
+        const size_t need = 32 * L.w_floats > (size_t)CS_SLICES * L.cout_pad ? 32 * L.w_floats : (size_t)CS_SLICES * L.cout_pad;
+        if (need > part) part = need;
+    }
+    d->nparams = off;
+    // split-K partials: a layer never needs more than 32 slices, and only the small layers get that many
+    size_t part_cap = 0;
+    for (const DLayer &L : d->L) {
+        const long P = (long)B * L.Ho * L.Ho;
+        const long tiles = (long)(L.cout_pad / 64) * ceil_div(L.cin_pad, 64) * 16;
+        long S = ceil_div(512, tiles);
+        if (S > 32) S = 32;
+        if (S > ceil_div(P, WG_PX)) S = ceil_div(P, WG_PX);
+        const size_t need = (size_t)S * L.w_floats > (size_t)CS_SLICES * L.cout_pad ? (size_t)S * L.w_floats : (size_t)CS_SLICES * L.cout_pad;
+        if (need > part_cap) part_cap = need;
+    }
+    (void)part;
+    d->part_floats = part_cap;
+    if (rc == LWG_OK) rc = d_alloc(&d->params, off);
+    if (rc == LWG_OK) rc = d_alloc(&d->grads, off);
+    if (rc == LWG_OK) rc = d_alloc(&d->m, off);
+    if (rc == LWG_OK) rc = d_alloc(&d->v, off);
+    if (rc == LWG_OK) rc = d_alloc(&d->part, part_cap);
+    if (rc == LWG_OK) rc = d_alloc(&d->loss, 4);
+    if (rc == LWG_OK) rc = d_alloc(&d->x0, B * (size_t)image_size * image_size * d->L[0].cin_pad);
+    if (rc != LWG_OK) {
+        lwg_discriminator_destroy(d);
+        return rc;
+    }
+    *out = d;
+    return LWG_OK;
+}
+
+void lwg_discriminator_destroy(lwg_discriminator *d)
+{
+    if (!d) return;
+    for (DLayer &L : d->L) {
+        float *ptrs[] = {L.wd, L.raw, L.actv, L.draw, L.dact, reinterpret_cast<float *>(L.stats), reinterpret_cast<float *>(L.sums)};
+        for (float *p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    float *ptrs[] = {d->params, d->grads, d->m, d->v, d->x0, d->part, d->loss};
+    for (float *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete d;
+}
+
+int lwg_discriminator_num_params(const lwg_discriminator *d, size_t *n_floats)
+{
+    LWG_REQUIRE(d && n_floats, "num_params: NULL argument");
+    *n_floats = d->nparams;
+    return LWG_OK;
+}
+
+int lwg_discriminator_load_weight(lwg_discriminator *d, const char *key, const float *data_host, const int64_t *shape, int ndim)
+{
+    LWG_REQUIRE(d && key && data_host && shape, "discriminator load_weight: NULL argument");
+    int l = 0;
+    bool is_bias = false;
+    if (d_find(d, key, &l, &is_bias) != 0) LWG_FAIL(LWG_ERR_INVALID_ARG, "discriminator: unknown state_dict key '%s'", key);
+    DLayer &L = d->L[l];
+    if (is_bias) {
+        if (ndim != 1 || shape[0] != L.cout) LWG_FAIL(LWG_ERR_INVALID_ARG, "%s: expected shape (%d,)", key, L.cout);
+        LWG_HIP(hipMemcpy(d->params + L.b_off, data_host, L.cout * sizeof(float), hipMemcpyHostToDevice));
+        L.got_b = true;
+    } else {
+        if (ndim != 4 || shape[0] != L.cout || shape[1] != L.cin || shape[2] != 4 || shape[3] != 4)
+            LWG_FAIL(LWG_ERR_INVALID_ARG, "%s: expected shape (%d,%d,4,4)", key, L.cout, L.cin);
+        std::vector<float> h(L.w_floats, 0.f);
+        for (int co = 0; co < L.cout; ++co)
+            for (int ci = 0; ci < L.cin; ++ci)
+                for (int t = 0; t < 16; ++t) h[((size_t)co * 16 + t) * L.cin_pad + ci] = data_host[((size_t)co * L.cin + ci) * 16 + t];
+        LWG_HIP(hipMemcpy(d->params + L.w_off, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.got_w = true;
+    }
+    d->wd_stale = true;
+    return LWG_OK;
+}
+
+int lwg_discriminator_read_weight(lwg_discriminator *d, const char *key, int from_grads, float *data_host, size_t n_floats)
+{
+    LWG_REQUIRE(d && key && data_host, "discriminator read_weight: NULL argument");
+    int l = 0;
+    bool is_bias = false;
+    if (d_find(d, key, &l, &is_bias) != 0) LWG_FAIL(LWG_ERR_INVALID_ARG, "discriminator: unknown state_dict key '%s'", key);
+    const DLayer &L = d->L[l];
+    const float *src = from_grads ? d->grads : d->params;
+    LWG_HIP(hipDeviceSynchronize());
+    if (is_bias) {
+        if (n_floats != (size_t)L.cout) LWG_FAIL(LWG_ERR_INVALID_ARG, "%s: expected %d floats", key, L.cout);
+        LWG_HIP(hipMemcpy(data_host, src + L.b_off, L.cout * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        if (n_floats != (size_t)L.cout * L.cin * 16) LWG_FAIL(LWG_ERR_INVALID_ARG, "%s: expected %d floats", key, L.cout * L.cin * 16);
+        std::vector<float> h(L.w_floats);
+        LWG_HIP(hipMemcpy(h.data(), src + L.w_off, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int co = 0; co < L.cout; ++co)
+            for (int ci = 0; ci < L.cin; ++ci)
+                for (int t = 0; t < 16; ++t) data_host[((size_t)co * L.cin + ci) * 16 + t] = h[((size_t)co * 16 + t) * L.cin_pad + ci];
+    }
+    return LWG_OK;
+}
+
+int lwg_discriminator_output_size(const lwg_discriminator *d, int *h)
+{
+    LWG_REQUIRE(d && h, "output_size: NULL argument");
+    *h = d->L.back().Ho;
+    return LWG_OK;
+}
+
+int lwg_discriminator_forward(lwg_discriminator *d, const float *x_nchw, int bs, float *out, lwg_stream_t stream)
+{
+    int rc = d_check(d, bs);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(x_nchw && out, "discriminator forward: NULL argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if ((rc = d_forward(d, x_nchw, nullptr, bs, st)) != LWG_OK) return rc;
+    const DLayer &L = d->L.back();
+    const long P = (long)bs * L.Ho * L.Ho;
+    take_channel0_kernel<<<ceil_div(P, 256), 256, 0, st>>>(L.raw, P, L.cout_pad, out);
+    LWG_LAUNCH_CHECK("take_channel0_kernel");
+    return LWG_OK;
+}
+
+int lwg_discriminator_backward(lwg_discriminator *d, const float *real_nchw, const float *fake_nchw, int bs, float *loss_device,
+                               lwg_stream_t stream)
+{
+    int rc = d_check(d, bs);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(real_nchw && fake_nchw, "discriminator backward: NULL argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->wd_stale && (rc = d_refresh_dgrad_weights(d, st)) != LWG_OK) return rc;
+    if ((rc = d_forward(d, real_nchw, fake_nchw, bs, st)) != LWG_OK) return rc;
+    const int B = 2 * bs, nl = (int)d->L.size();
+    {
+        DLayer &L = d->L[nl - 1];
+        lsgan_kernel<<<1, 256, 0, st>>>(L.raw, bs, L.Ho * L.Ho, L.cout_pad, L.dact, d->loss);
+        LWG_LAUNCH_CHECK("lsgan_kernel");
+        if (loss_device) LWG_HIP(hipMemcpyAsync(loss_device, d->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    for (int l = nl - 1; l >= 0; --l) {
+        DLayer &L = d->L[l];
+        const int HW = L.Ho * L.Ho;
+        const long total = (long)B * HW * L.cout_pad, P = (long)B * HW;
+        if (L.norm) {
+            in_bwd_reduce_kernel<<<dim3(L.cout_pad / 64, B), 256, 0, st>>>(L.raw, L.actv, L.dact, L.stats, HW, L.cout_pad, L.sums);
+            LWG_LAUNCH_CHECK("in_bwd_reduce_kernel");
+        }
+        act_bwd_kernel<<<ceil_div(total, 256), 256, 0, st>>>(L.raw, L.act ? L.actv : nullptr, L.dact, L.norm ? L.stats : nullptr,
+                                                             L.sums, HW, L.cout_pad, total, L.draw);
+        LWG_LAUNCH_CHECK("act_bwd_kernel");
+        // bias gradient
+        col_sum_partial_kernel<<<dim3(L.cout_pad / 64, CS_SLICES), 256, 0, st>>>(L.draw, P, L.cout_pad, d->part);
+        LWG_LAUNCH_CHECK("col_sum_partial_kernel");
+        reduce_slices_kernel<<<ceil_div(L.cout_pad, 256), 256, 0, st>>>(d->part, CS_SLICES, L.cout_pad, d->grads + L.b_off);
+        LWG_LAUNCH_CHECK("reduce_slices_kernel");
+        // weight gradient
+        const float *xin = l == 0 ? d->x0 : (d->L[l - 1].act ? d->L[l - 1].actv : d->L[l - 1].raw);
+        const long tiles = (long)(L.cout_pad / 64) * ceil_div(L.cin_pad, 64) * 16;
+        long S = ceil_div(512, tiles);
+        if (S > 32) S = 32;
+        if (S > ceil_div(P, WG_PX)) S = ceil_div(P, WG_PX);
+        const long per = ceil_div(ceil_div(P, S), WG_PX) * (long)WG_PX;
+        S = ceil_div(P, per);
+        if ((size_t)S * L.w_floats > d->part_floats) LWG_FAIL(LWG_ERR_STATE, "wgrad: partial buffer too small");
+        float *wout = S == 1 ? d->grads + L.w_off : d->part;
+        const dim3 grid(ceil_div(L.cin_pad, 64), L.cout_pad / 64, (unsigned)(16 * S));
+        wgrad_kernel<<<grid, 256, 0, st>>>(L.draw, L.cout_pad, xin, L.cin_pad, B, L.Hin, L.Hin, L.Ho, L.Ho, L.stride, 1, per, wout);
+        LWG_LAUNCH_CHECK("wgrad_kernel");
+        if (S > 1) {
+            reduce_slices_kernel<<<ceil_div((long)L.w_floats, 256), 256, 0, st>>>(d->part, (int)S, (long)L.w_floats, d->grads + L.w_off);
+            LWG_LAUNCH_CHECK("reduce_slices_kernel");
+        }
+        if (l > 0 && (rc = d_conv_dgrad(d, l, B, st)) != LWG_OK) return rc;
+    }
+    return LWG_OK;
+}
+
+int lwg_discriminator_buffers(lwg_discriminator *d, float **params, float **grads, size_t *n_floats)
+{
+    LWG_REQUIRE(d, "discriminator buffers: NULL handle");
+    if (params) *params = d->params;
+    if (grads) *grads = d->grads;
+    if (n_floats) *n_floats = d->nparams;
+    return LWG_OK;
+}
+
+int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float beta1, float beta2, float eps, lwg_stream_t stream)
+{
+    LWG_REQUIRE(d, "adam_step: NULL handle");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    d->step += 1;
+    const float bc1 = 1.f - powf(beta1, (float)d->step), bc2 = 1.f - powf(beta2, (float)d->step);
+    adam_kernel<<<ceil_div((long)d->nparams, 256), 256, 0, st>>>(d->params, d->grads, d->m, d->v, (long)d->nparams, lr, beta1,
+                                                                 beta2, eps, bc1, sqrtf(bc2));
+    LWG_LAUNCH_CHECK("adam_kernel");
+    return d_refresh_dgrad_weights(d, st);
+}
+
+}  // extern "C"

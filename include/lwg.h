@@ -195,6 +195,35 @@ LWG_API int lwg_inpaint_missing_weights(const lwg_inpaint *g);
 LWG_API int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, float *coarse_x, float *x,
                                 float *comp_imgs, lwg_stream_t stream);
 
+/* ---- training, first slice: the PatchGAN discriminator update ---------------------------------
+ * Replaces PatchDiscriminator.forward (networks/discriminator.py:8-57, norm_type='instance', use_sigmoid=False) and,
+ * for the discriminator, ImpersonatorTrainer._optimize_D + loss.backward() + torch.optim.Adam.step()
+ * (models/impersonator_trainer.py:229-232, 396-414).  state_dict keys: "model.<i>.weight" (Cout,Cin,4,4) and
+ * "model.<i>.bias" (Cout,) with the nn.Sequential indices of the reference (0, 2, 5, 8, ...). */
+typedef struct lwg_discriminator lwg_discriminator;
+LWG_API int lwg_discriminator_create(lwg_discriminator **out, int input_nc, int ndf, int n_layers, int image_size,
+                                     int max_batch);
+LWG_API void lwg_discriminator_destroy(lwg_discriminator *d);
+LWG_API int lwg_discriminator_load_weight(lwg_discriminator *d, const char *key, const float *data_host,
+                                          const int64_t *shape, int ndim);
+/* copies a parameter (from_grads = 0) or its gradient (1) back to the host in PyTorch layout; synchronises */
+LWG_API int lwg_discriminator_read_weight(lwg_discriminator *d, const char *key, int from_grads, float *data_host,
+                                          size_t n_floats);
+LWG_API int lwg_discriminator_num_params(const lwg_discriminator *d, size_t *n_floats);
+LWG_API int lwg_discriminator_output_size(const lwg_discriminator *d, int *h);   /* patch map edge (14 at 256, n_layers 4) */
+/* x (bs,input_nc,is,is) NCHW device -> out (bs,1,h,h) */
+LWG_API int lwg_discriminator_forward(lwg_discriminator *d, const float *x_nchw, int bs, float *out, lwg_stream_t stream);
+/* loss = mean((D(real)-1)^2) + mean((D(fake)+1)^2) and its gradient wrt every parameter, into the handle's flat
+ * gradient buffer (real, fake: (bs,input_nc,is,is) NCHW device; loss_device: optional device float). */
+LWG_API int lwg_discriminator_backward(lwg_discriminator *d, const float *real_nchw, const float *fake_nchw, int bs,
+                                       float *loss_device, lwg_stream_t stream);
+/* The flat device buffers (n_floats each, identical layout): what a data-parallel job all-reduces between backward
+ * and adam_step (torch.distributed / RCCL on the caller's side; padding entries are always zero). */
+LWG_API int lwg_discriminator_buffers(lwg_discriminator *d, float **params, float **grads, size_t *n_floats);
+/* torch.optim.Adam(lr, betas=(beta1, beta2), eps) step on the gradient buffer */
+LWG_API int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float beta1, float beta2, float eps,
+                                        lwg_stream_t stream);
+
 /* Test hook: copies an internal scratch buffer (device to device) after inference/swap/encode_src.
  * which: 0..2 = concat buffers cat[l] (bs, is>>l, is>>l, 2*conv_dim<<l)  [skip half | decoder half],
  *        3 = residual trunk output (bs, is/8, is/8, 8*conv_dim), 4..5 = skipper outputs 0..1,

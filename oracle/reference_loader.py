@@ -87,6 +87,7 @@ def load():
     ns.generator = importlib.import_module("networks.generator")
     ns.networks = importlib.import_module("networks.networks")
     ns.inpaintor = importlib.import_module("networks.inpaintor")
+    ns.discriminator = importlib.import_module("networks.discriminator")
     ns.nmr = importlib.import_module("utils.nmr")
     ns.util = importlib.import_module("utils.util")
     ns.batch_smpl = importlib.import_module("networks.batch_smpl")

@@ -293,3 +293,55 @@ def inpaint_forward(sd, imgs, masks, c_dim=4):
         x = _gated(x, sd, "refine_upsample_net.%d" % i, spec)
     x = torch.clamp(x, -1., 1.)
     return coarse_x, x, x * masks + imgs * (1 - masks)
+
+
+# ------------------------------------------------------------------------------------------------
+# Training, first slice: PatchGAN discriminator update.  CPU restatement with torch autograd.
+
+def discriminator_conv_keys(n_layers):
+    """nn.Sequential indices of the convs of PatchDiscriminator (networks/discriminator.py:29-49)."""
+    idx, keys = 0, []
+    for l in range(n_layers + 2):
+        keys.append(idx)
+        idx += 2 if l == 0 else 3
+    return keys
+
+
+def discriminator_forward(sd, x, n_layers=4):
+    """PatchDiscriminator.forward (networks/discriminator.py:29-57) with norm_type='instance' (affine=False, eps 1e-5),
+    use_sigmoid=False: conv4x4 s2 + LeakyReLU(0.2); (n_layers-1) x [conv4x4 s2, IN, LeakyReLU]; [conv4x4 s1, IN, LeakyReLU];
+    conv4x4 s1 -> 1 channel.  Differentiable wrt the tensors in `sd`."""
+    keys = discriminator_conv_keys(n_layers)
+    for l, k in enumerate(keys):
+        stride = 2 if l < n_layers else 1
+        x = F.conv2d(x, sd["model.%d.weight" % k], sd["model.%d.bias" % k], stride=stride, padding=1)
+        if l == len(keys) - 1:
+            break
+        if l > 0:
+            x = F.instance_norm(x, eps=1e-5)
+        x = F.leaky_relu(x, 0.2)
+    return x
+
+
+def discriminator_loss(sd, real, fake, n_layers=4):
+    """ImpersonatorTrainer._optimize_D / _compute_loss_D (models/impersonator_trainer.py:396-414), lambda_D_prob = 1."""
+    d_real = discriminator_forward(sd, real, n_layers)
+    d_fake = discriminator_forward(sd, fake, n_layers)
+    return torch.mean((d_real - 1) ** 2) + torch.mean((d_fake + 1) ** 2)
+
+
+def discriminator_train_steps(sd, batches, n_layers=4, lr=0.0002, betas=(0.5, 0.999), eps=1e-8):
+    """`len(batches)` updates with torch.optim.Adam (impersonator_trainer.py:231-232, train_options.py:36-38).
+    Returns (losses, gradients of the FIRST step, final parameters)."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=lr, betas=betas, eps=eps)
+    losses, first = [], None
+    for real, fake in batches:
+        opt.zero_grad()
+        loss = discriminator_loss(params, real, fake, n_layers)
+        loss.backward()
+        if first is None:
+            first = {k: v.grad.detach().clone() for k, v in params.items()}
+        opt.step()
+        losses.append(float(loss.detach()))
+    return losses, first, {k: v.detach().clone() for k, v in params.items()}

@@ -49,3 +49,17 @@ def maxdiff(a, b):
     d = (a - b).abs()
     idx = int(d.argmax())
     return float(d.max()), np.unravel_index(idx, tuple(d.shape))
+
+
+def discriminator_state_dict(seed=0, input_nc=6, ndf=64, n_layers=4):
+    """Seeded PatchDiscriminator parameters (conv weights ~ N(0, 0.02) as networks.py:57-58, biases ~ U(-0.1, 0.1))."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd, idx, cin, mult = {}, 0, input_nc, 1
+    chans = [ndf] + [ndf * min(2 ** n, 8) for n in range(1, n_layers)] + [ndf * min(2 ** n_layers, 8), 1]
+    for l, cout in enumerate(chans):
+        sd["model.%d.weight" % idx] = torch.randn(cout, cin, 4, 4, generator=g) * 0.02
+        sd["model.%d.bias" % idx] = torch.rand(cout, generator=g) * 0.2 - 0.1
+        idx += 2 if l == 0 else 3
+        cin = cout
+    return sd

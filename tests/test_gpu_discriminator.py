@@ -1,0 +1,98 @@
+"""GPU parity of the training path's first slice: PatchGAN discriminator forward, LSGAN loss,
+every parameter gradient and two Adam updates through the C ABI against the CPU oracle (torch autograd,
+oracle/torch_ref.py, pinned to the reference's PatchDiscriminator in tests/test_oracle_vs_reference.py).
+fp32 MFMA end to end; tolerances are relative to each tensor's scale."""
+import pytest
+import torch
+
+from oracle import torch_ref
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+
+
+# InstanceNorm cancels the bias of the conv in front of it: those gradients are pure round-off in both implementations
+NORMED_BIAS = {"model.%d.bias" % k for k in torch_ref.discriminator_conv_keys(4)[1:-1]}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from impersonator_amd.networks.discriminator import PatchDiscriminator
+    sd = helpers.discriminator_state_dict(seed=3)
+    D = PatchDiscriminator(6, 64, 4, 'instance', False, image_size=64, max_batch=2)
+    D.load_state_dict(sd)
+    D = D.cuda()
+    gen = torch.Generator().manual_seed(1)
+    batches = [(torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1, torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1)
+               for _ in range(2)]
+    yield dict(sd=sd, D=D, batches=batches)
+    D.release()
+
+
+def test_forward_matches_oracle(ctx):
+    real = ctx["batches"][0][0]
+    out = ctx["D"](real.cuda()).cpu()
+    ref = torch_ref.discriminator_forward(ctx["sd"], real)
+    assert out.shape == ref.shape == (2, 1, 2, 2)
+    assert _rel(out, ref) < 1e-4
+
+
+def test_loss_gradients_and_adam_steps(ctx):
+    D, batches = ctx["D"], ctx["batches"]
+    losses, grads, final = torch_ref.discriminator_train_steps(ctx["sd"], batches)
+    real, fake = batches[0]
+    loss0 = D.optimize_D(real.cuda(), fake.cuda(), all_reduce=False)
+    mine = D.gradients()
+    assert abs(float(loss0) - losses[0]) < 1e-5 * max(1.0, abs(losses[0]))
+    for k, g in grads.items():
+        assert mine[k].shape == g.shape
+        if k in NORMED_BIAS:
+            assert float(g.abs().max()) < 1e-5 and float(mine[k].abs().max()) < 1e-5, k
+            continue
+        assert _rel(mine[k], g) < 2e-3, (k, _rel(mine[k], g))
+    real, fake = batches[1]
+    loss1 = D.optimize_D(real.cuda(), fake.cuda(), all_reduce=False)
+    assert abs(float(loss1) - losses[1]) < 1e-3 * max(1.0, abs(losses[1]))
+    D.pull_parameters()
+    for k, v in final.items():
+        if k in NORMED_BIAS:
+            continue   # Adam normalises round-off gradients to +-lr: not comparable
+        # Adam turns a gradient into +-lr whatever its size, so entries whose gradient is round-off level may legitimately
+        # differ by 2*lr per step; the entries with a significant gradient must move together
+        big = grads[k].abs() > 1e-2 * grads[k].abs().max()
+        diff = (D.state_dict()[k].cpu() - v).abs()
+        assert float(diff[big].max()) < 0.2 * 0.0002, k
+        assert float(diff.max()) < 2.1 * 2 * 0.0002, k
+
+
+def test_deterministic_and_flat_buffers(ctx):
+    from impersonator_amd.networks.discriminator import PatchDiscriminator
+    outs = []
+    for _ in range(2):
+        D = PatchDiscriminator(6, 64, 4, 'instance', False, image_size=64, max_batch=2)
+        D.load_state_dict(ctx["sd"])
+        D = D.cuda()
+        real, fake = ctx["batches"][0]
+        D.optimize_D(real.cuda(), fake.cuda(), all_reduce=False)
+        p, g = D.flat_buffers()
+        outs.append((p.clone(), g.clone()))
+        assert p.numel() == g.numel() and p.is_cuda
+        D.release()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_reference_size_forward(ctx):
+    """The trainer's configuration (impersonator_trainer.py:219-222) at 256x256: 14x14 patch map."""
+    from impersonator_amd.networks.discriminator import PatchDiscriminator
+    D = PatchDiscriminator(6, 64, 4, 'instance', False, image_size=256, max_batch=1)
+    D.load_state_dict(ctx["sd"])
+    D = D.cuda()
+    x = torch.rand(1, 6, 256, 256, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    out = D(x.cuda()).cpu()
+    ref = torch_ref.discriminator_forward(ctx["sd"], x)
+    assert out.shape == ref.shape == (1, 1, 14, 14) and _rel(out, ref) < 1e-4
+    D.release()

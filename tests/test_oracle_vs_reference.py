@@ -101,3 +101,26 @@ def test_inpaintor_restatement_matches_reference(ref):
         b = torch_ref.inpaint_forward(sd, img, mask)
     for x, y in zip(a, b):
         assert torch.allclose(x, y, atol=1e-6)
+
+
+def test_discriminator_restatement_matches_reference(ref):
+    """oracle discriminator forward / LSGAN loss / gradients == the reference's PatchDiscriminator under torch autograd,
+    and the MI355X mirror exposes the same state_dict keys."""
+    from impersonator_amd.networks.discriminator import PatchDiscriminator
+    D = ref.discriminator.PatchDiscriminator(input_nc=6, ndf=64, n_layers=4, norm_type='instance', use_sigmoid=False)
+    mine = [(k, tuple(v.shape)) for k, v in PatchDiscriminator(6, 64, 4, 'instance', False, image_size=64).state_dict().items()]
+    assert mine == [(k, tuple(v.shape)) for k, v in D.state_dict().items()]
+    sd = helpers.discriminator_state_dict(seed=3)
+    D.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(1)
+    real = torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1
+    fake = torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1
+    out = D(real)
+    assert torch.allclose(out, torch_ref.discriminator_forward(sd, real), atol=1e-6, rtol=1e-5)
+    loss = torch.mean((D(real) - 1) ** 2) + torch.mean((D(fake) + 1) ** 2)   # impersonator_trainer.py:404-414
+    D.zero_grad()
+    loss.backward()
+    losses, grads, _ = torch_ref.discriminator_train_steps(sd, [(real, fake)])
+    assert abs(losses[0] - float(loss)) < 1e-6
+    for k, p in D.named_parameters():
+        assert torch.allclose(p.grad, grads[k], atol=1e-7, rtol=1e-4), k
