@@ -12,7 +12,7 @@ import ctypes
 import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, sharding
 from .networks import NetworkBase
 
 
@@ -153,11 +153,8 @@ class PatchDiscriminator(NetworkBase):
         lib = _lib.load()
         loss = torch.empty((), device=real.device, dtype=torch.float32)
         _lib.check(lib.lwg_discriminator_backward(h, _lib.ptr(real), _lib.ptr(fake), bs, _lib.ptr(loss), _lib.stream_ptr()))
-        if all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size()
-            if world > 1:
-                _, g = self.flat_buffers()
-                torch.distributed.all_reduce(g)
-                g.div_(world)
+        if all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            sharding.average_gradients(self.flat_buffers()[1])
         _lib.check(lib.lwg_discriminator_adam_step(h, float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.stream_ptr()))
         return loss

@@ -81,3 +81,13 @@ def gather_in_frame_order(local_items, num_frames, batch, rank, world):
             for t in range(s, e):
                 out[t] = next(it)
     return out
+
+
+def average_gradients(flat_grads):
+    """Data-parallel training: averages a flat gradient tensor over the ranks in place (all-reduce SUM
+    then divide) -- RCCL over xGMI for CUDA tensors, gloo on CPU.  No-op without an initialised multi-rank group.  The
+    reference does this implicitly through nn.DataParallel (models/impersonator_trainer.py:196-214)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grads)
+        flat_grads.div_(dist.get_world_size())
+    return flat_grads

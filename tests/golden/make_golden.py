@@ -171,11 +171,44 @@ def make_frame(ref):
     print("frame_golden: covered px", int(cov.sum()), "preds range", float(preds.min()), float(preds.max()))
 
 
+def make_discriminator(ref):
+    """One discriminator update of the REAL reference code: PatchDiscriminator (networks/discriminator.py) as the
+    trainer builds it (impersonator_trainer.py:219-222), the LSGAN loss of _optimize_D/_compute_loss_D (:396-414),
+    torch autograd and torch.optim.Adam (:231-232), on seeded weights/inputs (tests/helpers.discriminator_state_dict)."""
+    from tests import helpers
+    D = ref.discriminator.PatchDiscriminator(input_nc=6, ndf=64, n_layers=4, norm_type='instance', use_sigmoid=False)
+    sd = helpers.discriminator_state_dict(seed=3)
+    D.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(1)
+    real = torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1
+    fake = torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1
+    opt = torch.optim.Adam(D.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    with torch.no_grad():
+        d_real = D(real).numpy().copy()
+    opt.zero_grad()
+    loss = torch.mean((D(real) - 1) ** 2) + torch.mean((D(fake) + 1) ** 2)
+    loss.backward()
+    out = dict(d_real=d_real, loss=np.array([float(loss.detach())]))
+    for k, p in D.named_parameters():   # first weight gradient in full, the rest as (L1, L2) norms + a strided sample
+        g = p.grad.detach().double()
+        out["gnorm/" + k] = np.array([g.abs().sum().item(), (g * g).sum().sqrt().item()])
+        out["gsample/" + k] = p.grad.detach().flatten()[::97].numpy().copy()
+    opt.step()
+    for k, p in D.named_parameters():
+        out["psample/" + k] = p.detach().flatten()[::97].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "discriminator_golden.npz"), **out)
+    print("discriminator_golden: loss", float(loss.detach()))
+
+
 if __name__ == "__main__":
     ref = reference_loader.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "discriminator":   # add this fixture without regenerating the others
+        make_discriminator(ref)
+        sys.exit(0)
     make_teapot(ref)
     make_look_at()
     make_frame(ref)
+    make_discriminator(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -69,6 +69,29 @@ def test_loss_gradients_and_adam_steps(ctx):
         assert float(diff.max()) < 2.1 * 2 * 0.0002, k
 
 
+def test_matches_reference_golden(ctx):
+    """Against numbers produced by the real reference code (tests/golden/make_golden.py::make_discriminator)."""
+    from impersonator_amd.networks.discriminator import PatchDiscriminator
+    import numpy as np
+    g = helpers.golden("discriminator_golden.npz")
+    D = PatchDiscriminator(6, 64, 4, 'instance', False, image_size=64, max_batch=2)
+    D.load_state_dict(ctx["sd"])
+    D = D.cuda()
+    real, fake = ctx["batches"][0]
+    assert np.allclose(D(real.cuda()).cpu().numpy(), g["d_real"], atol=1e-5, rtol=1e-4)
+    loss = D.optimize_D(real.cuda(), fake.cuda(), all_reduce=False)
+    assert abs(float(loss) - float(g["loss"][0])) < 1e-5 * float(g["loss"][0])
+    grads = D.gradients()
+    for k, v in grads.items():
+        if k in NORMED_BIAS:
+            continue
+        ref = g["gnorm/" + k]
+        assert abs(v.double().abs().sum().item() - ref[0]) <= 2e-3 * ref[0], k
+        s = g["gsample/" + k]
+        assert float(np.abs(v.flatten()[::97].numpy() - s).max()) <= 2e-3 * float(np.abs(s).max()), k
+    D.release()
+
+
 def test_deterministic_and_flat_buffers(ctx):
     from impersonator_amd.networks.discriminator import PatchDiscriminator
     outs = []
