@@ -30,25 +30,28 @@ constexpr float kEps = 1e-5f;
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // ---- InstanceNorm statistics: (mean, 1/sqrt(var + eps)) per (image, channel) of an NHWC tensor, biased variance.
-// grid (C/64, N), 256 threads = 4 pixel slices x 64 channels; double accumulation, fixed reduction order.
+// grid (C/16, N), 256 threads = 16 pixel slices x 16 channels (64-byte rows); double accumulation, fixed reduction order.
+constexpr int RS_CH = 16, RS_SL = 16;
 __global__ __launch_bounds__(256) void in_stats_kernel(const float *__restrict__ x, int HW, int C, float2 *__restrict__ out)
 {
-    __shared__ double sh[2][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6, n = blockIdx.y;
+    __shared__ double sh[2][RS_SL][RS_CH];
+    const int cl = threadIdx.x & (RS_CH - 1), c = blockIdx.x * RS_CH + cl, slice = threadIdx.x / RS_CH, n = blockIdx.y;
     const float *p = x + (size_t)n * HW * C + c;
     double s = 0., q = 0.;
-    for (int i = slice; i < HW; i += 4) {
+    for (int i = slice; i < HW; i += RS_SL) {
         const double v = p[(size_t)i * C];
         s += v;
         q += v * v;
     }
-    sh[0][slice][threadIdx.x & 63] = s;
-    sh[1][slice][threadIdx.x & 63] = q;
+    sh[0][slice][cl] = s;
+    sh[1][slice][cl] = q;
     __syncthreads();
     if (slice == 0) {
-        const int l = threadIdx.x;
-        s = sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l];
-        q = sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l];
+        s = q = 0.;
+        for (int k = 0; k < RS_SL; ++k) {
+            s += sh[0][k][cl];
+            q += sh[1][k][cl];
+        }
         const double mean = s / HW, var = fmax(q / HW - mean * mean, 0.);
         out[(size_t)n * C + c] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)kEps)));
     }
@@ -103,17 +106,17 @@ __global__ __launch_bounds__(256) void lsgan_kernel(const float *__restrict__ ou
 
 // ---- backward of [InstanceNorm] + LeakyReLU.  g = dy * leaky'(y);  with norm:
 //      dx = rstd * (g - mean_hw(g) - xhat * mean_hw(g * xhat)),  xhat = (x - mean) * rstd.
-// pass 1: (sum g, sum g*xhat) per (image, channel); grid (C/64, N)
+// pass 1: (sum g, sum g*xhat) per (image, channel); grid (C/16, N), 16 pixel slices x 16 channels
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float *__restrict__ raw, const float *__restrict__ act,
                                                             const float *__restrict__ dact, const float2 *__restrict__ stats,
                                                             int HW, int C, float2 *__restrict__ sums)
 {
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, slice = threadIdx.x >> 6, n = blockIdx.y;
+    __shared__ double sh[2][RS_SL][RS_CH];
+    const int cl = threadIdx.x & (RS_CH - 1), c = blockIdx.x * RS_CH + cl, slice = threadIdx.x / RS_CH, n = blockIdx.y;
     const size_t base = (size_t)n * HW * C + c;
     const float2 st = stats[(size_t)n * C + c];
     double s1 = 0., s2 = 0.;
-    for (int i = slice; i < HW; i += 4) {
+    for (int i = slice; i < HW; i += RS_SL) {
         const size_t o = base + (size_t)i * C;
         const float g = dact[o] * (act[o] > 0.f ? 1.f : kLeaky);
         s1 += g;
@@ -123,8 +126,11 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float *__restr
     sh[1][slice][cl] = s2;
     __syncthreads();
     if (slice == 0) {
-        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        s1 = s2 = 0.;
+        for (int k = 0; k < RS_SL; ++k) {
+            s1 += sh[0][k][cl];
+            s2 += sh[1][k][cl];
+        }
         sums[(size_t)n * C + c] = make_float2((float)(s1 / HW), (float)(s2 / HW));
     }
 }
@@ -415,7 +421,7 @@ int d_forward(lwg_discriminator *d, const float *x_nchw_a, const float *x_nchw_b
         if ((rc = d_conv_forward(d, (int)l, x, B, st)) != LWG_OK) return rc;
         const int HW = L.Ho * L.Ho;
         if (L.norm) {
-            in_stats_kernel<<<dim3(L.cout_pad / 64, B), 256, 0, st>>>(L.raw, HW, L.cout_pad, L.stats);
+            in_stats_kernel<<<dim3(L.cout_pad / RS_CH, B), 256, 0, st>>>(L.raw, HW, L.cout_pad, L.stats);
             LWG_LAUNCH_CHECK("in_stats_kernel");
         }
         if (L.act) {
@@ -660,7 +666,7 @@ int lwg_discriminator_backward(lwg_discriminator *d, const float *real_nchw, con
         const int HW = L.Ho * L.Ho;
         const long total = (long)B * HW * L.cout_pad, P = (long)B * HW;
         if (L.norm) {
-            in_bwd_reduce_kernel<<<dim3(L.cout_pad / 64, B), 256, 0, st>>>(L.raw, L.actv, L.dact, L.stats, HW, L.cout_pad, L.sums);
+            in_bwd_reduce_kernel<<<dim3(L.cout_pad / RS_CH, B), 256, 0, st>>>(L.raw, L.actv, L.dact, L.stats, HW, L.cout_pad, L.sums);
             LWG_LAUNCH_CHECK("in_bwd_reduce_kernel");
         }
         act_bwd_kernel<<<ceil_div(total, 256), 256, 0, st>>>(L.raw, L.act ? L.actv : nullptr, L.dact, L.norm ? L.stats : nullptr,
