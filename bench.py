@@ -145,18 +145,30 @@ def main():
         tsf_inputs = imitator.transfer_params_by_smpl(smpls[s:e], "smooth", t=s)
         return imitator.forward(tsf_inputs, imitator.tsf_info["T"])
 
+    def run_steps(first, n):
+        """n steps through Imitator.predict_batches (what Imitator.inference runs): the geometry of step i+1 is
+        enqueued on a second stream while the generator of step i runs; every step's work is inside the loop."""
+        out = None
+        chunks = ((smpls[s:e], s) for s, e in (blocks[(first + i) % len(blocks)] for i in range(n)))
+        for _, out in imitator.predict_batches(chunks, "smooth"):
+            pass
+        return out
+
     # clock settle (untimed, before the warm-up): a cold GPU ramps its clocks over the first ~100 ms of load
     ts = time.perf_counter()
     while (time.perf_counter() - ts) * 1e3 < args.settle_ms:
         step(0)
         torch.cuda.synchronize(dev)
-    for i in range(args.warmup):
-        step(i)
+    run_steps(0, args.warmup)
+    sharding.barrier(dev)
+    # host cost of enqueueing a step, measured on a short burst into empty queues (over hundreds of steps the host
+    # simply blocks on the full launch queue, which says nothing)
+    th = time.perf_counter()
+    run_steps(0, 4)
+    host_dt = (time.perf_counter() - th) / 4 * args.steps
     sharding.barrier(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-    host_dt = time.perf_counter() - t0       # all K steps enqueued (the stream may still be running)
+    out = run_steps(args.warmup, args.steps)
     sharding.barrier(dev)
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else "cpu")
     assert bool(torch.isfinite(out).all())
@@ -165,8 +177,7 @@ def main():
     if not args.no_roofline:
         # same steps again with HIP events around every launch of the implicit-GEMM kernel (on its launch stream)
         imitator.generator.profile(True)
-        for i in range(args.steps):
-            step(args.warmup + i)
+        run_steps(args.warmup, args.steps)
         n, ms, flops = imitator.generator.profile_read()
         table = imitator.generator.profile_table()
         imitator.generator.profile(False)
@@ -194,12 +205,10 @@ def main():
     if precision != "fp32" and not args.no_fp32_mode:
         # the same steps with the convolutions on the exact-fp32 MFMA path, for the record
         imitator.generator.precision = "fp32"
-        for i in range(args.warmup):
-            step(i)
+        run_steps(0, args.warmup)
         sharding.barrier(dev)
         t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
+        run_steps(args.warmup, args.steps)
         sharding.barrier(dev)
         dt32 = sharding.max_over_ranks(time.perf_counter() - t1, dev if world > 1 else "cpu")
         imitator.generator.precision = precision

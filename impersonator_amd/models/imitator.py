@@ -207,6 +207,46 @@ class Imitator(BaseModel):
         front_mask = self.render.encode_front_fim(self.tsf_info['fim'], transpose=True, front_fn=True)
         return (1 - front_mask) * preds + self.tsf_info['tsf_img'] * front_mask * (1 - mask)
 
+    # ------------------------------------------------------------------ two-stream pipeline over batches
+    @torch.no_grad()
+    def predict_batches(self, batches, cam_strategy='smooth'):
+        """Yields (t, preds) for every (tgt_smpls_chunk, t) of `batches`.  Frames are independent once the source is
+        personalised, so the geometry of batch i+1 (swap_smpl, SMPL, rasteriser, flow, image warp: a dozen small,
+        latency-bound kernels) is enqueued on a second HIP stream while the generator's convolutions of batch i occupy
+        the main one; an event orders each hand-over.  Same results as transfer_params_by_smpl + forward per batch."""
+        main = torch.cuda.current_stream()
+        if getattr(self, '_side_stream', None) is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)          # the personalised source (and the caller's smpl tensors) are main-stream work
+
+        def prepare(item):
+            chunk, t = item
+            with torch.cuda.stream(side):
+                tsf_inputs = self.transfer_params_by_smpl(chunk, cam_strategy, t=t)
+                info = self.tsf_info
+                ready = torch.cuda.Event()
+                ready.record(side)
+            return t, tsf_inputs, info, ready
+
+        it = iter(batches)
+        try:
+            nxt = prepare(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            t, tsf_inputs, info, ready = nxt
+            try:
+                nxt = prepare(next(it))
+            except StopIteration:
+                nxt = None
+            main.wait_event(ready)
+            self.tsf_info = info
+            preds = self.forward(tsf_inputs, info['T'])
+            for v in (tsf_inputs, info['T'], info['fim'], info['tsf_img']):
+                v.record_stream(main)   # allocated under the side stream, consumed here
+            yield t, preds
+
     # ------------------------------------------------------------------ drivers (imitator.py:157-214)
     def _run_batches(self, tgt_smpls, cam_strategy, on_batch):
         smpls = torch.as_tensor(np.asarray(tgt_smpls), dtype=torch.float32).reshape(len(tgt_smpls), -1)
@@ -214,10 +254,8 @@ class Imitator(BaseModel):
         outputs = []
         if cam_strategy == 'smooth' and len(smpls):
             self.first_cam = smpls[0:1, 0:3].clone().cuda()
-        for s in range(0, len(smpls), bs):
-            chunk = smpls[s:s + bs]
-            tsf_inputs = self.transfer_params_by_smpl(chunk, cam_strategy, t=s)
-            preds = self.forward(tsf_inputs, self.tsf_info['T'])
+        smpls = smpls.cuda()
+        for s, preds in self.predict_batches(((smpls[s:s + bs], s) for s in range(0, len(smpls), bs)), cam_strategy):
             host = preds.permute(0, 2, 3, 1).cpu().numpy()   # one device->host copy per batch
             for i in range(host.shape[0]):
                 outputs.append(host[i])
