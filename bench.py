@@ -201,6 +201,19 @@ def main():
                                                            "frac": round(v[2] / (v[1] * 1e-3) / 1e12 / kernel_peak(k), 4)}
                                                        for k, v in table.items()}}}
 
+    if roofline is not None:
+        # bytes per launch of the dominant kernel from the committed PMC passes of the same command (tools/profile_round.sh:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); bench.py cannot
+        # collect counters itself
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath)).get(roofline["kernel"])
+            if t and "fetch_bytes_per_launch" in t and "write_bytes_per_launch" in t:
+                roofline["traffic"] = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
+                roofline["traffic_note"] = ("fabric-side bytes per launch (profiles/r01_traffic.md): %.0f MB read + %.0f MB "
+                                            "written; Infinity-Cache hits included, every XCD's L2 fetches its own copy of "
+                                            "the weights" % (t["fetch_bytes_per_launch"] / 1e6, t["write_bytes_per_launch"] / 1e6))
+
     fp32_mode = None
     if precision != "fp32" and not args.no_fp32_mode:
         # the same steps with the convolutions on the exact-fp32 MFMA path, for the record

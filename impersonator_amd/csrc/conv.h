@@ -60,6 +60,7 @@ struct ConvArgs {
     // negative input offset (ph.iy0/ix0), `bias` (per output channel, or null) is added in the epilogue, and
     // `accumulate` adds into y instead of storing.  Register-staged fp32 kernel only; no fused statistics
     // (partials must be null), mtiles = ceil(M / 128).
+    int natural_order;              // 1: keep the natural tile order (default 0: XCD bands, see conv_igemm_bf16x3)
     int general;
     const float *bias;
     ConvPhase ph[4];

@@ -42,7 +42,8 @@ constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B align
 // Shared epilogue: raw output store + per-tile InstanceNorm statistics.
 template <int BN, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, int phase, f32x16 (&acc)[WM][WN],
-                                               float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0)
+                                               float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0,
+                                               int mtile)
 {
     // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rsel = 4 * (lane >> 5);
@@ -96,7 +97,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                 const float d = p.x - mean;
                 m2 += p.y + 32.f * d * d;
             }
-            a.partials[((size_t)phase * a.mtiles + blockIdx.x) * a.Cout + n0 + tid] = make_float2(mean, m2);
+            a.partials[((size_t)phase * a.mtiles + mtile) * a.Cout + n0 + tid] = make_float2(mean, m2);
         }
     }
 }
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
                 }
             }
     } else {
-        igemm_epilogue<BN, WM, WN>(a, ph, blockIdx.z, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+        igemm_epilogue<BN, WM, WN>(a, ph, blockIdx.z, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, blockIdx.x);
     }
 }
 
@@ -549,7 +550,7 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
         stage_body(kt, slot, no{});
         if (++slot == NS) slot = 0;
     }
-    igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, blockIdx.x);
     __syncthreads();   // the statistics scratch aliases the ring: finish reading it before the next phase's DMA
     }  // phase loop
 }
@@ -575,7 +576,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
 //   * the stage barrier sits 3/4 into the MFMA stream; behind it the next stage's first fragments are fetched under
 //     the remaining MFMAs.
 // Measured dead ends (tools/igemm_bench.hip): eight waves splitting the two k-blocks of a stage (two per SIMD, partial
-// tiles added through LDS) 343 vs 409 TFLOP/s; 4-slot ring =; barrier at 1/2 instead of 3/4 =.  rocprofv3: LDS 18% busy,
+// tiles added through LDS) 343 vs 409 TFLOP/s; 4-slot ring =; barrier at 1/2 instead of 3/4 =; re-dealing the tiles so
+// that an XCD (own L2) covers 2 n-tiles x 16 m-tiles instead of 4 x 8 (fabric reads 107 -> ~71 MB per trunk launch) -2%.  rocprofv3: LDS 18% busy,
 // no bank conflicts; the matrix pipe is 49% busy at a power-limited 2.1-2.2 GHz (a pure MFMA loop on random operands
 // reaches 80% of the 2.5 PFLOP/s dense peak on this part, tools/mfma_peak.hip).
 template <int BN, int WM, int WN, int NS = 3, int DBG = 0>
@@ -597,7 +599,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Workgroups go to the 8 XCDs (each with its own 4 MiB L2) round-robin by linear id.  In natural order the three
+    // image rows a 3x3 tile needs belong to tiles on three other XCDs, so every L2 fetches them again: 1.2 GB of
+    // fabric reads for the 268 MB input of the 256x256 skipper.  Re-dealt, XCD k owns the contiguous band of m-tiles
+    // [k, k+1) * gridDim.x / 8 and walks it in order: neighbouring rows meet in one L2.
+    int bx = blockIdx.x;
+    const int by = blockIdx.y;
+    if (!(DBG & 64) && !a.natural_order && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int m0 = bx * BM, n0 = by * BN;
     const int hw_m = a.Hm * a.Wm, img = m0 / hw_m, rem0 = m0 - img * hw_m;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     auto uniform_ptr = [](const void *p) {   // wave-uniform pointer pinned to SGPRs (the "s" asm operand below)
@@ -795,7 +804,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
         if (++slot == NS) slot = 0;
     }
 
-    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0);
+    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
     if (DBG & 32) {   // bench only: keep every MFMA alive without an epilogue
         float keep = 0.f;
 #pragma unroll
@@ -1264,6 +1273,7 @@ int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
         case 213: launch_k_dbg<3, 13>(a, bn, st); break;  // MFMAs only
         case 240: launch_k_dbg<4, 0>(a, bn, st); break;   // 4-slot ring
         case 232: launch_k_dbg<3, 32>(a, bn, st); break;  // no epilogue
+        case 264: launch_k_dbg<3, 64>(a, bn, st); break;  // natural tile order (no XCD bands)
         case 0: launch_dbg<0>(a, bn, st); break;
         case 1: launch_dbg<1>(a, bn, st); break;
         case 3: launch_dbg<3>(a, bn, st); break;

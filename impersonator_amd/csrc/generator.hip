@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
+
 #include "conv.h"
 
 namespace lwg {
@@ -352,6 +354,8 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     a.w = L.w;
     a.w_split = L.w_split;
     a.precision = (g->split && L.w_split) ? 1 : 0;   // the 7x7 stem (Cin 6, fp32 NHWC8 input) stays on the fp32 kernel
+    static const bool natural = getenv("LWG_NATURAL_TILE_ORDER") != nullptr;   // A/B switch for measurements
+    a.natural_order = natural ? 1 : 0;
     a.zeros = g->zeros;
     if (a.precision == 1) {
         a.zeros = zero_tail_of(g, x);
