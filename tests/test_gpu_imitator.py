@@ -115,3 +115,22 @@ def test_smpl_device_kernels_match_tensor_op_formulation():
     # batch-size invariance of the device kernels (bit for bit)
     dv1, _, _ = md(beta[2:3].cuda(), theta[2:3].cuda(), get_skin=True)
     assert torch.equal(dv1, dv[2:3])
+
+
+def test_two_stream_pipeline_equals_the_sequential_path(imi):
+    """Imitator.predict_batches enqueues the geometry of batch i+1 on a second stream under the generator of batch i;
+    every batch must come out bit-identical to transfer_params_by_smpl + forward run one after the other."""
+    imitator = imi[0]
+    smpls = torch.from_numpy(demo.synthetic_smpls(24, seed=3)).cuda()
+    imitator.first_cam = smpls[0:1, 0:3].clone()
+    chunks = [(smpls[s:s + 4], s) for s in range(0, 24, 4)]
+    seq = []
+    for chunk, t in chunks:
+        x = imitator.transfer_params_by_smpl(chunk, "smooth", t=t)
+        seq.append(imitator.forward(x, imitator.tsf_info["T"]).clone())
+    for rep in range(3):   # repeated: a race would not show every time
+        got = [(t, p.clone()) for t, p in imitator.predict_batches(iter(chunks), "smooth")]
+        assert [t for t, _ in got] == [t for _, t in chunks]
+        for (_, p), q in zip(got, seq):
+            assert torch.equal(p, q)
+    assert list(imitator.predict_batches(iter([]), "smooth")) == []
