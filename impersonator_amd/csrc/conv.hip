@@ -40,13 +40,39 @@ constexpr int BK = kConvBK;
 constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B alignment, spreads banks)
 
 // Shared epilogue: raw output store + per-tile InstanceNorm statistics.
-template <int BN, int WM, int WN>
+// WIDE: the raw output goes through LDS (one 32x32 tile per wave at a time, 36-float pitch) so that it leaves as
+// 16-byte stores, 8 per tile, instead of 32 four-byte ones: the epilogue is store-ISSUE bound.  Callers must have a
+// barrier between their last LDS reads and this call; the statistics scratch sits behind the staging area.
+template <int BN, int WM, int WN, bool WIDE = false>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, int phase, f32x16 (&acc)[WM][WN],
                                                float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0,
                                                int mtile)
 {
     // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rsel = 4 * (lane >> 5);
+    if constexpr (WIDE) {
+        constexpr int TP = 36;                                  // staging pitch (floats)
+        float *stage = smem + (tid >> 6) * 32 * TP;              // one 32x32 tile per wave
+        const int rrow = lane >> 3, rcol = (lane & 7) * 4;       // read-back: 8 rows x 8 float4 per instruction
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + rsel) * TP + col] = acc[i][j][r];
+                // same wave wrote and reads: no barrier needed, only the LDS ordering of one wave
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = q * 8 + rrow;
+                    const float4 v = *reinterpret_cast<const float4 *>(stage + row * TP + rcol);
+                    const int rem = rem0 + wave_m * 32 * WM + i * 32 + row;
+                    const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
+                    const size_t opix = ((size_t)img * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
+                    *reinterpret_cast<float4 *>(a.y + opix * a.ldy + n0 + wave_n * 32 * WN + j * 32 + rcol) = v;
+                }
+            }
+        smem += 4 * 32 * TP;   // statistics scratch behind the staging tiles
+    } else {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -59,6 +85,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
 #pragma unroll
             for (int j = 0; j < WN; ++j) yo[j * 32] = acc[i][j][r];
         }
+    }
 
     // ---- epilogue 2: per-tile InstanceNorm statistics (mean, M2) per channel over the tile's 128 pixels.
     // Reduced per 32-row MFMA tile first and combined over the four row tiles in a fixed order, so the numbers do not
@@ -550,8 +577,8 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
         stage_body(kt, slot, no{});
         if (++slot == NS) slot = 0;
     }
-    igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, blockIdx.x);
-    __syncthreads();   // the statistics scratch aliases the ring: finish reading it before the next phase's DMA
+    igemm_epilogue<BN, WM, WN, true>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, blockIdx.x);
+    __syncthreads();   // the staging / statistics scratch aliases the ring: finish reading it before the next phase's DMA
     }  // phase loop
 }
 
@@ -804,7 +831,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
         if (++slot == NS) slot = 0;
     }
 
-    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
+    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN, !(DBG & 128)>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
     if (DBG & 32) {   // bench only: keep every MFMA alive without an epilogue
         float keep = 0.f;
 #pragma unroll
@@ -1274,6 +1301,7 @@ int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
         case 240: launch_k_dbg<4, 0>(a, bn, st); break;   // 4-slot ring
         case 232: launch_k_dbg<3, 32>(a, bn, st); break;  // no epilogue
         case 264: launch_k_dbg<3, 64>(a, bn, st); break;  // natural tile order (no XCD bands)
+        case 328: launch_k_dbg<3, 128>(a, bn, st); break; // 4-byte epilogue stores
         case 0: launch_dbg<0>(a, bn, st); break;
         case 1: launch_dbg<1>(a, bn, st); break;
         case 3: launch_dbg<3>(a, bn, st); break;
