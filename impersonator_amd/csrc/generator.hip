@@ -48,6 +48,7 @@ struct StreamNet {
     Layer dec[kNDown], skip[kNDown];
     float *heads_w = nullptr;  // [49][64][4]
     bool got_img = false, got_att = false;
+    bool has_skip = true;      // false: BGNet (ResNetGenerator): decoders without skip connections, one 3-channel head
 };
 
 }  // namespace
@@ -57,7 +58,8 @@ using namespace lwg;
 
 struct lwg_generator {
     int src_dim, tsf_dim, cd, repeat, is, max_batch;
-    StreamNet src, tsf;
+    StreamNet src, tsf, bg;
+    int bg_dim = 0;                   // 0: BGNet not enabled (lwg_generator_enable_bg)
     int ignored_keys = 0;
 
     // scratch (sized for max_batch)
@@ -181,8 +183,9 @@ void free_layer(Layer &L)
     L.w = L.gamma = L.beta = nullptr;
 }
 
-int build_stream(StreamNet &s, int in_dim, int cd, int repeat, bool with_decoder)
+int build_stream(StreamNet &s, int in_dim, int cd, int repeat, bool with_decoder, bool with_skip = true)
 {
+    s.has_skip = with_skip;
     init_conv(s.enc[0], in_dim, cd, 7, 1, 3);
     for (int i = 1; i <= kNDown; ++i) init_conv(s.enc[i], cd << (i - 1), cd << i, 3, 2, 1);
     const int ct = cd << kNDown;
@@ -197,9 +200,11 @@ int build_stream(StreamNet &s, int in_dim, int cd, int repeat, bool with_decoder
         int cur = ct;
         for (int i = 0; i < kNDown; ++i) {
             init_convT(s.dec[i], cur, cur / 2);
-            init_conv(s.skip[i], cur, cur / 2, 3, 1, 1);
             if ((rc = alloc_layer(s.dec[i])) != LWG_OK) return rc;
-            if ((rc = alloc_layer(s.skip[i])) != LWG_OK) return rc;
+            if (with_skip) {
+                init_conv(s.skip[i], cur, cur / 2, 3, 1, 1);
+                if ((rc = alloc_layer(s.skip[i])) != LWG_OK) return rc;
+            }
             cur /= 2;
         }
         if ((rc = dev_alloc(&s.heads_w, 49 * 64 * 4)) != LWG_OK) return rc;
@@ -305,8 +310,11 @@ int missing_in(const StreamNet &s, bool with_decoder)
     for (auto &L : s.res) need(L);
     if (with_decoder) {
         for (auto &L : s.dec) need(L);
-        for (auto &L : s.skip) need(L);
-        m += !s.got_img + !s.got_att;
+        if (s.has_skip) {
+            for (auto &L : s.skip) need(L);
+            m += !s.got_att;
+        }
+        m += !s.got_img;
     }
     return m;
 }
@@ -656,6 +664,7 @@ void lwg_generator_destroy(lwg_generator *g)
     if (!g) return;
     free_stream(g->src);
     free_stream(g->tsf);
+    free_stream(g->bg);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(g->x0);
     fr(g->raw);
@@ -677,8 +686,39 @@ int lwg_generator_load_weight(lwg_generator *g, const char *key, const float *da
     std::string k(key);
     if (k.rfind("module.", 0) == 0) k = k.substr(7);  // DataParallel prefix (models/models.py:163-171)
     if (k.rfind("bg_model.", 0) == 0) {
-        g->ignored_keys++;
-        return LWG_OK;  // BGNet is not on the Imitator.forward path (models/imitator.py:30-34)
+        if (!g->bg_dim) {
+            g->ignored_keys++;
+            return LWG_OK;  // BGNet only runs for --bg_model ORIGINAL (models/imitator.py:30-34): lwg_generator_enable_bg
+        }
+        // ResNetGenerator.model is one nn.Sequential (generator.py:29-58): [conv7, IN, ReLU], n_down x [conv, IN, ReLU],
+        // repeat x ResidualBlock, n_down x [convT, IN, ReLU], conv7, tanh
+        StreamNet &b = g->bg;
+        int idx = -1, sub = -1;
+        char tail[32] = {0};
+        const int res0 = 3 + 3 * kNDown, up0 = res0 + g->repeat, fin = up0 + 3 * kNDown;
+        auto put = [&](Layer &L, bool norm, const char *what) -> int {
+            if (!norm && !strcmp(what, "weight"))
+                return L.transposed ? upload_convT(L, data_host, shape, ndim, key) : upload_conv(L, data_host, shape, ndim, key);
+            if (norm && !strcmp(what, "weight")) return upload_vec(L.gamma, L.cout, &L.got_g, data_host, shape, ndim, key);
+            if (norm && !strcmp(what, "bias")) return upload_vec(L.beta, L.cout, &L.got_b, data_host, shape, ndim, key);
+            LWG_FAIL(LWG_ERR_INVALID_ARG, "load_weight: unknown key '%s'", key);
+        };
+        if (sscanf(k.c_str(), "bg_model.model.%d.main.%d.%31s", &idx, &sub, tail) == 3 && idx >= res0 && idx < up0) {
+            const int i = idx - res0;
+            if (sub == 0 || sub == 1) return put(b.res[2 * i], sub == 1, tail);
+            if (sub == 3 || sub == 4) return put(b.res[2 * i + 1], sub == 4, tail);
+            LWG_FAIL(LWG_ERR_INVALID_ARG, "load_weight: unknown key '%s'", key);
+        }
+        if (sscanf(k.c_str(), "bg_model.model.%d.%31s", &idx, tail) == 2) {
+            if (idx == fin && !strcmp(tail, "weight")) {
+                const int rc = upload_head(b, data_host, shape, ndim, 0, 3, g->cd, key);
+                if (rc == LWG_OK) b.got_img = true;
+                return rc;
+            }
+            if (idx >= 0 && idx < res0) return put(b.enc[idx / 3], idx % 3 == 1, tail);
+            if (idx >= up0 && idx < fin) return put(b.dec[(idx - up0) / 3], (idx - up0) % 3 == 1, tail);
+        }
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "load_weight: unknown key '%s'", key);
     }
     StreamNet *s = nullptr;
     bool is_tsf = false;
@@ -765,6 +805,73 @@ int lwg_generator_encode_src(lwg_generator *g, const float *src_inputs_nchw, flo
         x = o;
     }
     return LWG_OK;
+}
+
+int lwg_generator_enable_bg(lwg_generator *g, int bg_dim)
+{
+    LWG_REQUIRE(g, "enable_bg: NULL handle");
+    LWG_REQUIRE(bg_dim >= 1 && bg_dim <= 8, "enable_bg: bg_dim must be 1..8");
+    if (g->bg_dim) {
+        if (g->bg_dim != bg_dim) LWG_FAIL(LWG_ERR_STATE, "enable_bg: already enabled with bg_dim=%d", g->bg_dim);
+        return LWG_OK;
+    }
+    const int rc = build_stream(g->bg, bg_dim, g->cd, g->repeat, true, false);
+    if (rc == LWG_OK) g->bg_dim = bg_dim;
+    return rc;
+}
+
+// BGNet, ResNetGenerator.forward (generator.py:60-65): bg_inputs (bs, bg_dim, is, is) NCHW -> (bs, 3, is, is), fp32.
+// Runs on the tsf stream's scratch buffers (dense, no skip halves), so it must not overlap an inference call.
+int lwg_generator_bg_forward(lwg_generator *g, const float *bg_inputs_nchw, int bs, float *out_nchw, lwg_stream_t stream)
+{
+    LWG_REQUIRE(g && bg_inputs_nchw && out_nchw, "bg_forward: NULL argument");
+    if (!g->bg_dim) LWG_FAIL(LWG_ERR_STATE, "bg_forward: BGNet not enabled (lwg_generator_enable_bg)");
+    if (bs <= 0 || bs > g->max_batch) LWG_FAIL(LWG_ERR_STATE, "batch %d outside 1..max_batch=%d", bs, g->max_batch);
+    const int miss = missing_in(g->bg, true);
+    if (miss) LWG_FAIL(LWG_ERR_STATE, "%d BGNet weight tensors have not been loaded", miss);
+    hipStream_t st = as_stream(stream);
+    const StreamNet &s = g->bg;
+    const int is = g->is, cd = g->cd;
+    g->split = false;
+    int rc;
+    const float *x = nullptr;
+    if ((rc = pack_input(g, bg_inputs_nchw, 0, bs, g->bg_dim, st, &x)) != LWG_OK) return rc;
+    int ldx = 8;
+    for (int l = 0; l <= kNDown; ++l) {
+        float *dst = l < kNDown ? g->cat[l] : g->trunk[0];
+        const int C = cd << l;
+        if ((rc = run_encoder(g, s, l, x, ldx, bs, dst, C, nullptr, 0, 0, st)) != LWG_OK) return rc;
+        x = dst;
+        ldx = C;
+    }
+    int cur = 0;
+    for (int i = 0; i < g->repeat; ++i) {
+        if ((rc = run_resblock(g, s, i, g->trunk[cur], g->trunk[cur ^ 1], bs, nullptr, 0, 0, st)) != LWG_OK) return rc;
+        cur ^= 1;
+    }
+    const float *d = g->trunk[cur];
+    int dC = cd << kNDown, dH = is >> kNDown;
+    for (int i = 0; i < kNDown; ++i) {
+        const int oC = dC / 2, oH = dH * 2;
+        if ((rc = run_conv(g, s.dec[i], d, dC, bs, dH, dH, g->raw, st)) != LWG_OK) return rc;
+        if (i + 1 < kNDown) {
+            if ((rc = run_apply(g, bs, oH, oH, oC, true, g->sk[i], oC, nullptr, 0, nullptr, 0, 0, st)) != LWG_OK) return rc;
+            d = g->sk[i];
+        }
+        dC = oC;
+        dH = oH;
+    }
+    // final conv7 + tanh on the last convT's raw output (its InstanceNorm + ReLU folded into the halo load)
+    HeadsArgs h = {};
+    h.x = g->raw;
+    h.N = bs;
+    h.H = is;
+    h.W = is;
+    h.scale_shift = g->ss;
+    h.wh = s.heads_w;
+    h.color = out_nchw;
+    g->last_split = false;
+    return launch_heads(h, st);
 }
 
 int lwg_generator_inference(lwg_generator *g, const float *tsf_inputs, int layout, const float *T, int bs,

@@ -45,7 +45,7 @@ class Imitator(BaseModel):
         elif getattr(opt, 'bg_model', 'ORIGINAL') != 'ORIGINAL':
             self.bgnet = self._create_bgnet()
         else:
-            self.bgnet = None  # bg_model == 'ORIGINAL' would run generator.bg_model (BGNet), which this build does not cover
+            self.bgnet = self.generator.bg_model   # imitator.py:33-34: the generator's own BGNet
         self.hmr = (hmr if hmr is not None else self._create_hmr()).cuda()
         if render is None:
             render = SMPLRenderer(image_size=opt.image_size, tex_size=opt.tex_size, has_front=opt.front_warp,
@@ -128,10 +128,11 @@ class Imitator(BaseModel):
         body_mask = 1 - bg_mask
         if bg_img is not None:
             src_info['bg'] = torch.as_tensor(bg_img, dtype=torch.float32).cuda().reshape(1, 3, opt.image_size, opt.image_size)
-        elif self.bgnet is not None:
-            src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)
+        elif getattr(opt, 'bg_model', 'ORIGINAL') != 'ORIGINAL' or self.bgnet is not self.generator.bg_model:
+            src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)          # imitator.py:124-125
         else:
-            raise NotImplementedError("bg_model ORIGINAL (BGNet) is not covered: use the InpaintSANet checkpoint or pass bg_img")
+            # imitator.py:126-132: BGNet on the masked image + mask
+            src_info['bg'] = self.bgnet(torch.cat([img * bg_mask, bg_mask], dim=1))
 
         ft_mask = 1 - util.morph(src_info['cond'][:, -1:, :, :], ks=opt.ft_ks, mode='erode')
         src_inputs = torch.cat([img * ft_mask, src_info['cond']], dim=1)

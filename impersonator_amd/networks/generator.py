@@ -69,7 +69,8 @@ class ResidualBlock(nn.Module):
 
 
 class ResNetGenerator(NetworkBase):
-    """BGNet (generator.py:23-65).  Parameters only: it is not on the Imitator.forward path."""
+    """BGNet (generator.py:23-65): holds the parameters; `forward` runs in liblwg through the ImpersonatorGenerator that
+    owns it (Imitator.personalize uses it when --bg_model ORIGINAL, models/imitator.py:30-34,127-132)."""
 
     def __init__(self, conv_dim=64, c_dim=5, repeat_num=9, k_size=4, n_down=2):
         super().__init__()
@@ -86,6 +87,16 @@ class ResNetGenerator(NetworkBase):
             cur //= 2
         layers += [_ConvParams(cur, 3, 7), nn.Identity()]
         self.model = _seq(*layers)
+        self._owner = None
+
+    def forward(self, x, c=None):
+        """generator.py:60-65 (the domain-label argument `c` is never used on this path)."""
+        if c is not None:
+            raise NotImplementedError("ResNetGenerator.forward with a domain label")
+        owner = self._owner() if self._owner is not None else None
+        if owner is None:
+            raise RuntimeError("this BGNet is not attached to an ImpersonatorGenerator")
+        return owner.infer_bg(x)
 
 
 class ResUnetGenerator(NetworkBase):
@@ -139,7 +150,10 @@ class ImpersonatorGenerator(NetworkBase):
         self.precision = precision or os.environ.get("LWG_PRECISION", "bf16x3")
         if self.precision not in self.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+        self.bg_dim = bg_dim
         self.bg_model = ResNetGenerator(conv_dim=conv_dim, c_dim=bg_dim, repeat_num=repeat_num, k_size=3, n_down=N_DOWN)
+        import weakref
+        self.bg_model._owner = weakref.ref(self)
         self.src_model = ResUnetGenerator(conv_dim=conv_dim, c_dim=src_dim, repeat_num=repeat_num, k_size=3, n_down=N_DOWN)
         self.tsf_model = ResUnetGenerator(conv_dim=conv_dim, c_dim=tsf_dim, repeat_num=repeat_num, k_size=3, n_down=N_DOWN)
         self._handle = None
@@ -160,12 +174,11 @@ class ImpersonatorGenerator(NetworkBase):
                                                 self.repeat_num, self.image_size, self.max_batch))
             self._handle = h
             self._uploaded_version = None
+            _lib.check(lib.lwg_generator_enable_bg(self._handle, self.bg_dim))
         _lib.check(lib.lwg_generator_set_precision(self._handle, self.PRECISIONS[self.precision]))
         ver = self._weights_version()
         if self._uploaded_version != ver:
             for key, val in self.state_dict().items():
-                if key.startswith("bg_model."):
-                    continue
                 arr = val.detach().to("cpu", torch.float32).contiguous()
                 shape = (ctypes.c_int64 * arr.dim())(*arr.shape)
                 _lib.check(lib.lwg_generator_load_weight(self._handle, key.encode(), ctypes.c_void_p(arr.data_ptr()),
@@ -215,6 +228,19 @@ class ImpersonatorGenerator(NetworkBase):
         return x.float().contiguous(), 0
 
     # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def infer_bg(self, bg_inputs):
+        """self.bg_model(bg_inputs) (generator.py:216-218, models/imitator.py:127-132): (bs, bg_dim, H, W) -> (bs, 3, H, W)."""
+        self._need_cuda(bg_inputs)
+        x = bg_inputs.float().contiguous()
+        bs = x.shape[0]
+        if x.shape[1:] != (self.bg_dim, self.image_size, self.image_size):
+            raise ValueError("bg_inputs must be (bs, %d, %d, %d)" % (self.bg_dim, self.image_size, self.image_size))
+        h = self._ensure_handle(bs)
+        out = torch.empty((bs, 3, self.image_size, self.image_size), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().lwg_generator_bg_forward(h, _lib.ptr(x), bs, _lib.ptr(out), _lib.stream_ptr()))
+        return out
+
     @torch.no_grad()
     def encode_src(self, src_inputs):
         """generator.py:213-214 -> (encoder_outs[4], resnet_outs[repeat_num])."""

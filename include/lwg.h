@@ -138,6 +138,13 @@ LWG_API void lwg_generator_destroy(lwg_generator *g);
  * image against the fp32 reference (budget 1e-3), at ~2.2x the speed.  The 7x7 stem and heads are fp32 in both modes. */
 LWG_API int lwg_generator_set_precision(lwg_generator *g, int mode);
 
+/* BGNet = ImpersonatorGenerator.bg_model (ResNetGenerator, networks/generator.py:23-65), used by Imitator.personalize
+ * when --bg_model ORIGINAL (models/imitator.py:30-34, 127-132).  enable_bg allocates its weights (call before feeding
+ * "bg_model.*" keys, which are ignored otherwise); bg_forward: (bs, bg_dim, is, is) NCHW -> (bs, 3, is, is), fp32. */
+LWG_API int lwg_generator_enable_bg(lwg_generator *g, int bg_dim);
+LWG_API int lwg_generator_bg_forward(lwg_generator *g, const float *bg_inputs_nchw, int bs, float *out_nchw,
+                                     lwg_stream_t stream);
+
 /* Feed one state_dict entry (PyTorch layout, HOST memory), e.g.
  * "tsf_model.encoders.0.0.weight" (64,6,7,7), "tsf_model.resnets.2.main.1.bias" (512,),
  * "tsf_model.decoders.0.0.weight" (512,256,3,3), "tsf_model.attetion_reg.0.weight" (1,64,7,7).

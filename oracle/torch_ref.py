@@ -345,3 +345,31 @@ def discriminator_train_steps(sd, batches, n_layers=4, lr=0.0002, betas=(0.5, 0.
         opt.step()
         losses.append(float(loss.detach()))
     return losses, first, {k: v.detach().clone() for k, v in params.items()}
+
+
+def bgnet_forward(sd, x, repeat=6, n_down=3):
+    """ResNetGenerator.forward (networks/generator.py:23-65) as ImpersonatorGenerator builds it (k_size=3, n_down=3):
+    conv7-IN-ReLU, 3 x [conv3 s2-IN-ReLU], `repeat` residual blocks, 3 x [convT3 s2-IN-ReLU], conv7, tanh.
+    `sd` holds the 'bg_model.model.N...' entries of the generator's state_dict."""
+    P = "bg_model.model."
+
+    def cin(x, i, stride, pad, transposed=False):
+        w = sd[P + "%d.weight" % i]
+        x = (F.conv_transpose2d(x, w, stride=stride, padding=pad, output_padding=1) if transposed
+             else F.conv2d(x, w, stride=stride, padding=pad))
+        return F.relu(F.instance_norm(x, weight=sd[P + "%d.weight" % (i + 1)], bias=sd[P + "%d.bias" % (i + 1)], eps=1e-5))
+
+    x = cin(x, 0, 1, 3)
+    for i in range(n_down):
+        x = cin(x, 3 + 3 * i, 2, 1)
+    r0 = 3 + 3 * n_down
+    for i in range(repeat):
+        q = P + "%d.main." % (r0 + i)
+        y = F.conv2d(x, sd[q + "0.weight"], padding=1)
+        y = F.relu(F.instance_norm(y, weight=sd[q + "1.weight"], bias=sd[q + "1.bias"], eps=1e-5))
+        y = F.conv2d(y, sd[q + "3.weight"], padding=1)
+        x = x + F.instance_norm(y, weight=sd[q + "4.weight"], bias=sd[q + "4.bias"], eps=1e-5)
+    u0 = r0 + repeat
+    for i in range(n_down):
+        x = cin(x, u0 + 3 * i, 2, 1, transposed=True)
+    return torch.tanh(F.conv2d(x, sd[P + "%d.weight" % (u0 + 3 * n_down)], padding=3))

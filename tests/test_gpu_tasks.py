@@ -77,3 +77,27 @@ def test_viewer_matches_oracle():
         assert torch.equal(fr["fim"], vw.tsf_info["fim"].cpu())
         err = float((preds.cpu() - ref).abs().max())
         assert err <= 1e-3, (rt, err)
+
+
+def test_bgnet_original_background_model():
+    """--bg_model ORIGINAL: Imitator.personalize takes the background from the generator's own BGNet
+    (models/imitator.py:30-34,126-132; networks/generator.py:23-65)."""
+    import torch
+    from impersonator_amd import demo
+    from oracle import torch_ref
+    imitator, src_smpl, src_img, _ = demo.build_synthetic_imitator(batch_size=2, seed=0, affine="random", image_size=128)
+    assert imitator.bgnet is imitator.generator.bg_model
+    sd = {k: v.detach().cpu() for k, v in imitator.generator.state_dict().items()}
+    x = torch.rand(2, 4, 128, 128, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    out = imitator.generator.bg_model(x.cuda()).cpu()
+    with torch.no_grad():
+        ref = torch_ref.bgnet_forward(sd, x)
+    assert out.shape == ref.shape and float((out - ref).abs().max()) < 1e-3
+    imitator.personalize(src_img, src_smpl=src_smpl)          # no bg_img: BGNet inpaints
+    bg = imitator.src_info['bg'].cpu()
+    si = imitator.src_info
+    bg_mask = torch_ref.morph(si['cond'][:, -1:].cpu(), imitator._opt.bg_ks, "erode")
+    img = torch.from_numpy(src_img)[None]
+    with torch.no_grad():
+        ref_bg = torch_ref.bgnet_forward(sd, torch.cat([img * bg_mask, bg_mask], 1))
+    assert float((bg - ref_bg).abs().max()) < 1e-3

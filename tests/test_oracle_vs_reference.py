@@ -124,3 +124,12 @@ def test_discriminator_restatement_matches_reference(ref):
     assert abs(losses[0] - float(loss)) < 1e-6
     for k, p in D.named_parameters():
         assert torch.allclose(p.grad, grads[k], atol=1e-7, rtol=1e-4), k
+
+
+def test_bgnet_restatement_matches_reference(ref):
+    G = ref.generator.ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6).eval()
+    sd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=2, affine="random"))
+    G.load_state_dict(sd)
+    x = torch.rand(1, 4, 64, 64, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    with torch.no_grad():
+        assert torch.allclose(G.bg_model(x), torch_ref.bgnet_forward(sd, x), atol=1e-5, rtol=1e-5)
