@@ -43,6 +43,9 @@ _PROTOS = {
     "lwg_generator_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
     "lwg_generator_destroy": (None, [_vp]),
     "lwg_generator_set_precision": (_i, [_vp, _i]),
+    "lwg_generator_encode_src_n": (_i, [_vp, _vp, _i, _c.POINTER(_vp), _vp]),
+    "lwg_generator_decode_src": (_i, [_vp, _c.POINTER(_vp), _i, _vp, _vp, _vp]),
+    "lwg_generator_inference_n": (_i, [_vp, _vp, _i, _vp, _i, _c.POINTER(_vp), _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "lwg_generator_enable_bg": (_i, [_vp, _i]),
     "lwg_generator_bg_forward": (_i, [_vp, _vp, _i, _vp, _vp]),
     "lwg_generator_load_weight": (_i, [_vp, _c.c_char_p, _vp, _c.POINTER(_c.c_int64), _i]),

@@ -436,8 +436,9 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
 }
 
 struct Warp {
-    const float *src = nullptr;  // NHWC (1,H,W,C)
+    const float *src = nullptr;  // NHWC (n,H,W,C)
     const float *T = nullptr;    // resized flow (N,H,W,2)
+    int n = 1;                   // 1: one source shared by the batch (inference); N: a source per sample (infer_front)
 };
 
 int run_apply(lwg_generator *g, int N, int H, int W, int C, bool relu, float *dst, int ld_dst, const float *res,
@@ -458,7 +459,7 @@ int run_apply(lwg_generator *g, int N, int H, int W, int C, bool relu, float *ds
     a.nwarp = nwarp;
     for (int k = 0; k < nwarp; ++k) {
         a.warp_src[k] = warps[k].src;
-        a.warp_n[k] = 1;
+        a.warp_n[k] = warps[k].n;
         a.warp_T[k] = warps[k].T;
     }
     a.align_corners = align;
@@ -514,7 +515,7 @@ int check_ready(const lwg_generator *g, int bs)
 // the tsf stream shared by inference (one warp set) and swap (two)
 int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *const T[2],
             const float *const *feats[2], int nsets, int bs, int align, float *color, float *mask, const float *bg,
-            int bg_bs, float *pred, hipStream_t st)
+            int bg_bs, float *pred, hipStream_t st, int feats_bs = 1)
 {
     const StreamNet &s = g->tsf;
     const int is = g->is, cd = g->cd;
@@ -534,6 +535,7 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
         for (int k = 0; k < nsets; ++k) {
             w[k].src = feats[k][l];
             w[k].T = g->tscale[k][l - 1];
+            w[k].n = feats_bs;
         }
         const float *xin = g->cat[l - 1];
         const int ldx = 2 * (cd << (l - 1));
@@ -548,6 +550,7 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
         for (int k = 0; k < nsets; ++k) {
             w[k].src = feats[k][kNDown + 1 + i];
             w[k].T = g->tscale[k][kNDown - 1];
+            w[k].n = feats_bs;
         }
         if ((rc = run_resblock(g, s, i, g->trunk[cur], g->trunk[cur ^ 1], bs, w, nsets, align, st)) != LWG_OK) return rc;
         cur ^= 1;
@@ -614,7 +617,7 @@ int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, int conv
     g->repeat = repeat_num;
     g->is = image_size;
     g->max_batch = max_batch;
-    int rc = build_stream(g->src, src_dim, conv_dim, repeat_num, false);
+    int rc = build_stream(g->src, src_dim, conv_dim, repeat_num, true);   // decoder: infer_front / forward only
     if (rc == LWG_OK) rc = build_stream(g->tsf, tsf_dim, conv_dim, repeat_num, true);
 
     const size_t B = (size_t)max_batch, P = (size_t)image_size * image_size;
@@ -748,11 +751,9 @@ int lwg_generator_load_weight(lwg_generator *g, const char *key, const float *da
     const bool dec = sscanf(k.c_str(), "decoders.%d.%d.%31s", &i, &j, tail) == 3;
     const bool skp = !dec && sscanf(k.c_str(), "skippers.%d.%d.%31s", &i, &j, tail) == 3;
     if ((dec || skp) && i >= 0 && i < kNDown) {
-        if (!is_tsf) { g->ignored_keys++; return LWG_OK; }  // the source stream's decoder is never run (generator.py:136-147)
         return norm_or_conv(dec ? s->dec[i] : s->skip[i], j, tail);
     }
     if (k == "img_reg.0.weight" || k == "attetion_reg.0.weight") {
-        if (!is_tsf) { g->ignored_keys++; return LWG_OK; }
         const bool img = k[0] == 'i';
         const int rc = upload_head(*s, data_host, shape, ndim, img ? 0 : 3, img ? 3 : 1, g->cd, key);
         if (rc == LWG_OK) (img ? s->got_img : s->got_att) = true;
@@ -782,7 +783,13 @@ int lwg_generator_src_feature_shape(const lwg_generator *g, int index, int *C, i
 int lwg_generator_encode_src(lwg_generator *g, const float *src_inputs_nchw, float *const *feats_nhwc,
                              lwg_stream_t stream)
 {
-    int rc = check_ready(g, 1);
+    return lwg_generator_encode_src_n(g, src_inputs_nchw, 1, feats_nhwc, stream);
+}
+
+int lwg_generator_encode_src_n(lwg_generator *g, const float *src_inputs_nchw, int bs, float *const *feats_nhwc,
+                               lwg_stream_t stream)
+{
+    int rc = check_ready(g, bs);
     if (rc != LWG_OK) return rc;
     LWG_REQUIRE(src_inputs_nchw && feats_nhwc, "encode_src: NULL argument");
     for (int i = 0; i < kNDown + 1 + g->repeat; ++i) LWG_REQUIRE(feats_nhwc[i], "encode_src: feats_nhwc[%d] is NULL", i);
@@ -790,21 +797,69 @@ int lwg_generator_encode_src(lwg_generator *g, const float *src_inputs_nchw, flo
     // once per source, and its outputs are fp32 tensors handed to the caller (the LWB gathers read them): always fp32
     g->split = false;
     const float *x0 = nullptr;
-    if ((rc = pack_input(g, src_inputs_nchw, 0, 1, g->src_dim, st, &x0)) != LWG_OK) return rc;
+    if ((rc = pack_input(g, src_inputs_nchw, 0, bs, g->src_dim, st, &x0)) != LWG_OK) return rc;
     const float *x = x0;
     int ldx = 8;
     for (int l = 0; l <= kNDown; ++l) {
         const int C = g->cd << l;
-        if ((rc = run_encoder(g, g->src, l, x, ldx, 1, feats_nhwc[l], C, nullptr, 0, 0, st)) != LWG_OK) return rc;
+        if ((rc = run_encoder(g, g->src, l, x, ldx, bs, feats_nhwc[l], C, nullptr, 0, 0, st)) != LWG_OK) return rc;
         x = feats_nhwc[l];
         ldx = C;
     }
     for (int i = 0; i < g->repeat; ++i) {
         float *o = feats_nhwc[kNDown + 1 + i];
-        if ((rc = run_resblock(g, g->src, i, x, o, 1, nullptr, 0, 0, st)) != LWG_OK) return rc;
+        if ((rc = run_resblock(g, g->src, i, x, o, bs, nullptr, 0, 0, st)) != LWG_OK) return rc;
         x = o;
     }
     return LWG_OK;
+}
+
+// src_model.regress(src_model.decode(x, encoder_outs)) of infer_front (generator.py:238; ResUnetGenerator.decode /
+// regress :163-184) on features produced by encode_src_n: feats[0..2] are the skip operands, feats[last] the trunk output.
+int lwg_generator_decode_src(lwg_generator *g, const float *const *feats_nhwc, int bs, float *color, float *mask,
+                             lwg_stream_t stream)
+{
+    int rc = check_ready(g, bs);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(feats_nhwc && color && mask, "decode_src: NULL argument");
+    const int miss = missing_in(g->src, true);
+    if (miss) LWG_FAIL(LWG_ERR_STATE, "%d source-stream weight tensors (decoder / heads) have not been loaded", miss);
+    hipStream_t st = as_stream(stream);
+    const StreamNet &s = g->src;
+    const int is = g->is, cd = g->cd;
+    g->split = g->last_split = false;
+    // skip operands into the first halves of the concat buffers (torch.cat([skip, d]) by layout)
+    for (int l = 0; l < kNDown; ++l) {
+        LWG_REQUIRE(feats_nhwc[l], "decode_src: feats_nhwc[%d] is NULL", l);
+        const size_t C = (size_t)cd << l, P = (size_t)bs * (is >> l) * (is >> l);
+        LWG_HIP(hipMemcpy2DAsync(g->cat[l], 2 * C * sizeof(float), feats_nhwc[l], C * sizeof(float), C * sizeof(float), P,
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    const float *d = feats_nhwc[kNDown + g->repeat];
+    LWG_REQUIRE(d, "decode_src: the last residual feature is NULL");
+    int dC = cd << kNDown, dH = is >> kNDown;
+    for (int i = 0; i < kNDown; ++i) {
+        const int lvl = kNDown - 1 - i, oC = dC / 2, oH = dH * 2;
+        if ((rc = run_conv(g, s.dec[i], d, dC, bs, dH, dH, g->raw, st)) != LWG_OK) return rc;
+        if ((rc = run_apply(g, bs, oH, oH, oC, true, g->cat[lvl] + oC, 2 * oC, nullptr, 0, nullptr, 0, 0, st)) != LWG_OK) return rc;
+        if ((rc = run_conv(g, s.skip[i], g->cat[lvl], 2 * oC, bs, oH, oH, g->raw, st)) != LWG_OK) return rc;
+        if (i + 1 < kNDown) {
+            if ((rc = run_apply(g, bs, oH, oH, oC, true, g->sk[i], oC, nullptr, 0, nullptr, 0, 0, st)) != LWG_OK) return rc;
+            d = g->sk[i];
+        }
+        dC = oC;
+        dH = oH;
+    }
+    HeadsArgs h = {};
+    h.x = g->raw;
+    h.N = bs;
+    h.H = is;
+    h.W = is;
+    h.scale_shift = g->ss;
+    h.wh = s.heads_w;
+    h.color = color;
+    h.mask = mask;
+    return launch_heads(h, st);
 }
 
 int lwg_generator_enable_bg(lwg_generator *g, int bg_dim)
@@ -886,6 +941,23 @@ int lwg_generator_inference(lwg_generator *g, const float *tsf_inputs, int layou
     const float *const Ts[2] = {T, nullptr};
     const float *const *fs[2] = {feats_nhwc, nullptr};
     return run_tsf(g, tsf_inputs, layout, Ts, fs, 1, bs, align_corners, color, mask, bg, bg_bs, pred, as_stream(stream));
+}
+
+// inference with one source per sample (feats_bs == bs: the tsf half of infer_front, generator.py:216-243) or a shared
+// one (feats_bs == 1: lwg_generator_inference)
+int lwg_generator_inference_n(lwg_generator *g, const float *tsf_inputs, int layout, const float *T, int bs,
+                              const float *const *feats_nhwc, int feats_bs, int align_corners, float *color, float *mask,
+                              const float *bg, int bg_bs, float *pred, lwg_stream_t stream)
+{
+    int rc = check_ready(g, bs);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(tsf_inputs && T && feats_nhwc, "inference: NULL argument");
+    LWG_REQUIRE(feats_bs == 1 || feats_bs == bs, "inference: source features must have batch 1 or %d", bs);
+    LWG_REQUIRE(!pred || (bg && (bg_bs == 1 || bg_bs == bs)), "inference: pred needs bg with batch 1 or %d", bs);
+    for (int i = 0; i < kNDown + 1 + g->repeat; ++i) LWG_REQUIRE(feats_nhwc[i], "inference: feats_nhwc[%d] is NULL", i);
+    const float *const Ts[2] = {T, nullptr};
+    const float *const *fs[2] = {feats_nhwc, nullptr};
+    return run_tsf(g, tsf_inputs, layout, Ts, fs, 1, bs, align_corners, color, mask, bg, bg_bs, pred, as_stream(stream), feats_bs);
 }
 
 int lwg_generator_swap(lwg_generator *g, const float *tsf_inputs, int layout, const float *T12, const float *T21,

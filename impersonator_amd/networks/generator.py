@@ -245,13 +245,12 @@ class ImpersonatorGenerator(NetworkBase):
     def encode_src(self, src_inputs):
         """generator.py:213-214 -> (encoder_outs[4], resnet_outs[repeat_num])."""
         self._need_cuda(src_inputs)
-        if src_inputs.shape[0] != 1:
-            raise ValueError("encode_src runs once per source image (batch 1), as models/imitator.py:136 does")
-        h = self._ensure_handle(1)
+        n = src_inputs.shape[0]
+        h = self._ensure_handle(n)
         x = src_inputs.float().contiguous()
-        feats = [torch.empty((1, c, s, s), device=x.device, dtype=torch.float32).contiguous(
+        feats = [torch.empty((n, c, s, s), device=x.device, dtype=torch.float32).contiguous(
             memory_format=torch.channels_last) for c, s in self._feature_shapes()]
-        _lib.check(_lib.load().lwg_generator_encode_src(h, _lib.ptr(x), _lib.ptr_array(feats), _lib.stream_ptr()))
+        _lib.check(_lib.load().lwg_generator_encode_src_n(h, _lib.ptr(x), n, _lib.ptr_array(feats), _lib.stream_ptr()))
         return feats[:N_DOWN + 1], feats[N_DOWN + 1:]
 
     @torch.no_grad()
@@ -272,9 +271,13 @@ class ImpersonatorGenerator(NetworkBase):
         if bg_img is not None:
             bg = bg_img.float().contiguous()
             pred = torch.empty_like(color)
-        _lib.check(_lib.load().lwg_generator_inference(
-            h, _lib.ptr(x), layout, _lib.ptr(T), bs, _lib.ptr_array(feats), int(self.align_corners), _lib.ptr(color),
-            _lib.ptr(mask), _lib.ptr(bg), 0 if bg is None else bg.shape[0], _lib.ptr(pred), _lib.stream_ptr()))
+        feats_bs = feats[0].shape[0]     # 1: one source for the whole batch (Imitator); bs: a source per sample (infer_front)
+        if feats_bs not in (1, bs) or any(f.shape[0] != feats_bs for f in feats):
+            raise ValueError("source features must all have batch 1 or %d" % bs)
+        _lib.check(_lib.load().lwg_generator_inference_n(
+            h, _lib.ptr(x), layout, _lib.ptr(T), bs, _lib.ptr_array(feats), feats_bs, int(self.align_corners),
+            _lib.ptr(color), _lib.ptr(mask), _lib.ptr(bg), 0 if bg is None else bg.shape[0], _lib.ptr(pred),
+            _lib.stream_ptr()))
         return (color, mask) if bg_img is None else (pred, color, mask)
 
     @torch.no_grad()
@@ -330,13 +333,32 @@ class ImpersonatorGenerator(NetworkBase):
         """generator.py:317-320."""
         return self.stn(x, self.resize_trans(x, T))
 
+    @torch.no_grad()
     def infer_front(self, src_inputs, tsf_inputs, T):
-        raise NotImplementedError("training-time joint src/tsf forward (generator.py:216-243) is outside the "
-                                  "Imitator.forward() inference path this build covers")
+        """generator.py:216-243 -> (src_img, src_mask, tsf_img, tsf_mask): every sample has its own source.  The reference
+        interleaves the two streams level by level; the same arithmetic runs here as source stream (features kept), tsf
+        stream with per-sample Liquid-Warping-Block sources, then the source stream's own decoder and heads.
+        Inference only (no autograd graph)."""
+        self._need_cuda(src_inputs, tsf_inputs, T)
+        if src_inputs.shape[0] != tsf_inputs.shape[0]:
+            raise ValueError("src_inputs and tsf_inputs must have the same batch")
+        enc, res = self.encode_src(src_inputs)
+        tsf_img, tsf_mask = self.inference(enc, res, tsf_inputs, T)
+        n, s = src_inputs.shape[0], self.image_size
+        h = self._ensure_handle(n)
+        src_img = torch.empty((n, 3, s, s), device=tsf_img.device, dtype=torch.float32)
+        src_mask = torch.empty((n, 1, s, s), device=tsf_img.device, dtype=torch.float32)
+        _lib.check(_lib.load().lwg_generator_decode_src(h, _lib.ptr_array(enc + res), n, _lib.ptr(src_img), _lib.ptr(src_mask),
+                                                        _lib.stream_ptr()))
+        return src_img, src_mask, tsf_img, tsf_mask
 
+    @torch.no_grad()
     def forward(self, bg_inputs, src_inputs, tsf_inputs, T):
-        raise NotImplementedError("training-time forward (generator.py:204-211) is outside the Imitator.forward() "
-                                  "inference path; use encode_src() + inference()")
+        """generator.py:204-211 -> (img_bg, src_img, src_mask, tsf_img, tsf_mask), inference only (the trainer's
+        generator pass, models/impersonator_trainer.py:331-333, without an autograd graph)."""
+        img_bg = self.bg_model(bg_inputs)
+        src_img, src_mask, tsf_img, tsf_mask = self.infer_front(src_inputs, tsf_inputs, T)
+        return img_bg, src_img, src_mask, tsf_img, tsf_mask
 
     def peek(self, which, shape):
         """Test hook (lwg_generator_peek): copy of an internal NHWC scratch buffer, shaped `shape`."""

@@ -138,6 +138,18 @@ LWG_API void lwg_generator_destroy(lwg_generator *g);
  * image against the fp32 reference (budget 1e-3), at ~2.2x the speed.  The 7x7 stem and heads are fp32 in both modes. */
 LWG_API int lwg_generator_set_precision(lwg_generator *g, int mode);
 
+/* Batched forms for ImpersonatorGenerator.infer_front / forward (generator.py:204-243: one source per sample, both
+ * streams decoded).  encode_src_n: src_inputs (bs,src_dim,is,is) -> the same feature list with batch bs.
+ * decode_src: src_model.regress(src_model.decode(...)) on those features -> color (bs,3,is,is), mask (bs,1,is,is).
+ * inference_n: lwg_generator_inference with feats_bs in {1, bs} sources. */
+LWG_API int lwg_generator_encode_src_n(lwg_generator *g, const float *src_inputs_nchw, int bs, float *const *feats_nhwc,
+                                       lwg_stream_t stream);
+LWG_API int lwg_generator_decode_src(lwg_generator *g, const float *const *feats_nhwc, int bs, float *color, float *mask,
+                                     lwg_stream_t stream);
+LWG_API int lwg_generator_inference_n(lwg_generator *g, const float *tsf_inputs, int layout, const float *T, int bs,
+                                      const float *const *feats_nhwc, int feats_bs, int align_corners, float *color,
+                                      float *mask, const float *bg, int bg_bs, float *pred, lwg_stream_t stream);
+
 /* BGNet = ImpersonatorGenerator.bg_model (ResNetGenerator, networks/generator.py:23-65), used by Imitator.personalize
  * when --bg_model ORIGINAL (models/imitator.py:30-34, 127-132).  enable_bg allocates its weights (call before feeding
  * "bg_model.*" keys, which are ignored otherwise); bg_forward: (bs, bg_dim, is, is) NCHW -> (bs, 3, is, is), fp32. */

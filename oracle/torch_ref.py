@@ -373,3 +373,16 @@ def bgnet_forward(sd, x, repeat=6, n_down=3):
     for i in range(n_down):
         x = cin(x, u0 + 3 * i, 2, 1, transposed=True)
     return torch.tanh(F.conv2d(x, sd[P + "%d.weight" % (u0 + 3 * n_down)], padding=3))
+
+
+def generator_infer_front(sd, src_inputs, tsf_inputs, T, align_corners=False):
+    """ImpersonatorGenerator.infer_front (networks/generator.py:216-243): one source per sample, both streams decoded."""
+    enc, res = encode_src(sd, src_inputs)
+    tsf_img, tsf_mask = generator_inference(sd, enc, res, tsf_inputs, T, align_corners=align_corners)
+    src_img, src_mask = _regress(_decode(res[-1], enc, sd, "src_model"), sd, "src_model")
+    return src_img, src_mask, tsf_img, tsf_mask
+
+
+def generator_forward(sd, bg_inputs, src_inputs, tsf_inputs, T, align_corners=False):
+    """ImpersonatorGenerator.forward (networks/generator.py:204-211)."""
+    return (bgnet_forward(sd, bg_inputs),) + generator_infer_front(sd, src_inputs, tsf_inputs, T, align_corners)

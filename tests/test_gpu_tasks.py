@@ -101,3 +101,32 @@ def test_bgnet_original_background_model():
     with torch.no_grad():
         ref_bg = torch_ref.bgnet_forward(sd, torch.cat([img * bg_mask, bg_mask], 1))
     assert float((bg - ref_bg).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_generator_forward_and_infer_front(precision):
+    """ImpersonatorGenerator.forward / infer_front (generator.py:204-243): per-sample sources, both streams decoded,
+    BGNet -- the trainer's generator pass (impersonator_trainer.py:331-333), inference only."""
+    import torch
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    from oracle import torch_ref
+    from tests import helpers
+    sd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=2, affine="random"))
+    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, image_size=128, max_batch=2, precision=precision)
+    G.load_state_dict(sd)
+    G = G.cuda()
+    gen = torch.Generator().manual_seed(6)
+    bg = torch.rand(2, 4, 128, 128, generator=gen) * 2 - 1
+    src = torch.rand(2, 6, 128, 128, generator=gen) * 2 - 1
+    tsf = torch.rand(2, 6, 128, 128, generator=gen) * 2 - 1
+    T = torch.rand(2, 128, 128, 2, generator=gen) * 2.4 - 1.2
+    T[0, 40:80, 20:60] = -2
+    outs = G(bg.cuda(), src.cuda(), tsf.cuda(), T.cuda())
+    with torch.no_grad():
+        ref = torch_ref.generator_forward(sd, bg, src, tsf, T)
+    for name, a, b in zip(("img_bg", "src_img", "src_mask", "tsf_img", "tsf_mask"), outs, ref):
+        assert a.shape == b.shape and float((a.cpu() - b).abs().max()) < 1e-3, name
+    # the two samples have different sources: swapping the sources must change the tsf output
+    outs2 = G.infer_front(src.flip(0).cuda(), tsf.cuda(), T.cuda())
+    assert float((outs2[2] - outs[3]).abs().max()) > 1e-3
+    G.release()

@@ -133,3 +133,20 @@ def test_bgnet_restatement_matches_reference(ref):
     x = torch.rand(1, 4, 64, 64, generator=torch.Generator().manual_seed(4)) * 2 - 1
     with torch.no_grad():
         assert torch.allclose(G.bg_model(x), torch_ref.bgnet_forward(sd, x), atol=1e-5, rtol=1e-5)
+
+
+def test_generator_forward_restatement_matches_reference(ref):
+    """The trainer's generator pass (ImpersonatorGenerator.forward / infer_front, generator.py:204-243)."""
+    G = ref.generator.ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6).eval()
+    sd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=2, affine="random"))
+    G.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(6)
+    bg = torch.rand(2, 4, 64, 64, generator=gen) * 2 - 1
+    src = torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1
+    tsf = torch.rand(2, 6, 64, 64, generator=gen) * 2 - 1
+    T = torch.rand(2, 64, 64, 2, generator=gen) * 2.4 - 1.2
+    with torch.no_grad():
+        theirs = G(bg, src, tsf, T)
+        mine = torch_ref.generator_forward(sd, bg, src, tsf, T)
+    for a, b in zip(theirs, mine):
+        assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
