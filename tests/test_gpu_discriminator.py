@@ -141,3 +141,36 @@ def test_gradients_against_float64_autograd_128():
             continue
         assert float((mine[k].double() - g).abs().max()) <= 2e-5 * float(g.abs().max()), k
     D.release()
+
+
+def test_trainer_mirror_forward_and_d_phase():
+    """models/impersonator_trainer.py: generator pass (impersonator_trainer.py:329-348) + discriminator update (:396-411)
+    chained as optimize_parameters does for D; checked against the oracle composed the same way."""
+    import types
+    from impersonator_amd.models.impersonator_trainer import Impersonator
+    opt = types.SimpleNamespace(image_size=128, batch_size=2, map_name='uv_seg', norm_type='instance', repeat_num=6,
+                                lr_D=0.0002, D_adam_b1=0.5, D_adam_b2=0.999, lambda_D_prob=1, is_train=True)
+    model = Impersonator(opt)
+    gsd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=2, affine="random"))
+    dsd = helpers.discriminator_state_dict(seed=3)
+    model._G.load_state_dict(gsd)
+    model._D.load_state_dict(dsd)
+    gen = torch.Generator().manual_seed(8)
+    bg = torch.rand(2, 4, 128, 128, generator=gen) * 2 - 1
+    src = torch.rand(2, 6, 128, 128, generator=gen) * 2 - 1
+    tsf = torch.rand(2, 6, 128, 128, generator=gen) * 2 - 1
+    T = torch.rand(2, 128, 128, 2, generator=gen) * 2.4 - 1.2
+    real = torch.rand(2, 3, 128, 128, generator=gen) * 2 - 1
+    model.set_input(tsf.cuda(), real.cuda(), input_G_bg=bg.cuda(), input_G_src=src.cuda(), T=T.cuda())
+    fake_bg, fake_src, fake_tsf, masks = model.forward()
+    with torch.no_grad():
+        o_bg, o_sc, o_sm, o_tc, o_tm = torch_ref.generator_forward(gsd, bg, src, tsf, T)
+        o_tsf = o_tm * o_bg + (1 - o_tm) * o_tc
+    assert masks.shape == (4, 1, 128, 128) and float((fake_tsf.cpu() - o_tsf).abs().max()) < 1e-3
+    assert float((fake_src.cpu() - (o_sm * o_bg + (1 - o_sm) * o_sc)).abs().max()) < 1e-3
+    loss = model.optimize_D_phase()
+    with torch.no_grad():
+        ref_loss = torch_ref.discriminator_loss(dsd, torch.cat([real, tsf[:, 3:]], 1), torch.cat([o_tsf, tsf[:, 3:]], 1))
+    assert abs(float(loss) - float(ref_loss)) < 2e-3 * max(1.0, float(ref_loss))
+    model._D.pull_parameters()
+    assert float((model._D.state_dict()["model.0.weight"].cpu() - dsd["model.0.weight"]).abs().max()) > 1e-5
