@@ -993,8 +993,10 @@ __global__ __launch_bounds__(256) void unsplit_kernel(float *buf, size_t ngroups
 // broadcasts (scalar loads of the weights, tried first, left the two resident waves per SIMD waiting on s_waitcnt:
 // the SGPR file cannot hold a prefetched (kx, group) block).  The compiler emits v_pk_fma_f32 for the output pairs.
 constexpr int HT = 32, HH = HT + 6;         // tile edge, halo edge
-constexpr int HPITCH = 12;                  // floats per halo pixel: 8 channels + 4 pad
-constexpr int HEADS_W = 49 * 8 * 4;         // weights of one 8-channel chunk: [tap][channel][output]
+constexpr int HCH = 8;                      // channels per chunk.  16 halves the fabric re-reads of the input (634 -> ~320 MB:
+                                            // a 128-B line serves 4 chunk passes) but leaves one workgroup per CU: 301 vs 207 us
+constexpr int HPITCH = HCH + 4;             // floats per halo pixel
+constexpr int HEADS_W = 49 * HCH * 4;       // weights of one chunk: [tap][channel][output]
 constexpr int HEADS_LDS = (HH * HH * HPITCH + HEADS_W) * (int)sizeof(float);
 
 __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
@@ -1013,15 +1015,15 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 #pragma unroll
         for (int o = 0; o < 4; ++o) acc[r][o] = 0.f;
 
-    for (int chunk = 0; chunk < 8; ++chunk) {
+    for (int chunk = 0; chunk < 64 / HCH; ++chunk) {
         __syncthreads();
-        for (int i = tid; i < HH * HH * 2; i += 256) {
-            const int pix = i >> 1, half = i & 1;
+        for (int i = tid; i < HH * HH * (HCH / 4); i += 256) {
+            const int pix = i / (HCH / 4), half = i % (HCH / 4);
             const int hy = pix / HH, hx = pix - hy * HH;
             const int gy = y0 - 3 + hy, gx = x0 - 3 + hx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-                const int c = chunk * 8 + half * 4;
+                const int c = chunk * HCH + half * 4;
                 v = ld4(xin + ((size_t)gy * a.W + gx) * 64 + c);
                 const float4 s01 = ld4(reinterpret_cast<const float *>(ss + c));
                 const float4 s23 = ld4(reinterpret_cast<const float *>(ss + c + 2));
@@ -1033,13 +1035,13 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
             *reinterpret_cast<float4 *>(halo + pix * HPITCH + half * 4) = v;
         }
         float *wl = halo + HH * HH * HPITCH;
-        for (int i = tid; i < 49 * 8; i += 256) {   // (tap, channel) -> 4 outputs
-            const int t = i >> 3, c = i & 7;
-            *reinterpret_cast<float4 *>(wl + i * 4) = ld4(a.wh + ((size_t)t * 64 + chunk * 8 + c) * 4);
+        for (int i = tid; i < 49 * HCH; i += 256) {   // (tap, channel) -> 4 outputs
+            const int t = i / HCH, c = i % HCH;
+            *reinterpret_cast<float4 *>(wl + i * 4) = ld4(a.wh + ((size_t)t * 64 + chunk * HCH + c) * 4);
         }
         __syncthreads();
         for (int kx = 0; kx < 7; ++kx)
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < HCH / 4; ++q) {
                 // all LDS reads of the block up front (10 activation rows + 28 weight quads, ~150 VGPRs): one
                 // latency per 448 FMAs instead of one per 16
                 float4 hv[10], wq[7][4];
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
                 for (int hr = 0; hr < 10; ++hr) hv[hr] = ld4(halo + ((tg * 4 + hr) * HH + tx + kx) * HPITCH + q * 4);
 #pragma unroll
                 for (int ky = 0; ky < 7; ++ky) {
-                    const float *wp = wl + ((ky * 7 + kx) * 8 + q * 4) * 4;   // same address in every lane: broadcast reads
+                    const float *wp = wl + ((ky * 7 + kx) * HCH + q * 4) * 4;   // same address in every lane: broadcast reads
 #pragma unroll
                     for (int ci = 0; ci < 4; ++ci) wq[ky][ci] = ld4(wp + ci * 4);
                 }
