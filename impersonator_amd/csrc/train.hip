@@ -181,16 +181,17 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restr
 // to LDS as loaded, no transpose.  Workgroup = 64 co x 64 ci of one tap over a slice of the pixels, four waves of
 // 32 x 32; the slices' partial results are summed in a fixed order by reduce_slices_kernel (deterministic).
 constexpr int WG_PX = 32, WG_PITCH = 64 + 4;
+// KWd x (ntaps / KWd) filter taps; oihw = 0: out[slice][Cout][ntaps][Cin] (matrix layout), 1: out[slice][Cout][Cin][ntaps]
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dy, int Cout, const float *__restrict__ x,
                                                     int Cin, int N, int H, int W, int Ho, int Wo, int stride, int pad,
-                                                    long px_per_slice, float *__restrict__ out /* [slice][Cout][16][Cin] */)
+                                                    long px_per_slice, float *__restrict__ out, int KWd, int ntaps, int oihw)
 {
     __shared__ __attribute__((aligned(16))) float sA[2][WG_PX][WG_PITCH], sB[2][WG_PX][WG_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
-    const int tap = blockIdx.z & 15, slice = blockIdx.z >> 4;
-    const int kh = tap >> 2, kw = tap & 3;
+    const int tap = blockIdx.z % ntaps, slice = blockIdx.z / ntaps;
+    const int kh = tap / KWd, kw = tap - kh * KWd;
     const long P = (long)N * Ho * Wo;
     const long p0 = slice * px_per_slice, p1 = p0 + px_per_slice < P ? p0 + px_per_slice : P;
 
@@ -246,11 +247,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dy
     // C/D layout: col = lane&31 -> ci, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co
     const int ci = ci0 + wn * 32 + (lane & 31);
     if (ci < Cin) {
-        float *o = out + (size_t)slice * Cout * 16 * Cin;
+        float *o = out + (size_t)slice * Cout * ntaps * Cin;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            o[((size_t)co * 16 + tap) * Cin + ci] = acc[r];
+            if (co < Cout) o[oihw ? ((size_t)co * Cin + ci) * ntaps + tap : ((size_t)co * ntaps + tap) * Cin + ci] = acc[r];
         }
     }
 }
@@ -304,6 +305,40 @@ __global__ __launch_bounds__(256) void take_channel0_kernel(const float *__restr
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P) y[i] = x[(size_t)i * C];
+}
+
+// ---- op-level convolution API: weight re-layouts from PyTorch tensors (device to device)
+// mode 0: conv OIHW (Cout,Cin,k,k) -> forward matrix [Cout][tap][Cin]
+// mode 1: conv OIHW -> data-gradient matrix of a stride-1 conv [Cin][k*k-1-tap'][Cout]: dst[ci][t][co] = w[co][ci][T-1-t]
+// mode 2: "transposed-conv forward" phase matrices from a tensor laid out (A, B, 3, 3): dst phase (py,px), [b][t][a]
+//         = w[a][b][ky][kx], ky = py ? (ty ? 0 : 2) : 1 (generator.hip upload_convT).  Serves ConvTranspose2d forward
+//         (A = Cin, B = Cout) and the data gradient of Conv2d(k3,s2,p1) (its OIHW tensor read as A = Cout, B = Cin).
+__global__ __launch_bounds__(256) void weight_layout_kernel(const float *__restrict__ w, float *__restrict__ dst, int mode,
+                                                            int A, int B, int taps, long total, int pitch)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (mode == 0) {          // A = Cout, B = Cin: dst[a*pitch + t*B + b]
+        const int b = (int)(i % B), t = (int)((i / B) % taps), a = (int)(i / ((long)B * taps));
+        dst[(size_t)a * pitch + (size_t)t * B + b] = w[((size_t)a * B + b) * taps + t];
+    } else if (mode == 1) {   // A = Cout, B = Cin: dst[(b*taps + t)*A + a]
+        const int a = (int)(i % A), t = (int)((i / A) % taps), b = (int)(i / ((long)A * taps));
+        dst[i] = w[((size_t)a * B + b) * taps + (taps - 1 - t)];
+    } else {                  // four phases with 1, 2, 2, 4 taps, rows of B outputs x (t, a)
+        long j = i;
+        int phase = 0, nt = 1;
+        for (; phase < 4; ++phase) {
+            nt = (1 + (phase >> 1)) * (1 + (phase & 1));
+            const long sz = (long)B * nt * A;
+            if (j < sz) break;
+            j -= sz;
+        }
+        const int py = phase >> 1, px = phase & 1, KWp = 1 + px;
+        const int a = (int)(j % A), t = (int)((j / A) % nt), b = (int)(j / ((long)A * nt));
+        const int ty = t / KWp, tx = t - ty * KWp;
+        const int ky = py == 0 ? 1 : (ty == 0 ? 2 : 0), kx = px == 0 ? 1 : (tx == 0 ? 2 : 0);
+        dst[i] = w[(((size_t)a * B + b) * 3 + ky) * 3 + kx];
+    }
 }
 
 struct DLayer {
@@ -688,7 +723,7 @@ int lwg_discriminator_backward(lwg_discriminator *d, const float *real_nchw, con
         if ((size_t)S * L.w_floats > d->part_floats) LWG_FAIL(LWG_ERR_STATE, "wgrad: partial buffer too small");
         float *wout = S == 1 ? d->grads + L.w_off : d->part;
         const dim3 grid(ceil_div(L.cin_pad, 64), L.cout_pad / 64, (unsigned)(16 * S));
-        wgrad_kernel<<<grid, 256, 0, st>>>(L.draw, L.cout_pad, xin, L.cin_pad, B, L.Hin, L.Hin, L.Ho, L.Ho, L.stride, 1, per, wout);
+        wgrad_kernel<<<grid, 256, 0, st>>>(L.draw, L.cout_pad, xin, L.cin_pad, B, L.Hin, L.Hin, L.Ho, L.Ho, L.stride, 1, per, wout, 4, 16, 0);
         LWG_LAUNCH_CHECK("wgrad_kernel");
         if (S > 1) {
             reduce_slices_kernel<<<ceil_div((long)L.w_floats, 256), 256, 0, st>>>(d->part, (int)S, (long)L.w_floats, d->grads + L.w_off);
@@ -718,6 +753,179 @@ int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float beta1, flo
                                                                  beta2, eps, bc1, sqrtf(bc2));
     LWG_LAUNCH_CHECK("adam_kernel");
     return d_refresh_dgrad_weights(d, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Op-level convolution gradients (building blocks of the generator-side training step).
+namespace {
+
+struct ConvGeom { int Ho, Wo; size_t w_floats; };
+
+int conv_geom(const lwg_conv2d_desc *d, ConvGeom *g)
+{
+    LWG_REQUIRE(d && g, "conv2d: NULL descriptor");
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (!pow2(d->Cin) || !pow2(d->Cout) || d->Cin < 8 || d->Cout < 8)
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d: channel counts must be powers of two >= 8 (Cin=%d, Cout=%d)", d->Cin, d->Cout);
+    if (d->transposed) {
+        if (d->k != 3 || d->stride != 2 || d->pad != 1)
+            LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d: transposed convs are ConvTranspose2d(k3, s2, p1, output_padding 1)");
+        g->Ho = 2 * d->H; g->Wo = 2 * d->W;
+    } else {
+        if (d->stride != 1 && d->stride != 2) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d: stride must be 1 or 2");
+        if (d->k < 1 || d->k > 7) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d: kernel size 1..7");
+        g->Ho = (d->H + 2 * d->pad - d->k) / d->stride + 1;
+        g->Wo = (d->W + 2 * d->pad - d->k) / d->stride + 1;
+    }
+    if (d->N < 1 || g->Ho < 1 || g->Wo < 1) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv2d: empty tensor");
+    g->w_floats = (size_t)d->Cin * d->Cout * d->k * d->k;
+    return LWG_OK;
+}
+
+// plain conv through the general implicit GEMM: x (N,H,W,Cin) * wmat [Cout][k*k][Cin] -> y (N,Ho,Wo,Cout)
+int op_conv(const float *x, int N, int H, int W, int Cin, const float *wmat, const float *bias, int Cout, int k, int stride,
+            int pad, float *y, hipStream_t st)
+{
+    if (Cout % 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d: this direction needs a multiple of 64 output channels, got %d", Cout);
+    ConvArgs a = base_args(x, Cin, N, H, Cin, wmat, y, Cout);
+    a.W = W;
+    a.Hm = a.Ho = (H + 2 * pad - k) / stride + 1;
+    a.Wm = a.Wo = (W + 2 * pad - k) / stride + 1;
+    a.stride = stride; a.pad = pad; a.os = 1;
+    a.bias = bias;
+    a.nphase = 1;
+    a.ph[0] = ConvPhase{k, k, k * k, (int)align_up((size_t)k * k * Cin, kConvBK), 0, 0, 0, 0, 0};   // wmat rows have this pitch
+    a.mtiles = ceil_div((long)N * a.Hm * a.Wm, kConvBM);
+    return launch_conv_igemm(a, (Cout % 128 == 0 && Cin >= kConvBK) ? 128 : 64, st);
+}
+
+// "transposed conv forward" through the 4-phase decomposition: x (N,H,W,Cin) * phase matrices -> y (N,2H,2W,Cout)
+int op_convT(const float *x, int N, int H, int W, int Cin, const float *wph, int Cout, float *y, hipStream_t st)
+{
+    if (Cout % 64 || Cin < kConvBK) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d: this direction needs Cout %% 64 == 0 and Cin >= 32");
+    ConvArgs a = base_args(x, Cin, N, H, Cin, wph, y, Cout);
+    a.W = W;
+    a.Hm = H; a.Wm = W; a.Ho = 2 * H; a.Wo = 2 * W;
+    a.stride = 1; a.pad = 0; a.os = 2;
+    a.nphase = 4;
+    long off = 0;
+    for (int p = 0; p < 4; ++p) {
+        const int py = p >> 1, px = p & 1, nt = (1 + py) * (1 + px);
+        a.ph[p] = ConvPhase{1 + py, 1 + px, nt, nt * Cin, off, py, px, 0, 0};
+        off += (long)Cout * nt * Cin;
+    }
+    a.mtiles = ceil_div((long)N * H * W, kConvBM);
+    return launch_conv_igemm(a, Cout % 128 == 0 ? 128 : 64, st);
+}
+
+int relayout(const float *w, float *dst, int mode, int A, int B, int taps, long total, hipStream_t st, int pitch = 0)
+{
+    if (pitch && pitch != taps * B) LWG_HIP(hipMemsetAsync(dst, 0, (size_t)A * pitch * sizeof(float), st));
+    weight_layout_kernel<<<ceil_div(total, 256), 256, 0, st>>>(w, dst, mode, A, B, taps, total, pitch ? pitch : taps * B);
+    LWG_LAUNCH_CHECK("weight_layout_kernel");
+    return LWG_OK;
+}
+
+}  // namespace
+
+size_t lwg_conv2d_workspace_bytes(const lwg_conv2d_desc *d)
+{
+    ConvGeom g;
+    if (conv_geom(d, &g) != LWG_OK) return 0;
+    // one re-laid-out weight matrix, or up to 32 split-K partial gradients + the column-sum scratch
+    return (33 * g.w_floats + (size_t)32 * (d->Cout > d->Cin ? d->Cout : d->Cin) +
+            (size_t)CS_SLICES * (d->Cout > d->Cin ? d->Cout : d->Cin)) * sizeof(float);   // + row padding of the matrix
+}
+
+int lwg_conv2d_forward(const lwg_conv2d_desc *d, const float *x, const float *w, const float *bias, float *y, void *ws,
+                       size_t ws_bytes, lwg_stream_t stream)
+{
+    ConvGeom g;
+    int rc = conv_geom(d, &g);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(x && w && y && ws, "conv2d_forward: NULL argument");
+    if (ws_bytes < lwg_conv2d_workspace_bytes(d)) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv2d_forward: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *wm = static_cast<float *>(ws);
+    if (d->transposed) {
+        if (bias) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_forward: bias on a transposed conv");
+        if ((rc = relayout(w, wm, 2, d->Cin, d->Cout, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
+        return op_convT(x, d->N, d->H, d->W, d->Cin, wm, d->Cout, y, st);
+    }
+    const int pitch = (int)align_up((size_t)d->k * d->k * d->Cin, kConvBK);   // 7x7x8 = 392 -> 416
+    if ((rc = relayout(w, wm, 0, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st, pitch)) != LWG_OK) return rc;
+    return op_conv(x, d->N, d->H, d->W, d->Cin, wm, bias, d->Cout, d->k, d->stride, d->pad, y, st);
+}
+
+int lwg_conv2d_backward_data(const lwg_conv2d_desc *d, const float *dy, const float *w, float *dx, void *ws, size_t ws_bytes,
+                             lwg_stream_t stream)
+{
+    ConvGeom g;
+    int rc = conv_geom(d, &g);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(dy && w && dx && ws, "conv2d_backward_data: NULL argument");
+    if (ws_bytes < lwg_conv2d_workspace_bytes(d)) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv2d_backward_data: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *wm = static_cast<float *>(ws);
+    if (d->transposed) {
+        // gradient of ConvTranspose2d(k3,s2,p1,op1) = Conv2d(k3,s2,p1) of dy whose OIHW tensor is the (Cin,Cout,3,3) one
+        if ((rc = relayout(w, wm, 0, d->Cin, d->Cout, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
+        return op_conv(dy, d->N, g.Ho, g.Wo, d->Cout, wm, nullptr, d->Cin, 3, 2, 1, dx, st);
+    }
+    if (d->stride == 1) {
+        if (2 * d->pad != d->k - 1) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_data: stride-1 convs need 'same' padding");
+        if ((rc = relayout(w, wm, 1, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st)) != LWG_OK) return rc;
+        return op_conv(dy, d->N, g.Ho, g.Wo, d->Cout, wm, nullptr, d->Cin, d->k, 1, d->k - 1 - d->pad, dx, st);
+    }
+    if (d->k != 3 || d->pad != 1 || (d->H & 1) || (d->W & 1))
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_data: stride-2 convs are k3 p1 on even sizes (the discriminator's k4 has its own path)");
+    // gradient of Conv2d(k3,s2,p1) = ConvTranspose2d(k3,s2,p1,op1) forward of dy with the same tensor read as (Cout,Cin,3,3)
+    if ((rc = relayout(w, wm, 2, d->Cout, d->Cin, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
+    return op_convT(dy, d->N, g.Ho, g.Wo, d->Cout, wm, d->Cin, dx, st);
+}
+
+int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const float *dy, float *dw, float *dbias, void *ws,
+                               size_t ws_bytes, lwg_stream_t stream)
+{
+    ConvGeom g;
+    int rc = conv_geom(d, &g);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(x && dy && dw && ws, "conv2d_backward_weight: NULL argument");
+    if (ws_bytes < lwg_conv2d_workspace_bytes(d)) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv2d_backward_weight: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *part = static_cast<float *>(ws);
+    // the conv whose weight gradient this is: out (O channels, grad `go`) = conv(in (I channels), stride, pad)
+    // plain conv: in = x, go = dy.  ConvTranspose2d: the roles swap (dW[ci][co] pairs x[ci] with dy[co] taken 2i-1+kh).
+    const float *in = d->transposed ? dy : x, *go = d->transposed ? x : dy;
+    const int I = d->transposed ? d->Cout : d->Cin, O = d->transposed ? d->Cin : d->Cout;
+    const int Hin = d->transposed ? g.Ho : d->H, Win = d->transposed ? g.Wo : d->W;
+    const int Hg = d->transposed ? d->H : g.Ho, Wg = d->transposed ? d->W : g.Wo;
+    const int stride = d->transposed ? 2 : d->stride, pad = d->pad, taps = d->k * d->k;
+    if (O % 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_weight: needs a multiple of 64 channels on the gradient side, got %d", O);
+    const long P = (long)d->N * Hg * Wg;
+    const long tiles = (long)(O / 64) * ceil_div(I, 64) * taps;
+    long S = ceil_div(512, tiles);
+    if (S > 32) S = 32;
+    if (S > ceil_div(P, WG_PX)) S = ceil_div(P, WG_PX);
+    const long per = ceil_div(ceil_div(P, S), WG_PX) * (long)WG_PX;
+    S = ceil_div(P, per);
+    float *wout = S == 1 ? dw : part;
+    const dim3 grid(ceil_div(I, 64), O / 64, (unsigned)(taps * S));
+    wgrad_kernel<<<grid, 256, 0, st>>>(go, O, in, I, d->N, Hin, Win, Hg, Wg, stride, pad, per, wout, d->k, taps, 1);
+    LWG_LAUNCH_CHECK("wgrad_kernel");
+    if (S > 1) {
+        reduce_slices_kernel<<<ceil_div((long)g.w_floats, 256), 256, 0, st>>>(part, (int)S, (long)g.w_floats, dw);
+        LWG_LAUNCH_CHECK("reduce_slices_kernel");
+    }
+    if (dbias) {
+        if (d->transposed) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_weight: bias gradient of a transposed conv");
+        float *cs = part + 32 * g.w_floats;
+        col_sum_partial_kernel<<<dim3(d->Cout / 64, CS_SLICES), 256, 0, st>>>(dy, P, d->Cout, cs);
+        LWG_LAUNCH_CHECK("col_sum_partial_kernel");
+        reduce_slices_kernel<<<ceil_div(d->Cout, 256), 256, 0, st>>>(cs, CS_SLICES, d->Cout, dbias);
+        LWG_LAUNCH_CHECK("reduce_slices_kernel");
+    }
+    return LWG_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,76 @@
+"""Op-level convolution and its gradients on MI355X (liblwg, train.hip): thin tensor wrappers over
+lwg_conv2d_{forward, backward_data, backward_weight}.  Activations are NHWC fp32 CUDA tensors, weights keep PyTorch's
+layouts ((Cout,Cin,k,k); (Cin,Cout,3,3) for the transposed conv).  Building blocks of the generator-side training step
+(SURVEY.md 8f row 4); the inference path does not go through here."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class _Desc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("N", "H", "W", "Cin", "Cout", "k", "stride", "pad", "transposed")]
+
+
+def _desc(x_shape, cin, cout, k, stride, pad, transposed):
+    n, h, w, _ = x_shape
+    return _Desc(n, h, w, cin, cout, k, stride, pad, int(transposed))
+
+
+def _ws(d, dev):
+    nbytes = _lib.load().lwg_conv2d_workspace_bytes(ctypes.byref(d))
+    if not nbytes:
+        raise _lib.LwgError(-2, _lib.load().lwg_last_error().decode(errors="replace"))
+    return torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32), nbytes
+
+
+def _out_hw(h, w, k, stride, pad, transposed):
+    return (2 * h, 2 * w) if transposed else ((h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("lwg ops take contiguous float32 CUDA tensors (no CPU fallback)")
+
+
+@torch.no_grad()
+def conv2d_forward(x, w, bias=None, stride=1, pad=0, transposed=False):
+    """x (N,H,W,Cin) -> (N,Ho,Wo,Cout); F.conv2d / F.conv_transpose2d(stride 2, padding 1, output_padding 1)."""
+    _chk(x, w, bias)
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    d = _desc(x.shape, cin, cout, w.shape[2], stride, pad, transposed)
+    ho, wo = _out_hw(x.shape[1], x.shape[2], w.shape[2], stride, pad, transposed)
+    y = torch.empty((x.shape[0], ho, wo, cout), device=x.device, dtype=torch.float32)
+    ws, nb = _ws(d, x.device)
+    _lib.check(_lib.load().lwg_conv2d_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y),
+                                              _lib.ptr(ws), nb, _lib.stream_ptr()))
+    return y
+
+
+@torch.no_grad()
+def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, transposed=False):
+    """Gradient wrt the input: dy (N,Ho,Wo,Cout) -> dx of shape x_shape (N,H,W,Cin)."""
+    _chk(dy, w)
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    d = _desc(x_shape, cin, cout, w.shape[2], stride, pad, transposed)
+    dx = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
+    ws, nb = _ws(d, dy.device)
+    _lib.check(_lib.load().lwg_conv2d_backward_data(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(ws), nb,
+                                                    _lib.stream_ptr()))
+    return dx
+
+
+@torch.no_grad()
+def conv2d_backward_weight(x, dy, w_shape, stride=1, pad=0, transposed=False, with_bias=False):
+    """Gradient wrt the weight (PyTorch layout `w_shape`) and, optionally, the bias."""
+    _chk(x, dy)
+    cin, cout = (w_shape[0], w_shape[1]) if transposed else (w_shape[1], w_shape[0])
+    d = _desc(x.shape, cin, cout, w_shape[2], stride, pad, transposed)
+    dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
+    db = torch.empty(cout, device=x.device, dtype=torch.float32) if with_bias else None
+    ws, nb = _ws(d, x.device)
+    _lib.check(_lib.load().lwg_conv2d_backward_weight(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db),
+                                                      _lib.ptr(ws), nb, _lib.stream_ptr()))
+    return (dw, db) if with_bias else dw

@@ -243,6 +243,25 @@ LWG_API int lwg_discriminator_buffers(lwg_discriminator *d, float **params, floa
 LWG_API int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float beta1, float beta2, float eps,
                                         lwg_stream_t stream);
 
+/* ---- op-level convolution and its gradients (building blocks of the generator-side training step) ----------------
+ * Tensors NHWC fp32 on the device; weights in PyTorch layout: (Cout,Cin,k,k) for Conv2d, (Cin,Cout,3,3) for
+ * ConvTranspose2d(k3,s2,p1,output_padding 1) (`transposed` = 1; H, W are then the INPUT size, the output is 2H x 2W).
+ * Replaces F.conv2d / F.conv_transpose2d and torch.autograd's conv backward (the reference: networks/generator.py:8-20,
+ * 80-133 under loss.backward(), models/impersonator_trainer.py:355-357).  fp32 MFMA; channel counts powers of two >= 8,
+ * the side that becomes the GEMM's N dimension a multiple of 64 (Cout for forward, Cin for backward_data; for
+ * backward_weight Cout, or Cin when transposed).  stride 1: any k <= 7 with 'same' padding for backward_data;
+ * stride 2: k3 p1 on even sizes.  workspace: lwg_conv2d_workspace_bytes, scratch only (nothing persists). */
+typedef struct lwg_conv2d_desc {
+    int N, H, W, Cin, Cout, k, stride, pad, transposed;
+} lwg_conv2d_desc;
+LWG_API size_t lwg_conv2d_workspace_bytes(const lwg_conv2d_desc *d);
+LWG_API int lwg_conv2d_forward(const lwg_conv2d_desc *d, const float *x, const float *w, const float *bias, float *y,
+                               void *workspace, size_t workspace_bytes, lwg_stream_t stream);
+LWG_API int lwg_conv2d_backward_data(const lwg_conv2d_desc *d, const float *dy, const float *w, float *dx,
+                                     void *workspace, size_t workspace_bytes, lwg_stream_t stream);
+LWG_API int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const float *dy, float *dw, float *dbias,
+                                       void *workspace, size_t workspace_bytes, lwg_stream_t stream);
+
 /* Test hook: copies an internal scratch buffer (device to device) after inference/swap/encode_src.
  * which: 0..2 = concat buffers cat[l] (bs, is>>l, is>>l, 2*conv_dim<<l)  [skip half | decoder half],
  *        3 = residual trunk output (bs, is/8, is/8, 8*conv_dim), 4..5 = skipper outputs 0..1,
