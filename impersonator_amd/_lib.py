@@ -65,6 +65,10 @@ _PROTOS = {
     "lwg_conv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "lwg_conv2d_backward_data": (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "lwg_conv2d_backward_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    "lwg_instance_norm_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "lwg_instance_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lwg_grid_sample_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lwg_adam_update": (_i, [_vp, _vp, _vp, _vp, _c.c_size_t, _c.c_long, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
     "lwg_discriminator_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _i]),
     "lwg_discriminator_destroy": (None, [_vp]),
     "lwg_discriminator_load_weight": (_i, [_vp, _c.c_char_p, _vp, _c.POINTER(_c.c_int64), _i]),

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "conv.h"
+#include "sample.h"
 
 namespace lwg {
 namespace {
@@ -305,6 +306,107 @@ __global__ __launch_bounds__(256) void take_channel0_kernel(const float *__restr
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P) y[i] = x[(size_t)i * C];
+}
+
+// ---- op-level InstanceNorm2d(affine) [+ ReLU] and its gradient (NHWC fp32)
+// y = act(gamma * (x - mean) * rstd + beta); stats = (mean, rstd) per (image, channel) from in_stats_kernel
+__global__ __launch_bounds__(256) void in_apply_kernel(const float *__restrict__ x, const float2 *__restrict__ stats,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       int relu, int HW, int C, long total, float *__restrict__ y)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C), n = (int)(e / ((long)HW * C));
+    const float2 st = stats[(size_t)n * C + c];
+    float v = gamma[c] * ((x[e] - st.x) * st.y) + beta[c];
+    if (relu && v < 0.f) v = 0.f;
+    y[e] = v;
+}
+// pass 1: per (image, channel) sums of g and g * xhat, g = dy masked by the ReLU (y > 0) when y is given
+__global__ __launch_bounds__(256) void in_affine_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                   const float *__restrict__ dy, const float2 *__restrict__ stats,
+                                                                   int HW, int C, float2 *__restrict__ sums)
+{
+    __shared__ double sh[2][RS_SL][RS_CH];
+    const int cl = threadIdx.x & (RS_CH - 1), c = blockIdx.x * RS_CH + cl, slice = threadIdx.x / RS_CH, n = blockIdx.y;
+    const size_t base = (size_t)n * HW * C + c;
+    const float2 st = stats[(size_t)n * C + c];
+    double s1 = 0., s2 = 0.;
+    for (int i = slice; i < HW; i += RS_SL) {
+        const size_t o = base + (size_t)i * C;
+        const float g = (y && !(y[o] > 0.f)) ? 0.f : dy[o];
+        s1 += g;
+        s2 += (double)g * ((x[o] - st.x) * st.y);
+    }
+    sh[0][slice][cl] = s1;
+    sh[1][slice][cl] = s2;
+    __syncthreads();
+    if (slice == 0) {
+        s1 = s2 = 0.;
+        for (int k = 0; k < RS_SL; ++k) {
+            s1 += sh[0][k][cl];
+            s2 += sh[1][k][cl];
+        }
+        sums[(size_t)n * C + c] = make_float2((float)s1, (float)s2);   // plain sums: dbeta / dgamma need them over n too
+    }
+}
+// pass 2: dx = gamma * rstd * (g - S1/HW - xhat * S2/HW)
+__global__ __launch_bounds__(256) void in_affine_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                  const float *__restrict__ dy, const float2 *__restrict__ stats,
+                                                                  const float2 *__restrict__ sums, const float *__restrict__ gamma,
+                                                                  int HW, int C, long total, float *__restrict__ dx)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C), n = (int)(e / ((long)HW * C));
+    const float2 st = stats[(size_t)n * C + c], sm = sums[(size_t)n * C + c];
+    const float g = (y && !(y[e] > 0.f)) ? 0.f : dy[e];
+    const float inv = 1.f / (float)HW;
+    dx[e] = gamma[c] * st.y * (g - sm.x * inv - (x[e] - st.x) * st.y * (sm.y * inv));
+}
+// dbeta[c] = sum_n S1, dgamma[c] = sum_n S2 (fixed order)
+__global__ __launch_bounds__(256) void in_affine_bwd_params_kernel(const float2 *__restrict__ sums, int N, int C,
+                                                                   float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double b = 0., g = 0.;
+    for (int n = 0; n < N; ++n) {
+        b += sums[(size_t)n * C + c].x;
+        g += sums[(size_t)n * C + c].y;
+    }
+    dbeta[c] = (float)b;
+    dgamma[c] = (float)g;
+}
+
+// ---- gradient of bilinear grid_sample (zeros padding) wrt its INPUT, NHWC: dx[n][tap][c] += w_tap * dy[n][p][c].
+// Several output pixels may sample one source texel, so the accumulation is atomic (fp32 add: the summation order,
+// hence the last bits, can differ from run to run -- the same property torch's CUDA grid_sampler backward has).
+__global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ grid,
+                                                              int xn, int C, int H, int W, int Ho, int Wo, int align_corners,
+                                                              long total, float *__restrict__ dx)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (output pixel, 4 channels)
+    if (e >= total) return;
+    const int c4n = C >> 2;
+    const long pix = e / c4n;
+    const int c = (int)(e - pix * c4n) * 4;
+    const int n = (int)(pix / ((long)Ho * Wo));
+    const float2 gq = *reinterpret_cast<const float2 *>(grid + pix * 2);
+    const GridTaps t = grid_taps(gq.x, gq.y, W, H, align_corners);
+    const float4 g = ld4(dy + pix * C + c);
+    float *base = dx + (size_t)(xn > 1 ? n : 0) * H * W * C + c;
+    auto add = [&](int yy, int xx, float w) {
+        float *p = base + ((size_t)yy * W + xx) * C;
+        unsafeAtomicAdd(p + 0, w * g.x);
+        unsafeAtomicAdd(p + 1, w * g.y);
+        unsafeAtomicAdd(p + 2, w * g.z);
+        unsafeAtomicAdd(p + 3, w * g.w);
+    };
+    if (t.vnw) add(t.y0, t.x0, t.wnw);
+    if (t.vne) add(t.y0, t.x0 + 1, t.wne);
+    if (t.vsw) add(t.y0 + 1, t.x0, t.wsw);
+    if (t.vse) add(t.y0 + 1, t.x0 + 1, t.wse);
 }
 
 // ---- op-level convolution API: weight re-layouts from PyTorch tensors (device to device)
@@ -925,6 +1027,70 @@ int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const f
         reduce_slices_kernel<<<ceil_div(d->Cout, 256), 256, 0, st>>>(cs, CS_SLICES, d->Cout, dbias);
         LWG_LAUNCH_CHECK("reduce_slices_kernel");
     }
+    return LWG_OK;
+}
+
+/* InstanceNorm2d(affine=True, eps 1e-5, biased variance) [+ ReLU], NHWC fp32.  stats: (N, C) float2 (mean, rstd), written by
+ * forward and read by backward. */
+int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float *gamma, const float *beta, int relu, float *y,
+                              float *stats, lwg_stream_t stream)
+{
+    LWG_REQUIRE(x && gamma && beta && y && stats, "instance_norm_forward: NULL argument");
+    if (C % RS_CH) LWG_FAIL(LWG_ERR_UNSUPPORTED, "instance_norm: C=%d must be a multiple of %d", C, RS_CH);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float2 *s2 = reinterpret_cast<float2 *>(stats);
+    in_stats_kernel<<<dim3(C / RS_CH, N), 256, 0, st>>>(x, HW, C, s2);
+    LWG_LAUNCH_CHECK("in_stats_kernel");
+    const long total = (long)N * HW * C;
+    in_apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(x, s2, gamma, beta, relu, HW, C, total, y);
+    LWG_LAUNCH_CHECK("in_apply_kernel");
+    return LWG_OK;
+}
+
+/* y: the forward output when it went through the ReLU (its sign is the mask), NULL without activation.
+ * scratch: (N, C) float2.  dgamma / dbeta: (C,), overwritten. */
+int lwg_instance_norm_backward(const float *x, const float *y, const float *dy, const float *stats, const float *gamma, int N,
+                               int HW, int C, float *dx, float *dgamma, float *dbeta, float *scratch, lwg_stream_t stream)
+{
+    LWG_REQUIRE(x && dy && stats && gamma && dx && dgamma && dbeta && scratch, "instance_norm_backward: NULL argument");
+    if (C % RS_CH) LWG_FAIL(LWG_ERR_UNSUPPORTED, "instance_norm: C=%d must be a multiple of %d", C, RS_CH);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float2 *s2 = reinterpret_cast<const float2 *>(stats);
+    float2 *sums = reinterpret_cast<float2 *>(scratch);
+    in_affine_bwd_reduce_kernel<<<dim3(C / RS_CH, N), 256, 0, st>>>(x, y, dy, s2, HW, C, sums);
+    LWG_LAUNCH_CHECK("in_affine_bwd_reduce_kernel");
+    const long total = (long)N * HW * C;
+    in_affine_bwd_apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(x, y, dy, s2, sums, gamma, HW, C, total, dx);
+    LWG_LAUNCH_CHECK("in_affine_bwd_apply_kernel");
+    in_affine_bwd_params_kernel<<<ceil_div(C, 256), 256, 0, st>>>(sums, N, C, dgamma, dbeta);
+    LWG_LAUNCH_CHECK("in_affine_bwd_params_kernel");
+    return LWG_OK;
+}
+
+/* Gradient of lwg_grid_sample wrt its input (NHWC here): dy (n,Ho,Wo,C), grid (n,Ho,Wo,2) -> dx (xn,H,W,C), xn in {1, n};
+ * dx is ACCUMULATED into (zero it first).  Atomic fp32 adds: not bit-reproducible. */
+int lwg_grid_sample_backward(const float *dy, const float *grid, int xn, int C, int H, int W, int n, int Ho, int Wo,
+                             int align_corners, float *dx, lwg_stream_t stream)
+{
+    LWG_REQUIRE(dy && grid && dx, "grid_sample_backward: NULL argument");
+    if (C % 4) LWG_FAIL(LWG_ERR_UNSUPPORTED, "grid_sample_backward: C=%d must be a multiple of 4", C);
+    if (xn != 1 && xn != n) LWG_FAIL(LWG_ERR_INVALID_ARG, "grid_sample_backward: input batch must be 1 or %d", n);
+    const long total = (long)n * Ho * Wo * (C / 4);
+    grid_sample_bwd_kernel<<<ceil_div(total, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(dy, grid, xn, C, H, W, Ho, Wo,
+                                                                                                  align_corners, total, dx);
+    LWG_LAUNCH_CHECK("grid_sample_bwd_kernel");
+    return LWG_OK;
+}
+
+/* torch.optim.Adam step (no weight decay) on any flat fp32 device tensor; `step` counts from 1 */
+int lwg_adam_update(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, long step, float lr, float beta1,
+                    float beta2, float eps, lwg_stream_t stream)
+{
+    LWG_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_update: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    adam_kernel<<<ceil_div((long)n, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(param, grad, exp_avg, exp_avg_sq, (long)n,
+                                                                                          lr, beta1, beta2, eps, bc1, sqrtf(bc2));
+    LWG_LAUNCH_CHECK("adam_kernel");
     return LWG_OK;
 }
 

@@ -74,3 +74,51 @@ def conv2d_backward_weight(x, dy, w_shape, stride=1, pad=0, transposed=False, wi
     _lib.check(_lib.load().lwg_conv2d_backward_weight(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db),
                                                       _lib.ptr(ws), nb, _lib.stream_ptr()))
     return (dw, db) if with_bias else dw
+
+
+@torch.no_grad()
+def instance_norm_forward(x, gamma, beta, relu=False):
+    """x (N,H,W,C) -> (y, stats): F.instance_norm(weight, bias, eps=1e-5) [+ ReLU]; stats (N,C,2) = (mean, rstd)."""
+    _chk(x, gamma, beta)
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty((n, c, 2), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().lwg_instance_norm_forward(_lib.ptr(x), n, h * w, c, _lib.ptr(gamma), _lib.ptr(beta), int(relu),
+                                                     _lib.ptr(y), _lib.ptr(stats), _lib.stream_ptr()))
+    return y, stats
+
+
+@torch.no_grad()
+def instance_norm_backward(x, y, dy, stats, gamma):
+    """-> (dx, dgamma, dbeta); pass y (the forward output) when the forward applied the ReLU, else None."""
+    _chk(x, y, dy, stats, gamma)
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty(c, device=x.device, dtype=torch.float32)
+    scratch = torch.empty((n, c, 2), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().lwg_instance_norm_backward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), _lib.ptr(stats), _lib.ptr(gamma), n,
+                                                      h * w, c, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(scratch),
+                                                      _lib.stream_ptr()))
+    return dx, dgamma, dbeta
+
+
+@torch.no_grad()
+def grid_sample_backward(dy, grid, x_shape, align_corners=False):
+    """Gradient of F.grid_sample(x, grid) (bilinear, zeros) wrt x: dy (n,Ho,Wo,C) NHWC, grid (n,Ho,Wo,2) -> dx of NHWC
+    shape x_shape (xn,H,W,C), xn in {1, n} (1: one source shared by the batch, gradients summed)."""
+    _chk(dy, grid)
+    xn, h, w, c = x_shape
+    n, ho, wo, _ = dy.shape
+    dx = torch.zeros(tuple(x_shape), device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().lwg_grid_sample_backward(_lib.ptr(dy), _lib.ptr(grid), xn, c, h, w, n, ho, wo, int(align_corners),
+                                                    _lib.ptr(dx), _lib.stream_ptr()))
+    return dx
+
+
+@torch.no_grad()
+def adam_update(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8):
+    """In-place torch.optim.Adam step on flat (contiguous) tensors."""
+    _chk(param, grad, exp_avg, exp_avg_sq)
+    _lib.check(_lib.load().lwg_adam_update(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), param.numel(),
+                                           int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.stream_ptr()))

@@ -262,6 +262,22 @@ LWG_API int lwg_conv2d_backward_data(const lwg_conv2d_desc *d, const float *dy, 
 LWG_API int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                                        void *workspace, size_t workspace_bytes, lwg_stream_t stream);
 
+/* InstanceNorm2d(affine=True, eps 1e-5, biased variance) [+ ReLU] and its gradient, NHWC fp32 (x: (N,HW,C)).
+ * stats: (N,C,2) floats (mean, rstd) written by forward, read by backward.  backward: y = the forward output when it
+ * went through the ReLU (its sign is the mask) or NULL; scratch (N,C,2) floats; dgamma/dbeta (C,) overwritten. */
+LWG_API int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float *gamma, const float *beta, int relu,
+                                      float *y, float *stats, lwg_stream_t stream);
+LWG_API int lwg_instance_norm_backward(const float *x, const float *y, const float *dy, const float *stats,
+                                       const float *gamma, int N, int HW, int C, float *dx, float *dgamma, float *dbeta,
+                                       float *scratch, lwg_stream_t stream);
+/* Gradient of bilinear grid_sample (zeros padding) wrt its input, NHWC: dy (n,Ho,Wo,C), grid (n,Ho,Wo,2) ->
+ * dx (xn,H,W,C) ACCUMULATED (zero it first), xn in {1, n}.  Atomic fp32 adds (not bit-reproducible, as torch's). */
+LWG_API int lwg_grid_sample_backward(const float *dy, const float *grid, int xn, int C, int H, int W, int n, int Ho, int Wo,
+                                     int align_corners, float *dx, lwg_stream_t stream);
+/* torch.optim.Adam step (no weight decay, no amsgrad) on a flat fp32 device tensor; step counts from 1 */
+LWG_API int lwg_adam_update(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, long step, float lr,
+                            float beta1, float beta2, float eps, lwg_stream_t stream);
+
 /* Test hook: copies an internal scratch buffer (device to device) after inference/swap/encode_src.
  * which: 0..2 = concat buffers cat[l] (bs, is>>l, is>>l, 2*conv_dim<<l)  [skip half | decoder half],
  *        3 = residual trunk output (bs, is/8, is/8, 8*conv_dim), 4..5 = skipper outputs 0..1,

@@ -61,3 +61,54 @@ def test_unsupported_shapes_fail_loudly():
         ops.conv2d_forward(x, torch.zeros(64, 48, 3, 3, device="cuda"), None, 1, 1)      # 48 channels: not a power of two
     with pytest.raises(RuntimeError):
         ops.conv2d_forward(x.cpu(), torch.zeros(64, 48, 3, 3), None, 1, 1)               # no CPU fallback
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_instance_norm_forward_backward(relu):
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, C, H = 3, 64, 24
+    x = torch.randn(N, C, H, H, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    dy = torch.randn(N, C, H, H, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.instance_norm(xr, weight=gr, bias=br, eps=1e-5)
+    if relu:
+        y = F.relu(y)
+    y.backward(dy)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    yg, stats = ops.instance_norm_forward(nhwc(x), gamma.cuda(), beta.cuda(), relu)
+    assert _rel(yg.cpu().permute(0, 3, 1, 2), y.detach()) < 1e-5
+    dx, dg, db = ops.instance_norm_backward(nhwc(x), yg if relu else None, nhwc(dy), stats, gamma.cuda())
+    assert _rel(dx.cpu().permute(0, 3, 1, 2), xr.grad) < 2e-5
+    assert _rel(dg.cpu(), gr.grad) < 2e-5 and _rel(db.cpu(), br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_grid_sample_backward(shared):
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(12)
+    n, C, H = 3, 64, 20
+    x = torch.randn(1 if shared else n, C, H, H, generator=g)
+    grid = torch.rand(n, H, H, 2, generator=g) * 2.6 - 1.3
+    grid[0, 5:9, 3:8] = -2
+    dy = torch.randn(n, C, H, H, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.grid_sample(xr.expand(n, -1, -1, -1) if shared else xr, grid, align_corners=False).backward(dy)
+    dx = ops.grid_sample_backward(dy.permute(0, 2, 3, 1).contiguous().cuda(), grid.cuda(), (x.shape[0], H, H, C), False)
+    assert _rel(dx.cpu().permute(0, 3, 1, 2), xr.grad) < 1e-5
+
+
+def test_adam_update():
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(13)
+    p = torch.randn(1000, generator=g)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.5, 0.999))
+    pg, m, v = p.cuda(), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(1000, generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_update(pg, grad.cuda(), m, v, step, 2e-4, (0.5, 0.999))
+    assert float((pg.cpu() - ref.detach()).abs().max()) < 1e-6
