@@ -82,14 +82,16 @@ __global__ __launch_bounds__(256) void d_act_kernel(const float *__restrict__ ra
 
 // ---- LSGAN loss and its gradient on the 1-channel patch map (channel 0 of a Cp-channel NHWC tensor).
 // Images [0, N) are real (target +1), [N, 2N) fake (target -1).  One workgroup; fixed-order reduction.
+// halves = 2: images [0,N) target t0, [N,2N) target t1, loss = mean over each half, summed; halves = 1: N images, target t0
 __global__ __launch_bounds__(256) void lsgan_kernel(const float *__restrict__ out, int N, int HW, int Cp,
-                                                    float *__restrict__ dout, float *__restrict__ loss)
+                                                    float *__restrict__ dout, float *__restrict__ loss, int halves, float t0,
+                                                    float t1)
 {
     __shared__ double sh[256];
     const int per_half = N * HW;
     double acc = 0.;
-    for (int i = threadIdx.x; i < 2 * per_half; i += 256) {
-        const float y = i < per_half ? 1.f : -1.f;
+    for (int i = threadIdx.x; i < halves * per_half; i += 256) {
+        const float y = i < per_half ? t0 : t1;
         const float d = out[(size_t)i * Cp] - y;
         acc += (double)d * d;
         float *g = dout + (size_t)i * Cp;
@@ -260,20 +262,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dy
 // ---- data-gradient weight matrices from the master copy W[co][kh*4+kw][ci] (run after every optimiser step).
 // stride 1: one matrix [ci][kh'*4+kw'][co] = W[co][(3-kh')*4 + (3-kw')][ci]
 // stride 2: four phase matrices [ci][th*2+tw][co], phase (py,px): kh = py ? (th ? 0 : 2) : (th ? 1 : 3), same for kw
+// `rows` >= Cin input-channel rows are produced (rows beyond Cin are zero: the 64-wide matrix of the first layer)
 __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float *__restrict__ w, int Cout, int Cin, int stride,
-                                                            float *__restrict__ wd)
+                                                            float *__restrict__ wd, int rows)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)Cout * 16 * Cin;
+    const long total = (long)Cout * 16 * rows;
     if (i >= total) return;
     if (stride == 1) {
         const int co = (int)(i % Cout);
         const int t = (int)((i / Cout) % 16);
         const int ci = (int)(i / ((long)Cout * 16));
         const int kh = 3 - (t >> 2), kw = 3 - (t & 3);
-        wd[i] = w[((size_t)co * 16 + kh * 4 + kw) * Cin + ci];
+        wd[i] = ci < Cin ? w[((size_t)co * 16 + kh * 4 + kw) * Cin + ci] : 0.f;
     } else {
-        const long per_phase = (long)Cin * 4 * Cout;
+        const long per_phase = (long)rows * 4 * Cout;
         const int phase = (int)(i / per_phase);
         const long j = i - phase * per_phase;
         const int co = (int)(j % Cout);
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float *__restr
         const int py = phase >> 1, px = phase & 1, th = t >> 1, tw = t & 1;
         const int kh = py ? (th ? 0 : 2) : (th ? 1 : 3);
         const int kw = px ? (tw ? 0 : 2) : (tw ? 1 : 3);
-        wd[i] = w[((size_t)co * 16 + kh * 4 + kw) * Cin + ci];
+        wd[i] = ci < Cin ? w[((size_t)co * 16 + kh * 4 + kw) * Cin + ci] : 0.f;
     }
 }
 
@@ -379,6 +382,32 @@ __global__ __launch_bounds__(256) void in_affine_bwd_params_kernel(const float2 
     dgamma[c] = (float)g;
 }
 
+// ---- bilinear grid_sample (zeros padding), NHWC: y[n][p][c] = sum_tap w_tap * x[n or 0][tap][c]
+__global__ __launch_bounds__(256) void grid_sample_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ grid, int xn,
+                                                               int C, int H, int W, int Ho, int Wo, int align_corners, long total,
+                                                               float *__restrict__ y)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c4n = C >> 2;
+    const long pix = e / c4n;
+    const int c = (int)(e - pix * c4n) * 4;
+    const int n = (int)(pix / ((long)Ho * Wo));
+    const float2 gq = *reinterpret_cast<const float2 *>(grid + pix * 2);
+    const GridTaps t = grid_taps(gq.x, gq.y, W, H, align_corners);
+    const float *base = x + (size_t)(xn > 1 ? n : 0) * H * W * C + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto tap = [&](int yy, int xx, float w) {
+        const float4 v = ld4(base + ((size_t)yy * W + xx) * C);
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    };
+    if (t.vnw) tap(t.y0, t.x0, t.wnw);
+    if (t.vne) tap(t.y0, t.x0 + 1, t.wne);
+    if (t.vsw) tap(t.y0 + 1, t.x0, t.wsw);
+    if (t.vse) tap(t.y0 + 1, t.x0 + 1, t.wse);
+    *reinterpret_cast<float4 *>(y + pix * C + c) = acc;
+}
+
 // ---- gradient of bilinear grid_sample (zeros padding) wrt its INPUT, NHWC: dx[n][tap][c] += w_tap * dy[n][p][c].
 // Several output pixels may sample one source texel, so the accumulation is atomic (fp32 add: the summation order,
 // hence the last bits, can differ from run to run -- the same property torch's CUDA grid_sampler backward has).
@@ -464,6 +493,7 @@ struct lwg_discriminator {
     size_t nparams = 0;
     float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
     float *x0 = nullptr;        // packed input (2N, is, is, cin_pad0)
+    float *wd0 = nullptr, *dx0 = nullptr;   // input-gradient path (allocated on first use): 64-row matrices, (N,is,is,64)
     float *part = nullptr;      // split-K / column-sum partials
     size_t part_floats = 0;
     float *loss = nullptr;      // device scalar
@@ -534,7 +564,14 @@ int d_refresh_dgrad_weights(lwg_discriminator *d, hipStream_t st)
     for (size_t l = 1; l < d->L.size(); ++l) {
         const DLayer &L = d->L[l];
         const long total = (long)L.cout_pad * 16 * L.cin_pad;
-        dgrad_weights_kernel<<<ceil_div(total, 256), 256, 0, st>>>(d->params + L.w_off, L.cout_pad, L.cin_pad, L.stride, L.wd);
+        dgrad_weights_kernel<<<ceil_div(total, 256), 256, 0, st>>>(d->params + L.w_off, L.cout_pad, L.cin_pad, L.stride, L.wd,
+                                                                   L.cin_pad);
+        LWG_LAUNCH_CHECK("dgrad_weights_kernel");
+    }
+    if (d->wd0) {   // first layer, 64 output rows (only needed for the gradient wrt the input image)
+        const DLayer &L = d->L[0];
+        const long total = (long)L.cout_pad * 16 * 64;
+        dgrad_weights_kernel<<<ceil_div(total, 256), 256, 0, st>>>(d->params + L.w_off, L.cout_pad, L.cin_pad, L.stride, d->wd0, 64);
         LWG_LAUNCH_CHECK("dgrad_weights_kernel");
     }
     d->wd_stale = false;
@@ -700,7 +737,7 @@ void lwg_discriminator_destroy(lwg_discriminator *d)
         for (float *p : ptrs)
             if (p) (void)hipFree(p);
     }
-    float *ptrs[] = {d->params, d->grads, d->m, d->v, d->x0, d->part, d->loss};
+    float *ptrs[] = {d->params, d->grads, d->m, d->v, d->x0, d->part, d->loss, d->wd0, d->dx0};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
     delete d;
@@ -794,7 +831,7 @@ int lwg_discriminator_backward(lwg_discriminator *d, const float *real_nchw, con
     const int B = 2 * bs, nl = (int)d->L.size();
     {
         DLayer &L = d->L[nl - 1];
-        lsgan_kernel<<<1, 256, 0, st>>>(L.raw, bs, L.Ho * L.Ho, L.cout_pad, L.dact, d->loss);
+        lsgan_kernel<<<1, 256, 0, st>>>(L.raw, bs, L.Ho * L.Ho, L.cout_pad, L.dact, d->loss, 2, 1.f, -1.f);
         LWG_LAUNCH_CHECK("lsgan_kernel");
         if (loss_device) LWG_HIP(hipMemcpyAsync(loss_device, d->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
     }
@@ -1091,6 +1128,74 @@ int lwg_adam_update(float *param, const float *grad, float *exp_avg, float *exp_
     adam_kernel<<<ceil_div((long)n, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(param, grad, exp_avg, exp_avg_sq, (long)n,
                                                                                           lr, beta1, beta2, eps, bc1, sqrtf(bc2));
     LWG_LAUNCH_CHECK("adam_kernel");
+    return LWG_OK;
+}
+
+/* Generator-side adversarial term (impersonator_trainer.py:369-371): loss = mean((D(x) - target)^2) for x (bs,input_nc,is,is)
+ * and its gradient wrt x (same shape, NCHW); the discriminator's parameters get no gradient from this call. */
+int lwg_discriminator_input_grad(lwg_discriminator *d, const float *x_nchw, int bs, float target, float *loss_device,
+                                 float *dx_nchw, lwg_stream_t stream)
+{
+    int rc = d_check(d, bs);
+    if (rc != LWG_OK) return rc;
+    LWG_REQUIRE(x_nchw && dx_nchw, "discriminator input_grad: NULL argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!d->wd0) {
+        if ((rc = d_alloc(&d->wd0, (size_t)d->L[0].cout_pad * 16 * 64)) != LWG_OK) return rc;
+        if ((rc = d_alloc(&d->dx0, (size_t)d->max_batch * d->is * d->is * 64)) != LWG_OK) return rc;
+        d->wd_stale = true;
+    }
+    if (d->wd_stale && (rc = d_refresh_dgrad_weights(d, st)) != LWG_OK) return rc;
+    if ((rc = d_forward(d, x_nchw, nullptr, bs, st)) != LWG_OK) return rc;
+    const int nl = (int)d->L.size();
+    {
+        DLayer &L = d->L[nl - 1];
+        lsgan_kernel<<<1, 256, 0, st>>>(L.raw, bs, L.Ho * L.Ho, L.cout_pad, L.dact, d->loss, 1, target, 0.f);
+        LWG_LAUNCH_CHECK("lsgan_kernel");
+        if (loss_device) LWG_HIP(hipMemcpyAsync(loss_device, d->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    for (int l = nl - 1; l >= 0; --l) {
+        DLayer &L = d->L[l];
+        const int HW = L.Ho * L.Ho;
+        const long total = (long)bs * HW * L.cout_pad;
+        if (L.norm) {
+            in_bwd_reduce_kernel<<<dim3(L.cout_pad / RS_CH, bs), 256, 0, st>>>(L.raw, L.actv, L.dact, L.stats, HW, L.cout_pad, L.sums);
+            LWG_LAUNCH_CHECK("in_bwd_reduce_kernel");
+        }
+        act_bwd_kernel<<<ceil_div(total, 256), 256, 0, st>>>(L.raw, L.act ? L.actv : nullptr, L.dact, L.norm ? L.stats : nullptr,
+                                                             L.sums, HW, L.cout_pad, total, L.draw);
+        LWG_LAUNCH_CHECK("act_bwd_kernel");
+        if (l > 0) {
+            if ((rc = d_conv_dgrad(d, l, bs, st)) != LWG_OK) return rc;
+        } else {
+            // first layer: 4-phase transposed conv onto a 64-channel image (the real input channels are the first few)
+            ConvArgs a = base_args(L.draw, L.cout_pad, bs, L.Ho, L.cout_pad, d->wd0, d->dx0, 64);
+            a.Hm = a.Wm = L.Hin / 2; a.Ho = a.Wo = L.Hin;
+            a.stride = 1; a.pad = 0; a.os = 2;
+            a.nphase = 4;
+            for (int p = 0; p < 4; ++p) {
+                const int py = p >> 1, px = p & 1;
+                a.ph[p] = ConvPhase{2, 2, 4, 4 * L.cout_pad, (long)p * 64 * 4 * L.cout_pad, py, px, py ? 0 : -1, px ? 0 : -1};
+            }
+            a.mtiles = ceil_div((long)bs * a.Hm * a.Wm, kConvBM);
+            if ((rc = launch_conv_igemm(a, 64, st)) != LWG_OK) return rc;
+            if ((rc = lwg_unpack_nchw(d->dx0, bs, d->input_nc, d->is, d->is, 64, dx_nchw, stream)) != LWG_OK) return rc;
+        }
+    }
+    return LWG_OK;
+}
+
+/* bilinear grid_sample (zeros padding), NHWC: x (xn,H,W,C), xn in {1, n}; grid (n,Ho,Wo,2) -> y (n,Ho,Wo,C) */
+int lwg_grid_sample_nhwc(const float *x, int xn, int C, int H, int W, const float *grid, int n, int Ho, int Wo, int align_corners,
+                         float *y, lwg_stream_t stream)
+{
+    LWG_REQUIRE(x && grid && y, "grid_sample_nhwc: NULL argument");
+    if (C % 4) LWG_FAIL(LWG_ERR_UNSUPPORTED, "grid_sample_nhwc: C=%d must be a multiple of 4", C);
+    if (xn != 1 && xn != n) LWG_FAIL(LWG_ERR_INVALID_ARG, "grid_sample_nhwc: input batch must be 1 or %d", n);
+    const long total = (long)n * Ho * Wo * (C / 4);
+    grid_sample_nhwc_kernel<<<ceil_div(total, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(x, grid, xn, C, H, W, Ho, Wo,
+                                                                                                   align_corners, total, y);
+    LWG_LAUNCH_CHECK("grid_sample_nhwc_kernel");
     return LWG_OK;
 }
 

@@ -138,6 +138,22 @@ class PatchDiscriminator(NetworkBase):
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
     @torch.no_grad()
+    def input_grad(self, x, target=0.0):
+        """The generator's adversarial term (impersonator_trainer.py:369-371): (loss, d loss / d x) for
+        loss = mean((D(x) - target)^2); the discriminator's own parameters get no gradient."""
+        if not x.is_cuda:
+            raise RuntimeError("PatchDiscriminator runs on the MI355X only (no CPU fallback)")
+        h = self._ensure_handle()
+        x = x.detach().float().contiguous()
+        if x.shape[1:] != (self.input_nc, self.image_size, self.image_size) or x.shape[0] > self.max_batch:
+            raise ValueError("expected (<=%d, %d, %d, %d) input" % (self.max_batch, self.input_nc, self.image_size, self.image_size))
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().lwg_discriminator_input_grad(h, _lib.ptr(x), x.shape[0], float(target), _lib.ptr(loss), _lib.ptr(dx),
+                                                            _lib.stream_ptr()))
+        return loss, dx
+
+    @torch.no_grad()
     def optimize_D(self, real_input_D, fake_input_D, lr=0.0002, betas=(0.5, 0.999), eps=1e-8, all_reduce=True):
         """One discriminator update, impersonator_trainer.py:396-411 + backward + Adam (:231-232, train_options.py:36-38):
         loss = mean((D(real) - 1)^2) + mean((D(fake) + 1)^2).  Returns the loss (0-d CUDA tensor, before the update).

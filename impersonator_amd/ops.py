@@ -122,3 +122,15 @@ def adam_update(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), 
     _chk(param, grad, exp_avg, exp_avg_sq)
     _lib.check(_lib.load().lwg_adam_update(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), param.numel(),
                                            int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.stream_ptr()))
+
+
+@torch.no_grad()
+def grid_sample_nhwc(x, grid, align_corners=False):
+    """F.grid_sample (bilinear, zeros) on NHWC tensors: x (xn,H,W,C) with xn in {1, n}, grid (n,Ho,Wo,2) -> (n,Ho,Wo,C)."""
+    _chk(x, grid)
+    xn, h, w, c = x.shape
+    n, ho, wo, _ = grid.shape
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().lwg_grid_sample_nhwc(_lib.ptr(x), xn, c, h, w, _lib.ptr(grid), n, ho, wo, int(align_corners), _lib.ptr(y),
+                                                _lib.stream_ptr()))
+    return y

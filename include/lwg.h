@@ -262,6 +262,14 @@ LWG_API int lwg_conv2d_backward_data(const lwg_conv2d_desc *d, const float *dy, 
 LWG_API int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                                        void *workspace, size_t workspace_bytes, lwg_stream_t stream);
 
+/* Generator-side adversarial term (models/impersonator_trainer.py:369-371): loss = mean((D(x) - target)^2) on
+ * x (bs,input_nc,is,is) NCHW and its gradient wrt x (same shape); the discriminator's parameters get no gradient. */
+LWG_API int lwg_discriminator_input_grad(lwg_discriminator *d, const float *x_nchw, int bs, float target, float *loss_device,
+                                         float *dx_nchw, lwg_stream_t stream);
+/* bilinear grid_sample (zeros padding) on NHWC tensors: x (xn,H,W,C), xn in {1, n}; grid (n,Ho,Wo,2) -> y (n,Ho,Wo,C) */
+LWG_API int lwg_grid_sample_nhwc(const float *x, int xn, int C, int H, int W, const float *grid, int n, int Ho, int Wo,
+                                 int align_corners, float *y, lwg_stream_t stream);
+
 /* InstanceNorm2d(affine=True, eps 1e-5, biased variance) [+ ReLU] and its gradient, NHWC fp32 (x: (N,HW,C)).
  * stats: (N,C,2) floats (mean, rstd) written by forward, read by backward.  backward: y = the forward output when it
  * went through the ReLU (its sign is the mask) or NULL; scratch (N,C,2) floats; dgamma/dbeta (C,) overwritten. */

@@ -174,3 +174,19 @@ def test_trainer_mirror_forward_and_d_phase():
     assert abs(float(loss) - float(ref_loss)) < 2e-3 * max(1.0, float(ref_loss))
     model._D.pull_parameters()
     assert float((model._D.state_dict()["model.0.weight"].cpu() - dsd["model.0.weight"]).abs().max()) > 1e-5
+
+
+def test_input_gradient_for_the_generator_adversarial_term(ctx):
+    """loss_g_adv = mean(D(fake)^2) (impersonator_trainer.py:369-371) and its gradient wrt the fake image."""
+    from impersonator_amd.networks.discriminator import PatchDiscriminator
+    D = PatchDiscriminator(6, 64, 4, 'instance', False, image_size=128, max_batch=2)
+    D.load_state_dict(ctx["sd"])
+    D = D.cuda()
+    x = torch.rand(2, 6, 128, 128, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    loss, dx = D.input_grad(x.cuda(), 0.0)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.mean(torch_ref.discriminator_forward(ctx["sd"], xr) ** 2)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, float(ref))
+    assert _rel(dx.cpu(), xr.grad) < 1e-3
+    D.release()
