@@ -88,6 +88,7 @@ def load():
     ns.networks = importlib.import_module("networks.networks")
     ns.inpaintor = importlib.import_module("networks.inpaintor")
     ns.discriminator = importlib.import_module("networks.discriminator")
+    ns.trainer = importlib.import_module("models.impersonator_trainer")
     ns.nmr = importlib.import_module("utils.nmr")
     ns.util = importlib.import_module("utils.util")
     ns.batch_smpl = importlib.import_module("networks.batch_smpl")

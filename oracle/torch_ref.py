@@ -386,3 +386,57 @@ def generator_infer_front(sd, src_inputs, tsf_inputs, T, align_corners=False):
 def generator_forward(sd, bg_inputs, src_inputs, tsf_inputs, T, align_corners=False):
     """ImpersonatorGenerator.forward (networks/generator.py:204-211)."""
     return (bgnet_forward(sd, bg_inputs),) + generator_infer_front(sd, src_inputs, tsf_inputs, T, align_corners)
+
+
+# ------------------------------------------------------------------------------------------------
+# Training, generator side (SURVEY.md 8f row 4): ImpersonatorTrainer.forward + _optimize_G + Adam, CPU autograd.
+
+G_TRAIN_DEFAULTS = dict(lambda_D_prob=1.0, lambda_rec=10.0, lambda_tsf=10.0, lambda_mask=0.1, lambda_mask_smooth=1e-5,
+                        lr_G=0.0002, G_adam_b1=0.5, G_adam_b2=0.999)   # options/train_options.py:33-45
+
+
+def generator_train_loss(gsd, dsd, batch, opt=None, align_corners=False):
+    """models/impersonator_trainer.py: forward (:329-348, bg_both=False) + _optimize_G (:368-394) with the loss terms
+    that need no pretrained network: adversarial (LSGAN, target 0), L1 reconstruction of the source, L1 on the
+    transferred image (what the `--use_vgg` help text calls the default; the reference's own code path for it only works
+    with `self._crt_tsf` set -- VGGLoss needs a download -- so the pin test injects torch.nn.L1Loss there), mask MSE,
+    mask total variation.  No style / face terms (their flags default to off).
+    batch: input_G_bg (N,4,H,W), input_G_src, input_G_tsf (N,6,H,W), T (N,H,W,2), real_src, real_tsf (N,3,H,W),
+    bg_mask (2N,1,H,W).  Returns (total, dict of terms, (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks))."""
+    o = dict(G_TRAIN_DEFAULTS)
+    o.update(opt or {})
+    fake_bg, src_img, src_mask, tsf_img, tsf_mask = generator_forward(gsd, batch["input_G_bg"], batch["input_G_src"],
+                                                                      batch["input_G_tsf"], batch["T"], align_corners)
+    bs = src_img.shape[0]
+    fake_src_bg = fake_bg[0:bs]
+    fake_src_imgs = src_mask * fake_src_bg + (1 - src_mask) * src_img
+    fake_tsf_imgs = tsf_mask * fake_src_bg + (1 - tsf_mask) * tsf_img
+    fake_masks = torch.cat([src_mask, tsf_mask], dim=0)
+    d_fake = discriminator_forward(dsd, torch.cat([fake_tsf_imgs, batch["input_G_tsf"][:, 3:]], dim=1))
+    terms = dict(
+        g_adv=torch.mean(d_fake ** 2) * o["lambda_D_prob"],
+        g_rec=F.l1_loss(fake_src_imgs, batch["real_src"]) * o["lambda_rec"],
+        g_tsf=F.l1_loss(fake_tsf_imgs, batch["real_tsf"]) * o["lambda_tsf"],
+        g_mask=F.mse_loss(fake_masks, batch["bg_mask"]) * o["lambda_mask"],
+        g_mask_smooth=(torch.mean(torch.abs(fake_masks[:, :, :, :-1] - fake_masks[:, :, :, 1:])) +
+                       torch.mean(torch.abs(fake_masks[:, :, :-1, :] - fake_masks[:, :, 1:, :]))) * o["lambda_mask_smooth"])
+    return sum(terms.values()), terms, (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)
+
+
+def generator_train_steps(gsd, dsd, batches, opt=None, align_corners=False):
+    """`len(batches)` generator updates with torch.optim.Adam (impersonator_trainer.py:229-230, 355-357), the
+    discriminator frozen.  Returns (per-step loss terms, gradients of the first step, final parameters)."""
+    o = dict(G_TRAIN_DEFAULTS)
+    o.update(opt or {})
+    params = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+    optim = torch.optim.Adam(list(params.values()), lr=o["lr_G"], betas=(o["G_adam_b1"], o["G_adam_b2"]))
+    hist, first = [], None
+    for batch in batches:
+        optim.zero_grad()
+        total, terms, _ = generator_train_loss(params, dsd, batch, o, align_corners)
+        total.backward()
+        if first is None:
+            first = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v)) for k, v in params.items()}
+        optim.step()
+        hist.append({k: float(v.detach()) for k, v in terms.items()})
+    return hist, first, {k: v.detach().clone() for k, v in params.items()}

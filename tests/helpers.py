@@ -63,3 +63,15 @@ def discriminator_state_dict(seed=0, input_nc=6, ndf=64, n_layers=4):
         idx += 2 if l == 0 else 3
         cin = cout
     return sd
+
+
+def train_batch(seed=0, n=2, size=64):
+    """Seeded stand-in for what the reference's BodyRecoveryFlow hands the trainer (impersonator_trainer.py:300-319)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g) * 2 - 1
+    T = torch.rand(n, size, size, 2, generator=g) * 2.4 - 1.2
+    T[0, size // 4:size // 2, size // 8:size // 3] = -2
+    return dict(input_G_bg=r(n, 4, size, size), input_G_src=r(n, 6, size, size), input_G_tsf=r(n, 6, size, size), T=T,
+                real_src=r(n, 3, size, size), real_tsf=r(n, 3, size, size),
+                bg_mask=(torch.rand(2 * n, 1, size, size, generator=g) > 0.5).float())

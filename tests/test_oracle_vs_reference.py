@@ -150,3 +150,37 @@ def test_generator_forward_restatement_matches_reference(ref):
         mine = torch_ref.generator_forward(sd, bg, src, tsf, T)
     for a, b in zip(theirs, mine):
         assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+
+
+def test_generator_train_loss_matches_reference_trainer(ref):
+    """oracle generator_train_loss / gradients == the reference's ImpersonatorTrainer.forward + _optimize_G run unbound
+    on a stub `self` (its __init__ needs datasets and downloads).  `_crt_tsf` is torch.nn.L1Loss: without --use_vgg the
+    reference never defines it (impersonator_trainer.py:256-260 vs :376-380), with it it needs the VGG19 download."""
+    T = ref.trainer.Impersonator
+    G = ref.generator.ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6)
+    D = ref.discriminator.PatchDiscriminator(input_nc=6, ndf=64, n_layers=4, norm_type='instance', use_sigmoid=False)
+    gsd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=2, affine="random"))
+    dsd = helpers.discriminator_state_dict(seed=3)
+    G.load_state_dict(gsd)
+    D.load_state_dict(dsd)
+    b = helpers.train_batch(seed=5, n=2, size=64)
+    opt = types.SimpleNamespace(bg_both=False, use_vgg=False, use_style=False, use_face=False, lambda_D_prob=1, lambda_rec=10,
+                                lambda_tsf=10, lambda_mask=0.1, lambda_mask_smooth=1e-5)
+    me = types.SimpleNamespace(_G=G, _D=D, _opt=opt, _input_G_bg=b["input_G_bg"], _input_G_src=b["input_G_src"],
+                               _input_G_tsf=b["input_G_tsf"], _T=b["T"], _real_src=b["real_src"], _real_tsf=b["real_tsf"],
+                               _bg_mask=b["bg_mask"], _crt_l1=torch.nn.L1Loss(), _crt_tsf=torch.nn.L1Loss(),
+                               _crt_mask=torch.nn.MSELoss(), _loss_g_style=torch.zeros(1), _loss_g_face=torch.zeros(1),
+                               _loss_g_mask_smooth=torch.zeros(1))
+    me._compute_loss_D = types.MethodType(T._compute_loss_D, me)
+    me._compute_loss_smooth = types.MethodType(T._compute_loss_smooth, me)
+    fake = T.forward(me)
+    loss = T._optimize_G(me, *fake)
+    G.zero_grad()
+    loss.backward()
+    total, terms, mine_fake = torch_ref.generator_train_loss({k: v.clone().requires_grad_(True) for k, v in gsd.items()}, dsd, b)
+    assert abs(float(loss) - float(total)) < 1e-5 * max(1.0, float(total))
+    for a, c in zip(fake, mine_fake):
+        assert torch.allclose(a, c, atol=1e-5, rtol=1e-5)
+    _, grads, _ = torch_ref.generator_train_steps(gsd, dsd, [b])
+    for k, p in G.named_parameters():
+        assert torch.allclose(p.grad, grads[k], atol=1e-6 + 1e-4 * float(p.grad.abs().max()), rtol=0), k
