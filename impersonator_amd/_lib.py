@@ -67,7 +67,8 @@ _PROTOS = {
     "lwg_conv2d_backward_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "lwg_discriminator_input_grad": (_i, [_vp, _vp, _i, _c.c_float, _vp, _vp, _vp]),
     "lwg_grid_sample_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "lwg_instance_norm_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "lwg_instance_norm_scratch_bytes": (_c.c_size_t, [_i, _i, _i]),
+    "lwg_instance_norm_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "lwg_instance_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lwg_grid_sample_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "lwg_adam_update": (_i, [_vp, _vp, _vp, _vp, _c.c_size_t, _c.c_long, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),

@@ -382,6 +382,104 @@ __global__ __launch_bounds__(256) void in_affine_bwd_params_kernel(const float2 
     dgamma[c] = (float)g;
 }
 
+// ---- the same two reductions for large maps: the pixels of an (image, channel) are split into S slabs handled by
+// different workgroups (grid (C/16, N, S)), partial sums go to a double scratch [N][S][C][2] and are combined in slab
+// order by the *_final kernels -- deterministic, and 16 x S times more workgroups than channels / 16 x images.
+__global__ __launch_bounds__(256) void in_stats_partial_kernel(const float *__restrict__ x, int HW, int C, int S,
+                                                               double *__restrict__ part)
+{
+    __shared__ double sh[2][RS_SL][RS_CH];
+    const int cl = threadIdx.x & (RS_CH - 1), c = blockIdx.x * RS_CH + cl, slice = threadIdx.x / RS_CH, n = blockIdx.y, sb = blockIdx.z;
+    const int per = (HW + S - 1) / S, p0 = sb * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const float *p = x + (size_t)n * HW * C + c;
+    double s = 0., q = 0.;
+    for (int i = p0 + slice; i < p1; i += RS_SL) {
+        const double v = p[(size_t)i * C];
+        s += v;
+        q += v * v;
+    }
+    sh[0][slice][cl] = s;
+    sh[1][slice][cl] = q;
+    __syncthreads();
+    if (slice == 0) {
+        s = q = 0.;
+        for (int k = 0; k < RS_SL; ++k) {
+            s += sh[0][k][cl];
+            q += sh[1][k][cl];
+        }
+        double *o = part + (((size_t)n * S + sb) * C + c) * 2;
+        o[0] = s;
+        o[1] = q;
+    }
+}
+__global__ __launch_bounds__(256) void in_stats_final_kernel(const double *__restrict__ part, int N, int C, int S, int HW,
+                                                             float2 *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    double s = 0., q = 0.;
+    for (int k = 0; k < S; ++k) {
+        const double *o = part + (((size_t)n * S + k) * C + c) * 2;
+        s += o[0];
+        q += o[1];
+    }
+    const double mean = s / HW, var = fmax(q / HW - mean * mean, 0.);
+    out[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)kEps)));
+}
+__global__ __launch_bounds__(256) void in_affine_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                    const float *__restrict__ dy, const float2 *__restrict__ stats,
+                                                                    int HW, int C, int S, double *__restrict__ part)
+{
+    __shared__ double sh[2][RS_SL][RS_CH];
+    const int cl = threadIdx.x & (RS_CH - 1), c = blockIdx.x * RS_CH + cl, slice = threadIdx.x / RS_CH, n = blockIdx.y, sb = blockIdx.z;
+    const int per = (HW + S - 1) / S, p0 = sb * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const size_t base = (size_t)n * HW * C + c;
+    const float2 st = stats[(size_t)n * C + c];
+    double s1 = 0., s2 = 0.;
+    for (int i = p0 + slice; i < p1; i += RS_SL) {
+        const size_t o = base + (size_t)i * C;
+        const float g = (y && !(y[o] > 0.f)) ? 0.f : dy[o];
+        s1 += g;
+        s2 += (double)g * ((x[o] - st.x) * st.y);
+    }
+    sh[0][slice][cl] = s1;
+    sh[1][slice][cl] = s2;
+    __syncthreads();
+    if (slice == 0) {
+        s1 = s2 = 0.;
+        for (int k = 0; k < RS_SL; ++k) {
+            s1 += sh[0][k][cl];
+            s2 += sh[1][k][cl];
+        }
+        double *o = part + (((size_t)n * S + sb) * C + c) * 2;
+        o[0] = s1;
+        o[1] = s2;
+    }
+}
+__global__ __launch_bounds__(256) void in_sums_final_kernel(const double *__restrict__ part, int N, int C, int S,
+                                                            float2 *__restrict__ sums)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    double s1 = 0., s2 = 0.;
+    for (int k = 0; k < S; ++k) {
+        const double *o = part + (((size_t)n * S + k) * C + c) * 2;
+        s1 += o[0];
+        s2 += o[1];
+    }
+    sums[i] = make_float2((float)s1, (float)s2);
+}
+inline int in_slabs(int N, int C, int HW)
+{
+    // enough workgroups to fill the chip (~1024), at least 1024 pixels per slab, at most 64 slabs
+    long S = 1024 / ((long)(C / RS_CH) * N);
+    if (S > HW / 1024) S = HW / 1024;
+    if (S > 64) S = 64;
+    return S < 1 ? 1 : (int)S;
+}
+
 // ---- bilinear grid_sample (zeros padding), NHWC: y[n][p][c] = sum_tap w_tap * x[n or 0][tap][c]
 __global__ __launch_bounds__(256) void grid_sample_nhwc_kernel(const float *__restrict__ x, const float *__restrict__ grid, int xn,
                                                                int C, int H, int W, int Ho, int Wo, int align_corners, long total,
@@ -1069,15 +1167,30 @@ int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const f
 
 /* InstanceNorm2d(affine=True, eps 1e-5, biased variance) [+ ReLU], NHWC fp32.  stats: (N, C) float2 (mean, rstd), written by
  * forward and read by backward. */
-int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float *gamma, const float *beta, int relu, float *y,
-                              float *stats, lwg_stream_t stream)
+size_t lwg_instance_norm_scratch_bytes(int N, int HW, int C)
 {
-    LWG_REQUIRE(x && gamma && beta && y && stats, "instance_norm_forward: NULL argument");
+    if (N < 1 || HW < 1 || C < RS_CH) return 0;
+    return (size_t)N * in_slabs(N, C, HW) * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float);
+}
+
+int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float *gamma, const float *beta, int relu, float *y,
+                              float *stats, void *scratch, lwg_stream_t stream)
+{
+    LWG_REQUIRE(x && gamma && beta && y && stats && scratch, "instance_norm_forward: NULL argument");
     if (C % RS_CH) LWG_FAIL(LWG_ERR_UNSUPPORTED, "instance_norm: C=%d must be a multiple of %d", C, RS_CH);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float2 *s2 = reinterpret_cast<float2 *>(stats);
-    in_stats_kernel<<<dim3(C / RS_CH, N), 256, 0, st>>>(x, HW, C, s2);
-    LWG_LAUNCH_CHECK("in_stats_kernel");
+    const int S = in_slabs(N, C, HW);
+    if (S == 1) {
+        in_stats_kernel<<<dim3(C / RS_CH, N), 256, 0, st>>>(x, HW, C, s2);
+        LWG_LAUNCH_CHECK("in_stats_kernel");
+    } else {
+        double *part = static_cast<double *>(scratch);
+        in_stats_partial_kernel<<<dim3(C / RS_CH, N, S), 256, 0, st>>>(x, HW, C, S, part);
+        LWG_LAUNCH_CHECK("in_stats_partial_kernel");
+        in_stats_final_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, N, C, S, HW, s2);
+        LWG_LAUNCH_CHECK("in_stats_final_kernel");
+    }
     const long total = (long)N * HW * C;
     in_apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(x, s2, gamma, beta, relu, HW, C, total, y);
     LWG_LAUNCH_CHECK("in_apply_kernel");
@@ -1087,15 +1200,24 @@ int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float 
 /* y: the forward output when it went through the ReLU (its sign is the mask), NULL without activation.
  * scratch: (N, C) float2.  dgamma / dbeta: (C,), overwritten. */
 int lwg_instance_norm_backward(const float *x, const float *y, const float *dy, const float *stats, const float *gamma, int N,
-                               int HW, int C, float *dx, float *dgamma, float *dbeta, float *scratch, lwg_stream_t stream)
+                               int HW, int C, float *dx, float *dgamma, float *dbeta, void *scratch, lwg_stream_t stream)
 {
     LWG_REQUIRE(x && dy && stats && gamma && dx && dgamma && dbeta && scratch, "instance_norm_backward: NULL argument");
     if (C % RS_CH) LWG_FAIL(LWG_ERR_UNSUPPORTED, "instance_norm: C=%d must be a multiple of %d", C, RS_CH);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float2 *s2 = reinterpret_cast<const float2 *>(stats);
-    float2 *sums = reinterpret_cast<float2 *>(scratch);
-    in_affine_bwd_reduce_kernel<<<dim3(C / RS_CH, N), 256, 0, st>>>(x, y, dy, s2, HW, C, sums);
-    LWG_LAUNCH_CHECK("in_affine_bwd_reduce_kernel");
+    const int S = in_slabs(N, C, HW);
+    double *part = static_cast<double *>(scratch);
+    float2 *sums = reinterpret_cast<float2 *>(part + (size_t)N * S * C * 2);
+    if (S == 1) {
+        in_affine_bwd_reduce_kernel<<<dim3(C / RS_CH, N), 256, 0, st>>>(x, y, dy, s2, HW, C, sums);
+        LWG_LAUNCH_CHECK("in_affine_bwd_reduce_kernel");
+    } else {
+        in_affine_bwd_partial_kernel<<<dim3(C / RS_CH, N, S), 256, 0, st>>>(x, y, dy, s2, HW, C, S, part);
+        LWG_LAUNCH_CHECK("in_affine_bwd_partial_kernel");
+        in_sums_final_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, N, C, S, sums);
+        LWG_LAUNCH_CHECK("in_sums_final_kernel");
+    }
     const long total = (long)N * HW * C;
     in_affine_bwd_apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(x, y, dy, s2, sums, gamma, HW, C, total, dx);
     LWG_LAUNCH_CHECK("in_affine_bwd_apply_kernel");

@@ -1,15 +1,16 @@
-"""Training model -- the first slice of SURVEY.md 8f row 4: everything of a training iteration except the generator's
-own update.
+"""Training model: one training iteration of the reference on MI355X.
 
 Mirrors the reference's training model (models/impersonator_trainer.py, class Impersonator): `_create_generator` /
 `_create_discriminator` (:215-222), the Adam settings of `_init_train_vars` (:224-232), `forward` (:329-348: the
-three-stream generator pass and the background blends), `_optimize_D` (:396-411) and `_compute_loss_D` (:413-414).
-The generator-side update (backward through the ResUnet, the Liquid Warping Block and the blends, VGG / face losses
-with their absent pretrained nets) is not implemented yet; asking for it fails loudly."""
+three-stream generator pass and the background blends), `optimize_parameters` (:350-366), `_optimize_G` (:368-394) and
+`_optimize_D` (:396-414).  The generator update is models/generator_trainer.py (hand-written backward pass on the
+op-level HIP kernels), the discriminator update networks/discriminator.py.  Loss terms that need a downloaded network
+(--use_vgg, --use_style, --use_face: VGG19, SphereFace) are not available and fail loudly."""
 import torch
 
 from ..networks.discriminator import PatchDiscriminator
 from ..networks.generator import ImpersonatorGenerator
+from .generator_trainer import GeneratorTrainer
 from .models import BaseModel
 
 
@@ -27,6 +28,26 @@ class Impersonator(BaseModel):
         self._input_G_bg = self._input_G_src = self._input_G_tsf = self._T = None
         self._real_tsf = None
         self._d_loss = None
+        for flag in ('use_vgg', 'use_style', 'use_face'):
+            if getattr(opt, flag, False):
+                raise NotImplementedError("--%s needs a pretrained network that is a download of the reference" % flag)
+        self._g_trainer = None
+        self._real_src = self._bg_mask = None
+
+    def _generator_trainer(self):
+        if self._g_trainer is None:
+            o = self._opt
+            self._g_trainer = GeneratorTrainer(
+                self._G, self._D, lambda_D_prob=getattr(o, 'lambda_D_prob', 1), lambda_rec=getattr(o, 'lambda_rec', 10),
+                lambda_tsf=getattr(o, 'lambda_tsf', 10), lambda_mask=getattr(o, 'lambda_mask', 0.1),
+                lambda_mask_smooth=getattr(o, 'lambda_mask_smooth', 1e-5), lr=getattr(o, 'lr_G', 0.0002),
+                betas=(getattr(o, 'G_adam_b1', 0.5), getattr(o, 'G_adam_b2', 0.999)))
+        return self._g_trainer
+
+    def sync_generator(self):
+        """Trained parameters -> the inference generator (self._G), e.g. before saving a checkpoint or running Imitator."""
+        if self._g_trainer is not None:
+            self._G.load_state_dict(self._g_trainer.state_dict())
 
     def _create_generator(self):
         # impersonator_trainer.py:215-217
@@ -40,12 +61,13 @@ class Impersonator(BaseModel):
                                   n_layers=4, use_sigmoid=False, image_size=self._opt.image_size,
                                   max_batch=getattr(self._opt, 'batch_size', 4)).cuda()
 
-    def set_input(self, input_G_tsf, real_tsf, input_G_bg=None, input_G_src=None, T=None):
+    def set_input(self, input_G_tsf, real_tsf, input_G_bg=None, input_G_src=None, T=None, real_src=None, bg_mask=None):
         """The tensors a training iteration reads (impersonator_trainer.py:300-319), as the reference's BodyRecoveryFlow
         (`self._bdr`) produces them: the generator inputs of the three streams, the flow T and the real target image.
         `_optimize_D` alone needs input_G_tsf and real_tsf."""
         self._input_G_tsf, self._real_tsf = input_G_tsf, real_tsf
         self._input_G_bg, self._input_G_src, self._T = input_G_bg, input_G_src, T
+        self._real_src, self._bg_mask = real_src, bg_mask
 
     @torch.no_grad()
     def forward(self, keep_data_for_visuals=False, return_estimates=False):
@@ -75,6 +97,13 @@ class Impersonator(BaseModel):
         self._d_loss = self._D.optimize_D(real_input_D, fake_input_D, lr=self._current_lr_D, betas=self._D_betas)
         return self._d_loss
 
-    def optimize_parameters(self, *args, **kwargs):
-        raise NotImplementedError("generator-side training is not implemented yet (SURVEY.md 8f row 4); "
-                                  "the discriminator update is available as _optimize_D")
+    def optimize_parameters(self, trainable=True, keep_data_for_visuals=False):
+        """impersonator_trainer.py:350-366: generator pass, generator update, then (trainable) the discriminator update on
+        the images the generator produced before its update.  Returns the loss terms."""
+        batch = dict(input_G_bg=self._input_G_bg, input_G_src=self._input_G_src, input_G_tsf=self._input_G_tsf, T=self._T,
+                     real_src=self._real_src, real_tsf=self._real_tsf, bg_mask=self._bg_mask)
+        terms, (_, _, fake_tsf_imgs, _) = self._generator_trainer().optimize_G(batch)
+        losses = {k: float(v) for k, v in terms.items()}
+        if trainable:
+            losses['d_loss'] = float(self._optimize_D(fake_tsf_imgs))
+        return losses

@@ -31,7 +31,7 @@ def _out_hw(h, w, k, stride, pad, transposed):
 
 def _chk(*ts):
     for t in ts:
-        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        if t is not None and not (t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous()):
             raise RuntimeError("lwg ops take contiguous float32 CUDA tensors (no CPU fallback)")
 
 
@@ -83,8 +83,9 @@ def instance_norm_forward(x, gamma, beta, relu=False):
     n, h, w, c = x.shape
     y = torch.empty_like(x)
     stats = torch.empty((n, c, 2), device=x.device, dtype=torch.float32)
+    scratch = torch.empty(_lib.load().lwg_instance_norm_scratch_bytes(n, h * w, c) // 8 + 1, device=x.device, dtype=torch.float64)
     _lib.check(_lib.load().lwg_instance_norm_forward(_lib.ptr(x), n, h * w, c, _lib.ptr(gamma), _lib.ptr(beta), int(relu),
-                                                     _lib.ptr(y), _lib.ptr(stats), _lib.stream_ptr()))
+                                                     _lib.ptr(y), _lib.ptr(stats), _lib.ptr(scratch), _lib.stream_ptr()))
     return y, stats
 
 
@@ -96,7 +97,7 @@ def instance_norm_backward(x, y, dy, stats, gamma):
     dx = torch.empty_like(x)
     dgamma = torch.empty(c, device=x.device, dtype=torch.float32)
     dbeta = torch.empty(c, device=x.device, dtype=torch.float32)
-    scratch = torch.empty((n, c, 2), device=x.device, dtype=torch.float32)
+    scratch = torch.empty(_lib.load().lwg_instance_norm_scratch_bytes(n, h * w, c) // 8 + 1, device=x.device, dtype=torch.float64)
     _lib.check(_lib.load().lwg_instance_norm_backward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), _lib.ptr(stats), _lib.ptr(gamma), n,
                                                       h * w, c, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(scratch),
                                                       _lib.stream_ptr()))

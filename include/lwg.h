@@ -272,12 +272,14 @@ LWG_API int lwg_grid_sample_nhwc(const float *x, int xn, int C, int H, int W, co
 
 /* InstanceNorm2d(affine=True, eps 1e-5, biased variance) [+ ReLU] and its gradient, NHWC fp32 (x: (N,HW,C)).
  * stats: (N,C,2) floats (mean, rstd) written by forward, read by backward.  backward: y = the forward output when it
- * went through the ReLU (its sign is the mask) or NULL; scratch (N,C,2) floats; dgamma/dbeta (C,) overwritten. */
+ * went through the ReLU (its sign is the mask) or NULL; dgamma/dbeta (C,) overwritten.  scratch: device memory of
+ * lwg_instance_norm_scratch_bytes(N, HW, C) bytes (8-byte aligned; slab partial sums of the two-stage reductions). */
+LWG_API size_t lwg_instance_norm_scratch_bytes(int N, int HW, int C);
 LWG_API int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float *gamma, const float *beta, int relu,
-                                      float *y, float *stats, lwg_stream_t stream);
+                                      float *y, float *stats, void *scratch, lwg_stream_t stream);
 LWG_API int lwg_instance_norm_backward(const float *x, const float *y, const float *dy, const float *stats,
                                        const float *gamma, int N, int HW, int C, float *dx, float *dgamma, float *dbeta,
-                                       float *scratch, lwg_stream_t stream);
+                                       void *scratch, lwg_stream_t stream);
 /* Gradient of bilinear grid_sample (zeros padding) wrt its input, NHWC: dy (n,Ho,Wo,C), grid (n,Ho,Wo,2) ->
  * dx (xn,H,W,C) ACCUMULATED (zero it first), xn in {1, n}.  Atomic fp32 adds (not bit-reproducible, as torch's). */
 LWG_API int lwg_grid_sample_backward(const float *dy, const float *grid, int xn, int C, int H, int W, int n, int Ho, int Wo,

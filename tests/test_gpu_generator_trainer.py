@@ -86,3 +86,27 @@ def test_adam_step(setup):
         if not bool(big.any()):
             continue
         assert float((mine[k] - v).abs()[big].max()) < 0.2 * 0.0002, k
+
+
+def test_trainer_mirror_full_iteration(setup):
+    """models/impersonator_trainer.py::optimize_parameters (impersonator_trainer.py:350-366): generator update, then the
+    discriminator update on the images produced before it."""
+    import types
+    from impersonator_amd.models.impersonator_trainer import Impersonator
+    opt = types.SimpleNamespace(image_size=64, batch_size=2, map_name='uv_seg', norm_type='instance', repeat_num=6, is_train=True)
+    model = Impersonator(opt)
+    model._G.load_state_dict(setup["gsd"])
+    model._D.load_state_dict(setup["dsd"])
+    b = {k: v.cuda() for k, v in setup["batch"].items()}
+    model.set_input(b["input_G_tsf"], b["real_tsf"], input_G_bg=b["input_G_bg"], input_G_src=b["input_G_src"], T=b["T"],
+                    real_src=b["real_src"], bg_mask=b["bg_mask"])
+    losses = model.optimize_parameters()
+    for k, v in setup["hist"][0].items():
+        assert abs(losses[k] - v) < 1e-3 * max(1.0, abs(v)), k
+    with torch.no_grad():
+        _, _, (_, _, fake_tsf, _) = torch_ref.generator_train_loss(setup["gsd"], setup["dsd"], setup["batch"])
+        cond = setup["batch"]["input_G_tsf"][:, 3:]
+        d_ref = torch_ref.discriminator_loss(setup["dsd"], torch.cat([setup["batch"]["real_tsf"], cond], 1), torch.cat([fake_tsf, cond], 1))
+    assert abs(losses["d_loss"] - float(d_ref)) < 2e-3 * max(1.0, float(d_ref))
+    model.sync_generator()
+    assert float((model._G.state_dict()["tsf_model.img_reg.0.weight"].cpu() - setup["gsd"]["tsf_model.img_reg.0.weight"]).abs().max()) > 1e-5
