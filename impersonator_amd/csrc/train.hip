@@ -183,50 +183,62 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restr
 // wants from one ds_read_b32 per lane (A: lane -> channel co, k = pixel pair; B: lane -> channel ci), so the tiles go
 // to LDS as loaded, no transpose.  Workgroup = 64 co x 64 ci of one tap over a slice of the pixels, four waves of
 // 32 x 32; the slices' partial results are summed in a fixed order by reduce_slices_kernel (deterministic).
-constexpr int WG_PX = 32, WG_PITCH = 64 + 4;
-// KWd x (ntaps / KWd) filter taps; oihw = 0: out[slice][Cout][ntaps][Cin] (matrix layout), 1: out[slice][Cout][Cin][ntaps]
+constexpr int WG_PX = 32;
+// KWd x (ntaps / KWd) filter taps; oihw = 0: out[slice][Cout][ntaps][Cin] (matrix layout), 1: out[slice][Cout][Cin][ntaps].
+// T = 64: four waves of one 32x32 tile; T = 128 (both channel counts multiples of 128): four waves of 2x2 tiles -- four
+// times the MFMA work per byte staged through LDS.
+template <int T>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dy, int Cout, const float *__restrict__ x,
                                                     int Cin, int N, int H, int W, int Ho, int Wo, int stride, int pad,
                                                     long px_per_slice, float *__restrict__ out, int KWd, int ntaps, int oihw)
 {
-    __shared__ __attribute__((aligned(16))) float sA[2][WG_PX][WG_PITCH], sB[2][WG_PX][WG_PITCH];
+    constexpr int PITCH = T + 4, TW = T / 64, NV = T / 32;   // LDS row pitch; MFMA tiles per wave and side; float4 per thread and operand
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float *sA = wsm, *sB = wsm + 2 * WG_PX * PITCH;          // [2][WG_PX][PITCH] each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+    const int ci0 = blockIdx.x * T, co0 = blockIdx.y * T;
     const int tap = blockIdx.z % ntaps, slice = blockIdx.z / ntaps;
     const int kh = tap / KWd, kw = tap - kh * KWd;
     const long P = (long)N * Ho * Wo;
     const long p0 = slice * px_per_slice, p1 = p0 + px_per_slice < P ? p0 + px_per_slice : P;
 
-    const int lrow = tid >> 3, lcol = (tid & 7) * 4;     // loader: 32 pixel rows x 8 float4, two column halves
-    float4 ra[2], rb[2];
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;     // loader: 32 pixel rows x 8 float4, NV column groups of 32
+    float4 ra[NV], rb[NV];
     auto load = [&](long pc) {
         const long p = pc + lrow;
-        ra[0] = ra[1] = rb[0] = rb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) ra[v] = rb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < p1) {
             const float *d = dy + (size_t)p * Cout + co0 + lcol;
-            ra[0] = ld4(d);
-            ra[1] = ld4(d + 32);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ra[v] = ld4(d + 32 * v);
             const int n = (int)(p / ((long)Ho * Wo));
             const int rem = (int)(p - (long)n * Ho * Wo);
             const int oh = rem / Wo, ow = rem - oh * Wo;
             const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
             if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
                 const float *s = x + (((size_t)n * H + ih) * W + iw) * Cin + ci0 + lcol;
-                if (ci0 + lcol < Cin) rb[0] = ld4(s);
-                if (ci0 + lcol + 32 < Cin) rb[1] = ld4(s + 32);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (ci0 + lcol + 32 * v < Cin) rb[v] = ld4(s + 32 * v);
             }
         }
     };
     auto store = [&](int buf) {
-        *reinterpret_cast<float4 *>(&sA[buf][lrow][lcol]) = ra[0];
-        *reinterpret_cast<float4 *>(&sA[buf][lrow][lcol + 32]) = ra[1];
-        *reinterpret_cast<float4 *>(&sB[buf][lrow][lcol]) = rb[0];
-        *reinterpret_cast<float4 *>(&sB[buf][lrow][lcol + 32]) = rb[1];
-    };
-    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int v = 0; v < NV; ++v) {
+            *reinterpret_cast<float4 *>(sA + (buf * WG_PX + lrow) * PITCH + lcol + 32 * v) = ra[v];
+            *reinterpret_cast<float4 *>(sB + (buf * WG_PX + lrow) * PITCH + lcol + 32 * v) = rb[v];
+        }
+    };
+    f32x16 acc[TW][TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     int buf = 0;
     if (p0 < p1) {
@@ -239,24 +251,74 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dy
         if (more) load(pc + WG_PX);
 #pragma unroll
         for (int kk = 0; kk < WG_PX / 2; ++kk) {
-            const float av = sA[buf][2 * kk + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float bv = sB[buf][2 * kk + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            const float *ar = sA + (buf * WG_PX + 2 * kk + (lane >> 5)) * PITCH + wm * 32 * TW + (lane & 31);
+            const float *br = sB + (buf * WG_PX + 2 * kk + (lane >> 5)) * PITCH + wn * 32 * TW + (lane & 31);
+            float av[TW], bv[TW];
+#pragma unroll
+            for (int i = 0; i < TW; ++i) {
+                av[i] = ar[32 * i];
+                bv[i] = br[32 * i];
+            }
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (more) store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
     // C/D layout: col = lane&31 -> ci, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> co
-    const int ci = ci0 + wn * 32 + (lane & 31);
-    if (ci < Cin) {
-        float *o = out + (size_t)slice * Cout * ntaps * Cin;
+    float *o = out + (size_t)slice * Cout * ntaps * Cin;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (co < Cout) o[oihw ? ((size_t)co * Cin + ci) * ntaps + tap : ((size_t)co * ntaps + tap) * Cin + ci] = acc[r];
-        }
+    for (int j = 0; j < TW; ++j) {
+        const int ci = ci0 + (wn * TW + j) * 32 + (lane & 31);
+        if (ci >= Cin) continue;
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * TW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < Cout) o[oihw ? ((size_t)co * Cin + ci) * ntaps + tap : ((size_t)co * ntaps + tap) * Cin + ci] = acc[i][j][r];
+            }
     }
+}
+
+// launcher: picks the tile, the pixel slices (split-K) and the partial buffer.  `part` must hold 32 * Cout*ntaps*Cin floats
+// (at most 32 slices); the result lands in `out`.
+int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin, int Win, int Hg, int Wg, int stride, int pad,
+                 int KWd, int ntaps, int oihw, float *out, float *part, size_t part_floats, hipStream_t st)
+{
+    const long P = (long)N * Hg * Wg;
+    const size_t w_floats = (size_t)O * ntaps * I;
+    const int T = (O % 128 == 0 && I % 128 == 0) ? 128 : 64;
+    const long tiles = (long)(O / T) * ceil_div(I, T) * ntaps;
+    long S = ceil_div(512, tiles);
+    if (S > 32) S = 32;
+    if (S > ceil_div(P, WG_PX)) S = ceil_div(P, WG_PX);
+    const long per = ceil_div(ceil_div(P, S), WG_PX) * (long)WG_PX;
+    S = ceil_div(P, per);
+    if (S > 1 && (size_t)S * w_floats > part_floats) LWG_FAIL(LWG_ERR_STATE, "wgrad: partial buffer too small");
+    float *wout = S == 1 ? out : part;
+    const dim3 grid(ceil_div(I, T), O / T, (unsigned)(ntaps * S));
+    const size_t lds = (size_t)4 * WG_PX * (T + 4) * sizeof(float);
+    if (T == 128) {
+        static bool opt_in = false;
+        if (!opt_in) {
+            LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+            opt_in = true;
+        }
+        wgrad_kernel<128><<<grid, 256, lds, st>>>(go, O, in, I, N, Hin, Win, Hg, Wg, stride, pad, per, wout, KWd, ntaps, oihw);
+    } else {
+        wgrad_kernel<64><<<grid, 256, lds, st>>>(go, O, in, I, N, Hin, Win, Hg, Wg, stride, pad, per, wout, KWd, ntaps, oihw);
+    }
+    LWG_LAUNCH_CHECK("wgrad_kernel");
+    if (S > 1) {
+        reduce_slices_kernel<<<ceil_div((long)w_floats, 256), 256, 0, st>>>(part, (int)S, (long)w_floats, out);
+        LWG_LAUNCH_CHECK("reduce_slices_kernel");
+    }
+    return LWG_OK;
 }
 
 // ---- data-gradient weight matrices from the master copy W[co][kh*4+kw][ci] (run after every optimiser step).
@@ -803,7 +865,8 @@ int lwg_discriminator_create(lwg_discriminator **out, int input_nc, int ndf, int
     size_t part_cap = 0;
     for (const DLayer &L : d->L) {
         const long P = (long)B * L.Ho * L.Ho;
-        const long tiles = (long)(L.cout_pad / 64) * ceil_div(L.cin_pad, 64) * 16;
+        const int T = (L.cout_pad % 128 == 0 && L.cin_pad % 128 == 0) ? 128 : 64;   // as launch_wgrad
+        const long tiles = (long)(L.cout_pad / T) * ceil_div(L.cin_pad, T) * 16;
         long S = ceil_div(512, tiles);
         if (S > 32) S = 32;
         if (S > ceil_div(P, WG_PX)) S = ceil_div(P, WG_PX);
@@ -951,21 +1014,9 @@ int lwg_discriminator_backward(lwg_discriminator *d, const float *real_nchw, con
         LWG_LAUNCH_CHECK("reduce_slices_kernel");
         // weight gradient
         const float *xin = l == 0 ? d->x0 : (d->L[l - 1].act ? d->L[l - 1].actv : d->L[l - 1].raw);
-        const long tiles = (long)(L.cout_pad / 64) * ceil_div(L.cin_pad, 64) * 16;
-        long S = ceil_div(512, tiles);
-        if (S > 32) S = 32;
-        if (S > ceil_div(P, WG_PX)) S = ceil_div(P, WG_PX);
-        const long per = ceil_div(ceil_div(P, S), WG_PX) * (long)WG_PX;
-        S = ceil_div(P, per);
-        if ((size_t)S * L.w_floats > d->part_floats) LWG_FAIL(LWG_ERR_STATE, "wgrad: partial buffer too small");
-        float *wout = S == 1 ? d->grads + L.w_off : d->part;
-        const dim3 grid(ceil_div(L.cin_pad, 64), L.cout_pad / 64, (unsigned)(16 * S));
-        wgrad_kernel<<<grid, 256, 0, st>>>(L.draw, L.cout_pad, xin, L.cin_pad, B, L.Hin, L.Hin, L.Ho, L.Ho, L.stride, 1, per, wout, 4, 16, 0);
-        LWG_LAUNCH_CHECK("wgrad_kernel");
-        if (S > 1) {
-            reduce_slices_kernel<<<ceil_div((long)L.w_floats, 256), 256, 0, st>>>(d->part, (int)S, (long)L.w_floats, d->grads + L.w_off);
-            LWG_LAUNCH_CHECK("reduce_slices_kernel");
-        }
+        if ((rc = launch_wgrad(L.draw, L.cout_pad, xin, L.cin_pad, B, L.Hin, L.Hin, L.Ho, L.Ho, L.stride, 1, 4, 16, 0,
+                               d->grads + L.w_off, d->part, d->part_floats, st)) != LWG_OK)
+            return rc;
         if (l > 0 && (rc = d_conv_dgrad(d, l, B, st)) != LWG_OK) return rc;
     }
     return LWG_OK;
@@ -1140,20 +1191,7 @@ int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const f
     const int stride = d->transposed ? 2 : d->stride, pad = d->pad, taps = d->k * d->k;
     if (O % 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_weight: needs a multiple of 64 channels on the gradient side, got %d", O);
     const long P = (long)d->N * Hg * Wg;
-    const long tiles = (long)(O / 64) * ceil_div(I, 64) * taps;
-    long S = ceil_div(512, tiles);
-    if (S > 32) S = 32;
-    if (S > ceil_div(P, WG_PX)) S = ceil_div(P, WG_PX);
-    const long per = ceil_div(ceil_div(P, S), WG_PX) * (long)WG_PX;
-    S = ceil_div(P, per);
-    float *wout = S == 1 ? dw : part;
-    const dim3 grid(ceil_div(I, 64), O / 64, (unsigned)(taps * S));
-    wgrad_kernel<<<grid, 256, 0, st>>>(go, O, in, I, d->N, Hin, Win, Hg, Wg, stride, pad, per, wout, d->k, taps, 1);
-    LWG_LAUNCH_CHECK("wgrad_kernel");
-    if (S > 1) {
-        reduce_slices_kernel<<<ceil_div((long)g.w_floats, 256), 256, 0, st>>>(part, (int)S, (long)g.w_floats, dw);
-        LWG_LAUNCH_CHECK("reduce_slices_kernel");
-    }
+    if ((rc = launch_wgrad(go, O, in, I, d->N, Hin, Win, Hg, Wg, stride, pad, d->k, taps, 1, dw, part, 32 * g.w_floats, st)) != LWG_OK) return rc;
     if (dbias) {
         if (d->transposed) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_weight: bias gradient of a transposed conv");
         float *cs = part + 32 * g.w_floats;
