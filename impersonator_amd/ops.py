@@ -31,7 +31,7 @@ def _out_hw(h, w, k, stride, pad, transposed):
 
 def _chk(*ts):
     for t in ts:
-        if t is not None and not (t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous()):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError("lwg ops take contiguous float32 CUDA tensors (no CPU fallback)")
 
 
