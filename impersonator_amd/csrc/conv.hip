@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
     constexpr int Q = 6 * TILES;                          // MFMAs of a wave per stage
     static_assert(Q % LPS == 0, "DMA pieces must spread evenly over the MFMAs of a stage");
     constexpr int QP = Q / LPS;
-    constexpr int QB = Q * 3 / 4;                         // stage barrier before this MFMA
+    constexpr int QB = Q * 3 / 4;                         // stage barrier before this MFMA (2/3 measured no better)
     constexpr int ISSUED = QB / QP;                       // pieces of the stage already issued by then
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -751,13 +751,25 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
             f.bl[j] = *reinterpret_cast<const float4 *>(Bs + j * 32 * BK + cl);
         }
     };
+    // one fragment register of load_frags, in the order the products consume them (lo(A), hi(B) first)
+    auto load_one = [&](int slot, int kb, Frags &f, int idx) {
+        const float *As = smem + slot * STAGE + a_row;
+        const float *Bs = smem + slot * STAGE + b_row;
+        const int ch = fcol[kb], cl = fcol[2 + kb];
+        if (idx < WM) f.al[idx] = *reinterpret_cast<const float4 *>(As + idx * 32 * BK + cl);
+        else if (idx < WM + WN) f.bh[idx - WM] = *reinterpret_cast<const float4 *>(Bs + (idx - WM) * 32 * BK + ch);
+        else if (idx < 2 * WM + WN) f.ah[idx - WM - WN] = *reinterpret_cast<const float4 *>(As + (idx - WM - WN) * 32 * BK + ch);
+        else f.bl[idx - 2 * WM - WN] = *reinterpret_cast<const float4 *>(Bs + (idx - 2 * WM - WN) * 32 * BK + cl);
+    };
+    constexpr int NL = 2 * (WM + WN);
+    constexpr int RPM = (NL + (Q - QB) - 1) / (Q - QB);   // next-stage reads per MFMA after the barrier
     Frags fr;   // k-block-0 fragments of the stage about to run (fetched during the previous stage)
 
     auto stage_body = [&](int kt, auto slot_c, auto do_dma) {
         constexpr int slot = decltype(slot_c)::value;
         constexpr int slot1 = (slot + 1) % NS, slot2 = (slot + NS - 1) % NS;
         Frags f1, nx;
-        if (!(DBG & 8)) load_frags(slot, 1, f1);
+        if (DBG & 256) load_frags(slot, 1, f1);   // ablation: the reads in two bulk groups ahead of the MFMAs (2-3% slower)
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int kb = q / (3 * TILES), r = q % (3 * TILES);
@@ -773,14 +785,32 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
                 }
                 if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (!(DBG & 8)) load_frags(slot1, 0, nx);
-                __builtin_amdgcn_sched_barrier(0);
+                if (DBG & 256) {
+                    load_frags(slot1, 0, nx);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             const Frags &f = kb == 0 ? fr : f1;
             const float4 a4 = t == 0 ? f.al[i] : f.ah[i];
             const float4 b4 = t == 1 ? f.bl[j] : f.bh[j];
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a4),
                                                                 __builtin_bit_cast(bf16x8_t, b4), acc[i][j], 0, 0, 0);
+            if (!(DBG & 8) && !(DBG & 256)) {
+                // fragment reads ride behind the MFMAs, one or two each, so the matrix pipe never waits for a burst of
+                // LDS issue slots: k-block 1 of this stage behind the first NL products, k-block 0 of the next stage
+                // behind the first ones after the barrier
+                if (q < NL) {
+                    load_one(slot, 1, f1, q);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                } else if (q >= QB && RPM * (q - QB) < NL) {
+#pragma unroll
+                    for (int r2 = 0; r2 < RPM; ++r2)
+                        if (RPM * (q - QB) + r2 < NL) load_one(slot1, 0, nx, RPM * (q - QB) + r2);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+                }
+            }
             if (decltype(do_dma)::value && q % QP == QP - 1 && !(DBG & 1)) {
                 __builtin_amdgcn_sched_barrier(0);
                 dma_piece(q / QP, kt + (NS - 1), slot2);
@@ -1304,6 +1334,7 @@ int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
         case 232: launch_k_dbg<3, 32>(a, bn, st); break;  // no epilogue
         case 264: launch_k_dbg<3, 64>(a, bn, st); break;  // natural tile order (no XCD bands)
         case 328: launch_k_dbg<3, 128>(a, bn, st); break; // 4-byte epilogue stores
+        case 456: launch_k_dbg<3, 256>(a, bn, st); break; // fragment reads in two bulk groups
         case 0: launch_dbg<0>(a, bn, st); break;
         case 1: launch_dbg<1>(a, bn, st); break;
         case 3: launch_dbg<3>(a, bn, st); break;

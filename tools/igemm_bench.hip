@@ -24,7 +24,7 @@ int main(int argc, char **argv)
         {"skip2 128->64 @256 (bn64)", 8, 256, 128, 64, 3, 1, 64},
         {"enc3 256->512 s2 @64 (bn64)", 8, 64, 256, 512, 3, 2, 64},
     };
-    const int dbgs[] = {100, 200, 264, 232, 201, 213, 200};
+    const int dbgs[] = {100, 200, 456, 264, 232, 201, 213, 200};
     hipStream_t st;
     hipStreamCreate(&st);
     hipEvent_t e0, e1;
