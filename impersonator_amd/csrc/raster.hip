@@ -8,8 +8,8 @@
 // Design (MI355X-first, not a translation): the reference tests 65536 x 13776 pixel/face pairs per frame.
 // SMPL faces cover ~2 pixels each, so this implementation is FACE-parallel:
 //   1. face kernel   : one lane per (frame, face): cull, inverse matrix, conservative pixel bounding box;
-//                      faces with a small box are scan-converted by their own lane, larger ones are queued;
-//   2. large kernel  : one 256-lane workgroup per queued face sweeps its box;
+//                      faces with a small box are scan-converted by their own lane,
+//   2.                 larger ones are parked in the workgroup's LDS and swept by its 256 lanes after a barrier;
 //   3. both resolve visibility with ONE 64-bit atomicMin per covering pixel on the key
 //                      (orderable(zp) << 32 | face_id) -- the lexicographic minimum is exactly the reference's
 //                      "strictly smaller depth, lowest face index wins ties" rule (hazard H6) independent of
@@ -33,7 +33,6 @@ namespace {
 
 constexpr unsigned long long kKeyEmpty = ~0ull;
 constexpr int kInlineBoxMax = 64;     // boxes up to this many pixels are scan-converted by the face's lane
-constexpr int kLargeGrid = 2048;      // workgroups of the queued-face kernel (grid-stride over the queue)
 constexpr float kSliverRatio = 1e-4f; // |2*area| / extent^2 below this => ill-conditioned => full sweep
 constexpr float kHugeCoord = 1.0e6f;  // pixel coordinates beyond this => full sweep
 
@@ -107,94 +106,112 @@ __device__ __forceinline__ float bary_depth(const float v[9], const float inv[9]
     return (float)(1. / (double)(w[0] / v[2] + w[1] / v[5] + w[2] / v[8]));
 }
 
-__device__ __forceinline__ void shade_pixel(const float v[9], const float inv[9], int fn, int xi, int yi, int is,
-                                            float near_z, float far_z, unsigned long long *__restrict__ keys)
+// Returns the key the pixel held before (all-ones when nothing was written): the callers fold it into a value the
+// kernel's last instructions depend on, which makes every atomic a *returning* one the wave has to wait for.  A
+// fire-and-forget atomicMin could still be on its way to memory when the kernel was reported complete, and land
+// after the next frame's clear had reset that key (seen with other kernels loading the fabric from a second and
+// third stream: a 16-pixel run -- one 128-byte request -- of the previous batch's hidden face showing through).
+__device__ __forceinline__ unsigned long long shade_pixel(const float v[9], const float inv[9], int fn, int xi, int yi,
+                                                          int is, float near_z, float far_z,
+                                                          unsigned long long *__restrict__ keys)
 {
     const float xp = pixel_centre(xi, is), yp = pixel_centre(yi, is);
-    if (!inside(v, xp, yp)) return;
+    if (!inside(v, xp, yp)) return kKeyEmpty;
     float w[3];
     const float zp = bary_depth(v, inv, xi, yi, w);
     // .cu:154-159: reject zp <= near, far <= zp; depth_min starts at far, so NaN never wins either
-    if (!(zp > near_z && zp < far_z)) return;
+    if (!(zp > near_z && zp < far_z)) return kKeyEmpty;
     const unsigned long long key = ((unsigned long long)order_bits(zp) << 32) | (unsigned)fn;
-    atomicMin(keys + (size_t)yi * is + xi, key);
+    return atomicMin(keys + (size_t)yi * is + xi, key);
 }
 
+// One lane per face: inverse matrix, culling, conservative box.  Small boxes are scan-converted by the lane itself;
+// faces with a larger box are parked in the workgroup's own LDS list and, after a barrier, swept by all 256 lanes of
+// that workgroup.  (An earlier version handed the large faces to a second kernel through a queue in the workspace;
+// keeping them inside the workgroup drops that launch and every cross-kernel read of queue state.)
 __global__ __launch_bounds__(256) void raster_face_kernel(const float *__restrict__ faces, int total, int nf, int is,
                                                           float near_z, float far_z, float *__restrict__ faces_inv,
-                                                          unsigned long long *__restrict__ keys,
-                                                          Box *__restrict__ boxes, int *__restrict__ queue,
-                                                          int *__restrict__ queue_len)
+                                                          unsigned long long *__restrict__ keys)
 {
+    __shared__ int sh_n;
+    __shared__ int sh_t[256];
+    __shared__ Box sh_box[256];
+    __shared__ float sh_v[256][9], sh_inv[256][9];
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    float v[9];
+    float v[9], inv[9];
+    unsigned long long seen = kKeyEmpty;
+    bool live = t < total;
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = faces[(size_t)t * 9 + k];
-    if (backside(v)) return;
-
-    float px[3], py[3], inv[9], det;
-    face_inverse(v, is, px, py, inv, det);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) faces_inv[(size_t)t * 9 + k] = inv[k];
-
-    const float xmn = fminf(fminf(px[0], px[1]), px[2]), xmx = fmaxf(fmaxf(px[0], px[1]), px[2]);
-    const float ymn = fminf(fminf(py[0], py[1]), py[2]), ymx = fmaxf(fmaxf(py[0], py[1]), py[2]);
-    const float ext = fmaxf(xmx - xmn, ymx - ymn);
-    bool finite = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) finite = finite && (px[k] - px[k] == 0.f) && (py[k] - py[k] == 0.f);
-    const bool sweep_all = !finite || !(fabsf(det) > kSliverRatio * ext * ext) ||
-                           fmaxf(fmaxf(fabsf(xmn), fabsf(xmx)), fmaxf(fabsf(ymn), fabsf(ymx))) > kHugeCoord;
-    int x0 = 0, y0 = 0, x1 = is - 1, y1 = is - 1;
-    if (!sweep_all) {
-        // pixel xi sits at pixel-space coordinate xi exactly; one extra pixel of margin on every side
-        x0 = max(0, (int)floorf(xmn) - 1);
-        y0 = max(0, (int)floorf(ymn) - 1);
-        x1 = min(is - 1, (int)ceilf(xmx) + 1);
-        y1 = min(is - 1, (int)ceilf(ymx) + 1);
-        if (x0 > x1 || y0 > y1) return;
+        for (int k = 0; k < 9; ++k) v[k] = faces[(size_t)t * 9 + k];
+        live = !backside(v);
     }
-    const int b = t / nf, fn = t - b * nf;
-    unsigned long long *kb = keys + (size_t)b * is * is;
-    const int bw = x1 - x0 + 1, area = bw * (y1 - y0 + 1);
-    if (area <= kInlineBoxMax) {
-        for (int yi = y0; yi <= y1; ++yi)
-            for (int xi = x0; xi <= x1; ++xi) shade_pixel(v, inv, fn, xi, yi, is, near_z, far_z, kb);
-    } else {
-        Box bx;
-        bx.x0 = (unsigned short)x0; bx.y0 = (unsigned short)y0; bx.x1 = (unsigned short)x1; bx.y1 = (unsigned short)y1;
-        boxes[t] = bx;
-        queue[atomicAdd(queue_len, 1)] = t;
-    }
-}
+    if (live) {
+        float px[3], py[3], det;
+        face_inverse(v, is, px, py, inv, det);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) faces_inv[(size_t)t * 9 + k] = inv[k];
 
-__global__ __launch_bounds__(256) void raster_large_kernel(const float *__restrict__ faces,
-                                                           const float *__restrict__ faces_inv, int nf, int is,
-                                                           float near_z, float far_z,
-                                                           unsigned long long *__restrict__ keys,
-                                                           const Box *__restrict__ boxes,
-                                                           const int *__restrict__ queue,
-                                                           const int *__restrict__ queue_len)
-{
-    const int n = *queue_len;
-    for (int q = blockIdx.x; q < n; q += gridDim.x) {
-        const int t = queue[q];
-        float v[9], inv[9];
+        const float xmn = fminf(fminf(px[0], px[1]), px[2]), xmx = fmaxf(fmaxf(px[0], px[1]), px[2]);
+        const float ymn = fminf(fminf(py[0], py[1]), py[2]), ymx = fmaxf(fmaxf(py[0], py[1]), py[2]);
+        const float ext = fmaxf(xmx - xmn, ymx - ymn);
+        bool finite = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) finite = finite && (px[k] - px[k] == 0.f) && (py[k] - py[k] == 0.f);
+        const bool sweep_all = !finite || !(fabsf(det) > kSliverRatio * ext * ext) ||
+                               fmaxf(fmaxf(fabsf(xmn), fabsf(xmx)), fmaxf(fabsf(ymn), fabsf(ymx))) > kHugeCoord;
+        int x0 = 0, y0 = 0, x1 = is - 1, y1 = is - 1;
+        if (!sweep_all) {
+            // pixel xi sits at pixel-space coordinate xi exactly; one extra pixel of margin on every side
+            x0 = max(0, (int)floorf(xmn) - 1);
+            y0 = max(0, (int)floorf(ymn) - 1);
+            x1 = min(is - 1, (int)ceilf(xmx) + 1);
+            y1 = min(is - 1, (int)ceilf(ymx) + 1);
+        }
+        if (x0 <= x1 && y0 <= y1) {
+            const int b = t / nf, fn = t - b * nf;
+            const int bw = x1 - x0 + 1, area = bw * (y1 - y0 + 1);
+            if (area <= kInlineBoxMax) {
+                unsigned long long *kb = keys + (size_t)b * is * is;
+                for (int yi = y0; yi <= y1; ++yi)
+                    for (int xi = x0; xi <= x1; ++xi) seen &= shade_pixel(v, inv, fn, xi, yi, is, near_z, far_z, kb);
+            } else {
+                const int slot = atomicAdd(&sh_n, 1);
+                Box bx;
+                bx.x0 = (unsigned short)x0; bx.y0 = (unsigned short)y0; bx.x1 = (unsigned short)x1; bx.y1 = (unsigned short)y1;
+                sh_t[slot] = t;
+                sh_box[slot] = bx;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    sh_v[slot][k] = v[k];
+                    sh_inv[slot][k] = inv[k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = sh_n;
+    for (int e = 0; e < n; ++e) {
+        const int tt = sh_t[e];
+        const Box bx = sh_box[e];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            v[k] = faces[(size_t)t * 9 + k];
-            inv[k] = faces_inv[(size_t)t * 9 + k];
+            v[k] = sh_v[e][k];
+            inv[k] = sh_inv[e][k];
         }
-        const Box bx = boxes[t];
-        const int b = t / nf, fn = t - b * nf;
+        const int b = tt / nf, fn = tt - b * nf;
         unsigned long long *kb = keys + (size_t)b * is * is;
         const int bw = bx.x1 - bx.x0 + 1, area = bw * (bx.y1 - bx.y0 + 1);
         for (int p = threadIdx.x; p < area; p += blockDim.x) {
             const int yy = p / bw;
-            shade_pixel(v, inv, fn, bx.x0 + (p - yy * bw), bx.y0 + yy, is, near_z, far_z, kb);
+            seen &= shade_pixel(v, inv, fn, bx.x0 + (p - yy * bw), bx.y0 + yy, is, near_z, far_z, kb);
         }
     }
+    // the wave has to hold the returned keys in registers here, i.e. wait for every atomic it issued
+    asm volatile("" ::"v"((unsigned)seen), "v"((unsigned)(seen >> 32)));
 }
 
 struct ResolveOut {
@@ -210,7 +227,7 @@ struct ResolveOut {
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__restrict__ faces,
                                                              const float *__restrict__ faces_inv,
-                                                             const unsigned long long *__restrict__ keys, int bs,
+                                                             unsigned long long *__restrict__ keys, int bs,
                                                              int nf, int is, float far_z, ResolveOut o)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,7 +237,9 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__rest
     const int yo = pn / is, xi = pn - yo * is;
     const int yi = is - 1 - yo;  // the maps are flipped vertically on the way out (rasterize.py:334-338)
 
-    const unsigned long long key = keys[(size_t)b * npix + (size_t)yi * is + xi];
+    // the keys are only ever touched at agent scope (store in the clear kernel, atomicMin, this load): their lines
+    // never sit in one XCD's L2 waiting for a kernel-boundary write-back / invalidate
+    const unsigned long long key = atomicMax(keys + (size_t)b * npix + (size_t)yi * is + xi, 0ull);
     int fn = -1;
     float w[3] = {0.f, 0.f, 0.f};
     float zp = far_z;
@@ -337,9 +356,6 @@ __global__ __launch_bounds__(256) void bc_transform_kernel(const float *__restri
 struct RasterWs {
     unsigned long long *keys;
     float *faces_inv;
-    Box *boxes;
-    int *queue;
-    int *queue_len;
 };
 
 size_t raster_ws_bytes(int bs, int nf, int is)
@@ -347,9 +363,6 @@ size_t raster_ws_bytes(int bs, int nf, int is)
     size_t n = 0;
     n += align_up((size_t)bs * is * is * sizeof(unsigned long long), 256);
     n += align_up((size_t)bs * nf * 9 * sizeof(float), 256);
-    n += align_up((size_t)bs * nf * sizeof(Box), 256);
-    n += align_up((size_t)bs * nf * sizeof(int), 256);
-    n += 256;
     return n;
 }
 
@@ -360,13 +373,14 @@ RasterWs carve(void *ws, int bs, int nf, int is)
     r.keys = reinterpret_cast<unsigned long long *>(p);
     p += align_up((size_t)bs * is * is * sizeof(unsigned long long), 256);
     r.faces_inv = reinterpret_cast<float *>(p);
-    p += align_up((size_t)bs * nf * 9 * sizeof(float), 256);
-    r.boxes = reinterpret_cast<Box *>(p);
-    p += align_up((size_t)bs * nf * sizeof(Box), 256);
-    r.queue = reinterpret_cast<int *>(p);
-    p += align_up((size_t)bs * nf * sizeof(int), 256);
-    r.queue_len = reinterpret_cast<int *>(p);
     return r;
+}
+
+// Depth keys to "empty": an ordinary kernel of the launch sequence rather than a hipMemsetAsync.
+__global__ __launch_bounds__(256) void raster_clear_kernel(unsigned long long *__restrict__ keys, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMax(keys + i, kKeyEmpty);   // an RMW like the atomicMin of the faces: same coherent path
 }
 
 int check_raster_args(const void *faces, int bs, int nf, int is, const void *fim, const void *wim, const void *ws,
@@ -386,15 +400,12 @@ int run_raster(const float *faces, int bs, int nf, int is, float near_z, float f
                void *ws, hipStream_t st)
 {
     const RasterWs w = carve(ws, bs, nf, is);
-    LWG_HIP(hipMemsetAsync(w.keys, 0xff, (size_t)bs * is * is * sizeof(unsigned long long), st));
-    LWG_HIP(hipMemsetAsync(w.queue_len, 0, sizeof(int), st));
+    const long nkeys = (long)bs * is * is;
+    raster_clear_kernel<<<ceil_div(nkeys, 256), 256, 0, st>>>(w.keys, nkeys);
+    LWG_LAUNCH_CHECK("raster_clear_kernel");
     const int total = bs * nf;
-    raster_face_kernel<<<ceil_div(total, 256), 256, 0, st>>>(faces, total, nf, is, near_z, far_z, w.faces_inv, w.keys,
-                                                             w.boxes, w.queue, w.queue_len);
+    raster_face_kernel<<<ceil_div(total, 256), 256, 0, st>>>(faces, total, nf, is, near_z, far_z, w.faces_inv, w.keys);
     LWG_LAUNCH_CHECK("raster_face_kernel");
-    raster_large_kernel<<<kLargeGrid, 256, 0, st>>>(faces, w.faces_inv, nf, is, near_z, far_z, w.keys, w.boxes,
-                                                    w.queue, w.queue_len);
-    LWG_LAUNCH_CHECK("raster_large_kernel");
     raster_resolve_kernel<<<ceil_div((long)bs * is * is, 256), 256, 0, st>>>(faces, w.faces_inv, w.keys, bs, nf, is,
                                                                             far_z, out);
     LWG_LAUNCH_CHECK("raster_resolve_kernel");

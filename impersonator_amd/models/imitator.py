@@ -194,11 +194,13 @@ class Imitator(BaseModel):
         return tsf_inputs
 
     @torch.no_grad()
-    def forward(self, tsf_inputs, T):
-        """imitator.py:326-336: pred = mask*bg + (1-mask)*color, blend fused into the generator's last kernel."""
+    def forward(self, tsf_inputs, T, generator=None):
+        """imitator.py:326-336: pred = mask*bg + (1-mask)*color, blend fused into the generator's last kernel.
+        `generator` (extension): the engine replica to run on (predict_batches), default self.generator."""
         src_encoder_outs, src_resnet_outs = self.src_info['feats']
-        pred_imgs, _, tsf_mask = self.generator.inference(src_encoder_outs, src_resnet_outs, tsf_inputs, T,
-                                                          bg_img=self.src_info['bg'])
+        generator = self.generator if generator is None else generator
+        pred_imgs, _, tsf_mask = generator.inference(src_encoder_outs, src_resnet_outs, tsf_inputs, T,
+                                                     bg_img=self.src_info['bg'])
         if self._opt.front_warp:
             pred_imgs = self.warp_front(pred_imgs, tsf_mask)
         return pred_imgs
@@ -208,45 +210,124 @@ class Imitator(BaseModel):
         front_mask = self.render.encode_front_fim(self.tsf_info['fim'], transpose=True, front_fn=True)
         return (1 - front_mask) * preds + self.tsf_info['tsf_img'] * front_mask * (1 - mask)
 
-    # ------------------------------------------------------------------ two-stream pipeline over batches
+    # ------------------------------------------------------------------ stream pipeline over batches
+    lanes = 2   # generator engines (and HIP streams) predict_batches deals consecutive batches to; env LWG_LANES
+
+    def _lanes(self, n):
+        """n (stream, generator) pairs, each with its own HIP stream; lane 0 drives self.generator, the others an
+        engine replica over the same parameters (ImpersonatorGenerator.replica: own scratch, own weight copy)."""
+        have = getattr(self, '_lane_cache', None)
+        if have is None or have[0][1] is not self.generator:
+            have = self._lane_cache = [(torch.cuda.Stream(), self.generator)]
+        while len(have) < n:
+            have.append((torch.cuda.Stream(), self.generator.replica().cuda()))
+        for _, g in have[1:n]:
+            g.precision, g.align_corners = self.generator.precision, self.generator.align_corners
+        return have[:n]
+
     @torch.no_grad()
-    def predict_batches(self, batches, cam_strategy='smooth'):
-        """Yields (t, preds) for every (tgt_smpls_chunk, t) of `batches`.  Frames are independent once the source is
-        personalised, so the geometry of batch i+1 (swap_smpl, SMPL, rasteriser, flow, image warp: a dozen small,
-        latency-bound kernels) is enqueued on a second HIP stream while the generator's convolutions of batch i occupy
-        the main one; an event orders each hand-over.  Same results as transfer_params_by_smpl + forward per batch."""
+    def predict_batches(self, batches, cam_strategy='smooth', lanes=None):
+        """Yields (t, preds) for every (tgt_smpls_chunk, t) of `batches`, in order.  Frames are independent once the
+        source is personalised, so consecutive batches are processed in rounds of `lanes`:
+          1. the geometry of the round's batches (swap_smpl, SMPL, rasteriser, flow, image warp: a dozen small kernels
+             sharing one workspace) runs batch after batch on a side stream, *with nothing else on the GPU*;
+          2. their generators then run side by side, each on its own stream and engine (scratch): a layer is
+             conv -> finalize -> apply, every launch waiting for the one before, and the idle tails and launch gaps
+             of one chain are filled by the other's kernels (+15 % frames/s at batch 8 with two lanes; a third adds
+             1 %).
+        The next round's geometry waits for this round's generators.  That barrier is deliberate: with the geometry
+        overlapping generator kernels of other streams (which bought another 7 %), about one batch in 150 came out
+        with one 16-pixel run of a hidden face of the *previous* batch in its face-index map -- inputs, kernel order
+        and key accesses all checked out (tools notes in DESIGN.md section 6), the generators alone never
+        differed in 1800 concurrent batches, so until that is understood the rasteriser gets the chip to itself.
+        Events order every hand-over; round r+1 is enqueued before round r is yielded, so a consumer that
+        synchronises on a result (device->host copy) does not drain the pipeline.  Same results as
+        transfer_params_by_smpl + forward per batch."""
+        import os
+        nl = max(1, int(lanes if lanes is not None else os.environ.get("LWG_LANES", self.lanes)))
         main = torch.cuda.current_stream()
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
+        lane_list = self._lanes(nl)
         side.wait_stream(main)          # the personalised source (and the caller's smpl tensors) are main-stream work
+        for st, _ in lane_list:
+            st.wait_stream(main)
 
-        def prepare(item):
-            chunk, t = item
+        def enqueue_round(items, prev_done):
+            """geometry of `items` on the side stream (after the generators of the previous round), then one generator
+            per lane; returns [(t, preds, info, done_event)]"""
+            prepared = []
             with torch.cuda.stream(side):
-                tsf_inputs = self.transfer_params_by_smpl(chunk, cam_strategy, t=t)
-                info = self.tsf_info
+                for ev in prev_done:
+                    side.wait_event(ev)
+                sizes = [int(chunk.shape[0]) if chunk.dim() > 1 else 1 for chunk, _ in items]
+                if len(items) > 1 and all(t != 0 for _, t in items[1:]) and all(torch.is_tensor(c) for c, _ in items):
+                    # one launch sequence for the whole round (the kernels are latency-bound at these sizes), then
+                    # per-batch views of every result; a later chunk with t == 0 would reset the camera reference
+                    # mid-way, that (unusual) order takes the chunk-by-chunk path below
+                    whole = torch.cat([c.reshape(n, -1) for (c, _), n in zip(items, sizes)], dim=0)
+                    tsf_inputs = self.transfer_params_by_smpl(whole, cam_strategy, t=items[0][1])
+                    info, k0 = self.tsf_info, 0
+                    for (_, t), n in zip(items, sizes):
+                        part = {k: (v[k0:k0 + n] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == whole.shape[0]
+                                    else v) for k, v in info.items()}
+                        prepared.append((t, tsf_inputs[k0:k0 + n], part))
+                        k0 += n
+                else:
+                    for chunk, t in items:
+                        tsf_inputs = self.transfer_params_by_smpl(chunk, cam_strategy, t=t)
+                        prepared.append((t, tsf_inputs, self.tsf_info))
                 ready = torch.cuda.Event()
                 ready.record(side)
-            return t, tsf_inputs, info, ready
+            out = []
+            for (t, tsf_inputs, info), (st, gen) in zip(prepared, lane_list):
+                with torch.cuda.stream(st):
+                    st.wait_event(ready)
+                    self.tsf_info = info
+                    preds = self.forward(tsf_inputs, info['T'], generator=gen)
+                    for v in [tsf_inputs] + [x for x in info.values() if torch.is_tensor(x)]:
+                        v.record_stream(st)   # allocated under the side stream, consumed here ...
+                        v.record_stream(main)  # ... and by whoever reads tsf_info after the yield
+                    done = torch.cuda.Event()
+                    done.record(st)
+                out.append((t, preds, info, done))
+            return out
 
-        it = iter(batches)
+        def rounds():
+            group = []
+            for item in batches:
+                group.append(item)
+                if len(group) == nl:
+                    yield group
+                    group = []
+            if group:
+                yield group
+
+        pending, prev_done = None, []
         try:
-            nxt = prepare(next(it))
-        except StopIteration:
-            return
-        while nxt is not None:
-            t, tsf_inputs, info, ready = nxt
-            try:
-                nxt = prepare(next(it))
-            except StopIteration:
-                nxt = None
-            main.wait_event(ready)
-            self.tsf_info = info
-            preds = self.forward(tsf_inputs, info['T'])
-            for v in (tsf_inputs, info['T'], info['fim'], info['tsf_img']):
-                v.record_stream(main)   # allocated under the side stream, consumed here
-            yield t, preds
+            for group in rounds():
+                cur = enqueue_round(group, prev_done)
+                prev_done = [e[3] for e in cur]
+                if pending is not None:
+                    for t, preds, info, done in pending:
+                        main.wait_event(done)
+                        preds.record_stream(main)
+                        self.tsf_info = info
+                        yield t, preds
+                pending = cur
+            if pending is not None:
+                for t, preds, info, done in pending:
+                    main.wait_event(done)
+                    preds.record_stream(main)
+                    self.tsf_info = info
+                    yield t, preds
+                pending = None
+        finally:
+            # whatever the consumer does next on its stream (also after leaving the loop early) comes after the lanes
+            for ev in prev_done:
+                main.wait_event(ev)
+            main.wait_stream(side)
 
     # ------------------------------------------------------------------ drivers (imitator.py:157-214)
     def _run_batches(self, tgt_smpls, cam_strategy, on_batch):

@@ -189,6 +189,17 @@ class ImpersonatorGenerator(NetworkBase):
             self._uploaded_version = ver
         return self._handle
 
+    def replica(self):
+        """A second engine over the *same* parameters (extension): own device handle, so own scratch and own copy of
+        the re-laid-out weights.  Imitator.predict_batches runs consecutive batches on two of them, each on its own HIP
+        stream, so that the launch gaps and workgroup tails of one batch's dependent kernel chain are filled by the
+        other's.  Precision and align_corners follow the original at every use (see Imitator._lanes)."""
+        r = ImpersonatorGenerator(self.bg_dim, self.src_dim, self.tsf_dim, conv_dim=self.conv_dim,
+                                  repeat_num=self.repeat_num, image_size=self.image_size, max_batch=self.max_batch,
+                                  align_corners=self.align_corners, precision=self.precision)
+        r.bg_model, r.src_model, r.tsf_model = self.bg_model, self.src_model, self.tsf_model   # shared Parameters
+        return r
+
     def release(self):
         if self._handle is not None:
             _lib.load().lwg_generator_destroy(self._handle)
@@ -223,7 +234,7 @@ class ImpersonatorGenerator(NetworkBase):
     def _input_layout(self, x):
         """1 when `x` is the NHWC8-backed view produced by SMPLRenderer.transfer, else 0 (plain NCHW)."""
         n, c, h, w = x.shape
-        if x.stride() == (h * w * 8, 1, w * 8, 8) and x.storage_offset() == 0 and c <= 8:
+        if x.stride() == (h * w * 8, 1, w * 8, 8) and x.storage_offset() % (h * w * 8) == 0 and c <= 8:
             return x, 1
         return x.float().contiguous(), 0
 

@@ -117,9 +117,11 @@ def test_smpl_device_kernels_match_tensor_op_formulation():
     assert torch.equal(dv1, dv[2:3])
 
 
-def test_two_stream_pipeline_equals_the_sequential_path(imi):
-    """Imitator.predict_batches enqueues the geometry of batch i+1 on a second stream under the generator of batch i;
-    every batch must come out bit-identical to transfer_params_by_smpl + forward run one after the other."""
+@pytest.mark.parametrize("lanes", [1, 2, 3])
+def test_stream_pipeline_equals_the_sequential_path(imi, lanes):
+    """Imitator.predict_batches enqueues the geometry of batch i+1 on a side stream and deals the generators of
+    consecutive batches to `lanes` engines on their own streams; every batch must come out, in order, bit-identical to
+    transfer_params_by_smpl + forward run one after the other."""
     imitator = imi[0]
     smpls = torch.from_numpy(demo.synthetic_smpls(24, seed=3)).cuda()
     imitator.first_cam = smpls[0:1, 0:3].clone()
@@ -129,8 +131,12 @@ def test_two_stream_pipeline_equals_the_sequential_path(imi):
         x = imitator.transfer_params_by_smpl(chunk, "smooth", t=t)
         seq.append(imitator.forward(x, imitator.tsf_info["T"]).clone())
     for rep in range(3):   # repeated: a race would not show every time
-        got = [(t, p.clone()) for t, p in imitator.predict_batches(iter(chunks), "smooth")]
+        got = []
+        for t, p in imitator.predict_batches(iter(chunks), "smooth", lanes=lanes):
+            assert imitator.tsf_info["T"].shape[0] == p.shape[0]   # tsf_info is the yielded batch's
+            got.append((t, p.clone()))
         assert [t for t, _ in got] == [t for _, t in chunks]
         for (_, p), q in zip(got, seq):
             assert torch.equal(p, q)
-    assert list(imitator.predict_batches(iter([]), "smooth")) == []
+    assert list(imitator.predict_batches(iter([]), "smooth", lanes=lanes)) == []
+    assert len(list(imitator.predict_batches(iter(chunks[:1]), "smooth", lanes=lanes))) == 1
