@@ -238,7 +238,7 @@ class Imitator(BaseModel):
         The next round's geometry waits for this round's generators.  That barrier is deliberate: with the geometry
         overlapping generator kernels of other streams (which bought another 7 %), about one batch in 150 came out
         with one 16-pixel run of a hidden face of the *previous* batch in its face-index map -- inputs, kernel order
-        and key accesses all checked out (tools notes in DESIGN.md section 6), the generators alone never
+        and key accesses all checked out, the generators alone never
         differed in 1800 concurrent batches, so until that is understood the rasteriser gets the chip to itself.
         Events order every hand-over; round r+1 is enqueued before round r is yielded, so a consumer that
         synchronises on a result (device->host copy) does not drain the pipeline.  Same results as

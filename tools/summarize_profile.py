@@ -18,8 +18,11 @@ def short(name):
 def stats(path, out, bench=None):
     rows = list(csv.DictReader(open(path)))
     with open(out, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode\n"
-                "# (__amd_rocclr_copyBuffer rows are the one-time weight uploads of the setup, outside the timed steps)\n\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --lanes 1 --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode\n"
+                "# (--lanes 1: one generator at a time, so a kernel's duration is its own -- the default two lanes overlap the\n"
+                "#  kernels of two batches, which is what the bench line below gains from; bench.py's roofline pass times its\n"
+                "#  kernels on one lane for the same reason.  __amd_rocclr_copyBuffer rows are the one-time weight uploads of\n"
+                "#  the setup, outside the timed steps)\n\n")
         if bench:
             f.write("bench.py line of the same code (un-profiled run):\n\n```json\n%s\n```\n\n" % open(bench).read().strip())
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
