@@ -1,0 +1,36 @@
+"""Stress check of Imitator.predict_batches (development aid): N passes of six 4-frame batches through the lane
+pipeline, every batch compared bit for bit with transfer_params_by_smpl + forward run one after the other.
+    python tools/lane_stress.py [passes=40] [lanes=2,3]
+This is the run that exposed (and now guards) the rasteriser glitch described in DESIGN.md section 5.1."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from impersonator_amd import demo  # noqa: E402
+
+passes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+lane_counts = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2,3").split(",")]
+im, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=4, seed=0, affine="random")
+im.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+smpls = torch.from_numpy(demo.synthetic_smpls(24, seed=3)).cuda()
+im.first_cam = smpls[0:1, 0:3].clone()
+chunks = [(smpls[s:s + 4], s) for s in range(0, 24, 4)]
+seq = []
+for chunk, t in chunks:
+    x = im.transfer_params_by_smpl(chunk, "smooth", t=t)
+    seq.append(im.forward(x, im.tsf_info["T"]).clone())
+torch.cuda.synchronize()
+bad = tot = 0
+for p in range(passes):
+    for nl in lane_counts:
+        got = [q.clone() for _, q in im.predict_batches(iter(chunks), "smooth", lanes=nl)]   # no sync per batch
+        torch.cuda.synchronize()
+        tot += 1
+        for k, (a, b) in enumerate(zip(got, seq)):
+            if not torch.equal(a, b):
+                print("pass", p, "lanes", nl, "batch", k, "differs, max |d| =", float((a - b).abs().max()), flush=True)
+                bad += 1
+print("differing batches: %d in %d passes of %d batches" % (bad, tot, len(chunks)))
+sys.exit(1 if bad else 0)
