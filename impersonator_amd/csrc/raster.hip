@@ -20,9 +20,17 @@
 //                      image and the generator's NHWC8 input -- five reference passes in one.
 // Work per frame drops from 9.0e8 pair tests to ~2e5; traffic is the algorithmic minimum (faces in, maps out).
 //
-// Exactness: this file is compiled with -ffp-contract=off and keeps the operand types of the .cu file,
-// including its double literals (hazard H5): 0.5 * (...) , (2. * yi + 1 - is) / is, min(max(w, 0.), 1.),
-// 1. / (...).  Conservative boxes are safe because a pixel can only pass the three float edge tests if it
+// Exactness: this file is compiled with -ffp-contract=off and evaluates the .cu file's expressions in the same
+// order.  The .cu file's double literals (hazard H5) promote four sub-expressions to double -- 0.5 * (...),
+// (2. * yi + 1 - is) / is, min(max(w, 0.), 1.), 1. / (...) -- each of which takes float (or small-integer) inputs
+// and is narrowed to float at once.  Every one has a float form with the identical result: halving and clamping
+// to [0, 1] are exact; and for a quotient a / b of two floats (or integers < 2^24), narrowing the correctly rounded
+// double quotient cannot differ from the correctly rounded float quotient, because a quotient that is not itself a
+// float rounding boundary stays at least 2^-49 (relative) away from every such boundary, far more than the 2^-53
+// the double rounding moves it (hipcc's float division is correctly rounded).  So the kernels use float
+// instructions only -- the oracle (oracle/raster_ref.c) keeps the doubles, and the bit-exact tests against it over
+// thousands of frames are the check of this paragraph.  (It also took the f64 divide sequences, the slowest
+// instructions of the face kernel, out of the per-pixel loop.)  Conservative boxes are safe because a pixel can only pass the three float edge tests if it
 // lies within float rounding (<< 1 px) of the triangle, except for degenerate / sliver faces whose edge
 // functions are ill-conditioned; those (and non-finite or huge coordinates) sweep the whole image.
 #include "common.h"
@@ -62,8 +70,8 @@ __device__ __forceinline__ void face_inverse(const float v[9], int is, float px[
 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        px[k] = (float)(0.5 * (double)(v[3 * k + 0] * is + is - 1));
-        py[k] = (float)(0.5 * (double)(v[3 * k + 1] * is + is - 1));
+        px[k] = 0.5f * (v[3 * k + 0] * is + is - 1);   // .cu: 0.5 * (double)(float expr), narrowed: halving is exact
+        py[k] = 0.5f * (v[3 * k + 1] * is + is - 1);
     }
     float m[9];
     m[0] = py[1] - py[2];
@@ -80,8 +88,10 @@ __device__ __forceinline__ void face_inverse(const float v[9], int is, float px[
     for (int k = 0; k < 9; ++k) inv[k] = m[k] / det;
 }
 
-// .cu:113-114: pixel centre in normalised coordinates, evaluated in double and narrowed
-__device__ __forceinline__ float pixel_centre(int i, int is) { return (float)((2. * i + 1 - is) / is); }
+// .cu:113-114: pixel centre in normalised coordinates.  The .cu file evaluates (2. * i + 1 - is) / is in double and
+// narrows; for integers below 2^13 the correctly rounded float quotient is the same number (see the note on float
+// arithmetic in the header), so no double-precision instruction is needed.
+__device__ __forceinline__ float pixel_centre(int i, int is) { return (float)(2 * i + 1 - is) / (float)is; }
 
 // .cu:132-134
 __device__ __forceinline__ bool inside(const float v[9], float xp, float yp)
@@ -98,12 +108,12 @@ __device__ __forceinline__ float bary_depth(const float v[9], const float inv[9]
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         w[k] = inv[3 * k + 0] * xi + inv[3 * k + 1] * yi + inv[3 * k + 2];
-        w[k] = (float)fmin(fmax((double)w[k], 0.), 1.);
+        w[k] = fminf(fmaxf(w[k], 0.f), 1.f);   // .cu clamps in double and narrows: same value
         w_sum += w[k];
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) w[k] /= w_sum;
-    return (float)(1. / (double)(w[0] / v[2] + w[1] / v[5] + w[2] / v[8]));
+    return 1.f / (w[0] / v[2] + w[1] / v[5] + w[2] / v[8]);   // .cu: 1. / (double)(float sum), narrowed: same value
 }
 
 // Returns the key the pixel held before (all-ones when nothing was written): the callers fold it into a value the

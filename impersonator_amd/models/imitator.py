@@ -212,6 +212,7 @@ class Imitator(BaseModel):
 
     # ------------------------------------------------------------------ stream pipeline over batches
     lanes = 2   # generator engines (and HIP streams) predict_batches deals consecutive batches to; env LWG_LANES
+    overlap_geometry = os.environ.get("LWG_OVERLAP_GEOMETRY", "0") == "1"   # see predict_batches
 
     def _lanes(self, n):
         """n (stream, generator) pairs, each with its own HIP stream; lane 0 drives self.generator, the others an
@@ -259,8 +260,9 @@ class Imitator(BaseModel):
             per lane; returns [(t, preds, info, done_event)]"""
             prepared = []
             with torch.cuda.stream(side):
-                for ev in prev_done:
-                    side.wait_event(ev)
+                if not self.overlap_geometry:
+                    for ev in prev_done:
+                        side.wait_event(ev)
                 sizes = [int(chunk.shape[0]) if chunk.dim() > 1 else 1 for chunk, _ in items]
                 if len(items) > 1 and all(t != 0 for _, t in items[1:]) and all(torch.is_tensor(c) for c, _ in items):
                     # one launch sequence for the whole round (the kernels are latency-bound at these sizes), then
