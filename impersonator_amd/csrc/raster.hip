@@ -29,7 +29,8 @@
 // float rounding boundary stays at least 2^-49 (relative) away from every such boundary, far more than the 2^-53
 // the double rounding moves it (hipcc's float division is correctly rounded).  So the kernels use float
 // instructions only -- the oracle (oracle/raster_ref.c) keeps the doubles, and the bit-exact tests against it over
-// thousands of frames are the check of this paragraph.  (It also took the f64 divide sequences, the slowest
+// thousands of frames are the check of this paragraph (tests/test_raster_float_identities.py tries the identities
+// themselves on millions of values on the CPU).  (It also took the f64 divide sequences, the slowest
 // instructions of the face kernel, out of the per-pixel loop.)  Conservative boxes are safe because a pixel can only pass the three float edge tests if it
 // lies within float rounding (<< 1 px) of the triangle, except for degenerate / sliver faces whose edge
 // functions are ill-conditioned; those (and non-finite or huge coordinates) sweep the whole image.
