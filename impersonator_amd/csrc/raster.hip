@@ -28,7 +28,7 @@
 // double quotient cannot differ from the correctly rounded float quotient, because a quotient that is not itself a
 // float rounding boundary stays at least 2^-49 (relative) away from every such boundary, far more than the 2^-53
 // the double rounding moves it (hipcc's float division is correctly rounded).  So the kernels use float
-// instructions only -- the oracle (oracle/raster_ref.c) keeps the doubles, and the bit-exact tests against it over
+// instructions only -- the CPU restatement the tests compare with keeps the doubles, and the bit-exact tests against it over
 // thousands of frames are the check of this paragraph (tests/test_raster_float_identities.py tries the identities
 // themselves on millions of values on the CPU).  (It also took the f64 divide sequences, the slowest
 // instructions of the face kernel, out of the per-pixel loop.)  Conservative boxes are safe because a pixel can only pass the three float edge tests if it
