@@ -13,8 +13,10 @@ region; the per-batch device->host copy of the result is outside it.  Every rank
 own frames (weak scaling, no data-path collective).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the implicit-GEMM conv kernel (exact-fp32 MFMA), algorithmic FLOP / HIP-event time of its launches
-  cpu_baseline : the CPU oracle (port of the reference's PyTorch path + C rasteriser) timed on this box's host cores.
+  roofline     : the dominant implicit-GEMM conv kernel, algorithmic FLOP / HIP-event time of its launches, as a
+                 fraction of the MFMA peak both ways (algorithmic and executed products); exact_fp32_mode has its own
+  cpu_baseline : the CPU oracle (port of the reference's PyTorch path + C rasteriser) timed on this box's host cores
+  parity       : the timed pipeline re-run on 16 frames after the timed region and compared with the oracle.
 """
 import argparse
 import json
@@ -42,6 +44,18 @@ def kernel_peak(name):
 
 BATCH = 8
 IMAGE_SIZE = 256
+TRAFFIC_FILE = "r02_traffic.json"
+
+
+def csrc_digest():
+    """sha256 over the kernel sources (what profiles/*_traffic.json is stamped with by tools/summarize_profile.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "impersonator_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
 
 
 def parse():
@@ -99,7 +113,7 @@ def cpu_baseline(seed=0, batches=2):
             cam[:, 1:] += chunk[:, 1:3] - smpls[0:1, 1:3]
             info = hmr.get_details(torch.cat([cam, chunk[:, 3:75], si["shape"].expand(BATCH, -1)], 1))
             fr = torch_ref.transfer_frame(src_img, p2v, info["cam"], info["verts"], faces_t, map_fn)
-            return torch_ref.imitator_forward(sd, enc, res, bg_img, fr["tsf_inputs"], fr["T"])[0]
+            return fr["fim"], torch_ref.imitator_forward(sd, enc, res, bg_img, fr["tsf_inputs"], fr["T"])[0]
 
         # a 256-thread intra-op pool is slower than 32 threads on these convs: pick the best of a few pool sizes on one
         # batch each (the first call also warms up), then time `batches` batches with it
@@ -115,12 +129,55 @@ def cpu_baseline(seed=0, batches=2):
         cores = best[0]
         torch.set_num_threads(cores)
         t0 = time.perf_counter()
-        for b in range(1, batches + 1):
-            one_batch(b)
+        kept = [one_batch(b) for b in range(1, batches + 1)]
         dt = time.perf_counter() - t0
-    return {"value": round(batches * BATCH / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+    line = {"value": round(batches * BATCH / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d batches of %d frames (256x256) after warm-up, best of 16/32/64 intra-op threads on a box with %d "
-                      "logical cores, torch %s CPU fp32 + OpenMP C rasteriser" % (batches, BATCH, os.cpu_count(), torch.__version__)}
+                      "logical cores, torch %s CPU fp32 + OpenMP C rasteriser" % (batches, BATCH, os.cpu_count(), torch.__version__),
+            "port_vs_reference": "the port runs at 1.00x +- 0.03 of the reference's own modules on the same batch "
+                                 "(profiles/r02_port_vs_reference.md, measured where /root/reference exists)"}
+    return line, {"fim": torch.cat([k[0] for k in kept]), "pred": torch.cat([k[1] for k in kept]), "first_batch": 1}
+
+
+def parity_block(imitator, src_img, bg_img, smpls, lanes, theta_chain):
+    """Runs, OUTSIDE the timed region, the two batches the CPU baseline computed (frames 8..23) through the pipeline
+    that was timed and checks them against the oracle: (a) `same_vertices` -- the oracle restarts from the posed
+    vertices the device produced (the definition every parity test uses: a 1e-6 difference in a vertex can move a
+    face edge across a pixel centre, which is a different, legitimate image); (b) `theta_chain` -- the oracle's
+    own SMPL from the same theta, reported with the number of face-index pixels that differ."""
+    from oracle import torch_ref
+    b0 = theta_chain["first_batch"]
+    nb = theta_chain["pred"].shape[0] // BATCH
+    chunks = [(smpls[b * BATCH:(b + 1) * BATCH], b * BATCH) for b in range(b0, b0 + nb)]
+    preds, verts, cams, fims, Ts = [], [], [], [], []
+    for _, p in imitator.predict_batches(iter(chunks), "smooth", lanes=lanes):
+        info = imitator.tsf_info
+        preds.append(p.cpu())
+        verts.append(info["verts"].cpu())
+        cams.append(info["cam"].cpu())
+        fims.append(info["fim"].cpu())
+        Ts.append(info["T"].cpu())
+    pred, fim = torch.cat(preds), torch.cat(fims)
+    sd = {k: v.detach().cpu() for k, v in imitator.generator.state_dict().items()}
+    faces_t, map_fn, si = imitator.render.faces.cpu(), imitator.render.map_fn.cpu(), imitator.src_info
+    src_t, bg_t = torch.from_numpy(src_img)[None], torch.from_numpy(bg_img)[None]
+    with torch.no_grad():
+        src = torch_ref.personalize(sd, src_t, si["cam"].cpu(), si["verts"].cpu(), faces_t, map_fn, ft_ks=imitator._opt.ft_ks)
+        fr, ref = torch_ref.imitator_frames(sd, src, src_t, bg_t, torch.cat(cams), torch.cat(verts), faces_t, map_fn)
+    agree = (fim == theta_chain["fim"])
+    d_chain = (pred - theta_chain["pred"]).abs()
+    frames_agree = agree.flatten(1).all(1)
+    return {"frames": int(pred.shape[0]), "linf": round(float((pred - ref).abs().max()), 7),
+            "fim_mismatch": int((fim != fr["fim"]).sum()) + int((si["fim"].cpu() != src["fim"]).sum()),
+            "T_linf": round(float((torch.cat(Ts) - fr["T"]).abs().max()), 9),
+            "bound": 1e-3, "oracle": "same_vertices: oracle/torch_ref.py + raster_ref.c restarted from the device's posed "
+                                     "vertices; pipeline = the timed one (%d lanes)" % lanes,
+            "theta_chain": {"fim_mismatch_pixels": int((~agree).sum()),
+                            "frames_with_identical_fim": int(frames_agree.sum()),
+                            "linf_on_those_frames": (round(float(d_chain[frames_agree].max()), 7)
+                                                     if bool(frames_agree.any()) else None),
+                            "linf_all": round(float(d_chain.max()), 7),
+                            "note": "oracle's own CPU SMPL from the same theta (vertices differ by ~1e-6)"}}
 
 
 def main():
@@ -178,11 +235,11 @@ def main():
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else "cpu")
     assert bool(torch.isfinite(out).all())
 
-    roofline = None
-    if not args.no_roofline:
-        # same steps again with HIP events around every launch of the implicit-GEMM kernel (on its launch stream), on
-        # ONE lane: with two lanes the kernels of two batches share the chip and a launch's elapsed time is no longer
-        # that kernel's own (the timed region above is what gains from the overlap, not the kernel)
+    def roofline_pass():
+        """K steps again with HIP events around every launch of the conv kernels (recorded by liblwg on the launch
+        stream), on ONE lane: with two lanes the kernels of two batches share the chip and a launch's elapsed time is
+        no longer that kernel's own (the timed region above is what gains from the overlap, not the kernel).  Returns
+        the block for the conv arithmetic currently selected."""
         imitator.generator.profile(True)
         run_steps(args.warmup, args.steps, lanes=1)
         n, ms, flops = imitator.generator.profile_read()
@@ -192,35 +249,50 @@ def main():
         # (names are the ones rocprofv3 --stats prints, so profiles/ can be checked against this line)
         name, (kn, kms, kfl) = max(table.items(), key=lambda kv: kv[1][1])
         achieved = kfl / (kms * 1e-3) / 1e12
-        peak = kernel_peak(name)
+        x3 = "bf16x3" in name
+        peak = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
         ideal_ms = sum(v[2] / (kernel_peak(k) * 1e12) * 1e3 for k, v in table.items())
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3),
-                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": None, "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
-                    "flop_per_launch": kfl / max(kn, 1),
-                    "measured": "HIP events around each launch, steps re-run on one lane (kernels not overlapped)",
-                    "peak_note": ("algorithmic flops; bf16x3 kernels execute 3 bf16 MFMA products per multiply-add, peak = "
-                                  "2500 (dense bf16) / 3; fp32 kernels: 157.3 (v_mfma_f32_32x32x2_f32)"),
-                    "all_conv_kernels": {"achieved": round(flops / (ms * 1e-3) / 1e12, 3),
-                                         "frac": round(ideal_ms / ms, 4),
-                                         "launches": n, "ms_per_step": round(ms / args.steps, 4),
-                                         "by_kernel": {k: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 5),
-                                                           "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2),
-                                                           "frac": round(v[2] / (v[1] * 1e-3) / 1e12 / kernel_peak(k), 4)}
-                                                       for k, v in table.items()}}}
-
-    if roofline is not None:
-        # bytes per launch of the dominant kernel from the committed PMC passes of the same command (tools/profile_round.sh:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); bench.py cannot
-        # collect counters itself
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        block = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": round(peak, 1),
+                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                 "frac_algorithmic": round(achieved / peak, 4),
+                 "frac_pipe": round(achieved * (3.0 if x3 else 1.0) / peak, 4),
+                 "executed_tflops": round(achieved * (3.0 if x3 else 1.0), 2),
+                 "traffic": None, "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
+                 "flop_per_launch": kfl / max(kn, 1),
+                 "measured": "HIP events around each launch, steps re-run on one lane (kernels not overlapped)",
+                 "frac_note": ("achieved = ALGORITHMIC flops (2*M*Cout*taps*Cin, real taps and channels) / launch time; "
+                               "frac = frac_algorithmic = achieved / peak of the MFMA instruction used (bf16 dense 2500, "
+                               "fp32 157.3).  A bf16x3 kernel executes 3 bf16 MFMA products per algorithmic multiply-add: "
+                               "frac_pipe = 3 * achieved / 2500 is the matrix-pipe utilisation (what the PMC pass in "
+                               "profiles/ measures as MFMA busy)"),
+                 "all_conv_kernels": {"achieved": round(flops / (ms * 1e-3) / 1e12, 3),
+                                      "frac_pipe": round(ideal_ms / ms, 4),
+                                      "launches": n, "ms_per_step": round(ms / args.steps, 4),
+                                      "by_kernel": {k: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 5),
+                                                        "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2),
+                                                        "frac_pipe": round(v[2] / (v[1] * 1e-3) / 1e12 / kernel_peak(k), 4)}
+                                                    for k, v in table.items()}}}
+        # bytes per launch of the dominant kernel from the committed PMC passes of the same command
+        # (tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md
+        # prescribes); bench.py cannot collect counters itself.  The file carries the digest of the kernel sources it
+        # was measured on: a stale measurement is dropped, not attached.
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tpath):
-            t = json.load(open(tpath)).get(roofline["kernel"])
-            if t and "fetch_bytes_per_launch" in t and "write_bytes_per_launch" in t:
-                roofline["traffic"] = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
-                roofline["traffic_note"] = ("fabric-side bytes per launch (profiles/r01_traffic.md): %.0f MB read + %.0f MB "
-                                            "written; Infinity-Cache hits included, every XCD's L2 fetches its own copy of "
-                                            "the weights" % (t["fetch_bytes_per_launch"] / 1e6, t["write_bytes_per_launch"] / 1e6))
+            tj = json.load(open(tpath))
+            stamp = tj.get("_stamp", {})
+            t = tj.get(name)
+            if stamp.get("csrc_sha256") != csrc_digest():
+                block["traffic_note"] = ("profiles/%s was measured on other kernel sources (stamp %s..., now %s...): "
+                                         "not attached" % (TRAFFIC_FILE, str(stamp.get("csrc_sha256"))[:10], csrc_digest()[:10]))
+            elif t and "fetch_bytes_per_launch" in t and "write_bytes_per_launch" in t:
+                block["traffic"] = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
+                block["traffic_note"] = ("fabric-side bytes per launch (profiles/%s, commit %s): %.0f MB read + %.0f MB "
+                                         "written; Infinity-Cache hits included, every XCD's L2 fetches its own copy of "
+                                         "the weights" % (TRAFFIC_FILE, stamp.get("commit", "?"),
+                                                          t["fetch_bytes_per_launch"] / 1e6, t["write_bytes_per_launch"] / 1e6))
+        return block
+
+    roofline = roofline_pass() if not args.no_roofline else None
 
     fp32_mode = None
     if precision != "fp32" and not args.no_fp32_mode:
@@ -232,10 +304,12 @@ def main():
         run_steps(args.warmup, args.steps)
         sharding.barrier(dev)
         dt32 = sharding.max_over_ranks(time.perf_counter() - t1, dev if world > 1 else "cpu")
-        imitator.generator.precision = precision
         fp32_mode = {"value": round(world * BATCH * args.steps / dt32, 3), "unit": "frames/s",
                      "ms_per_step": round(dt32 / args.steps * 1e3, 4), "dtype": "f32",
                      "note": "same workload, precision='fp32' (v_mfma_f32_32x32x2_f32, bit-exact fmaf chains)"}
+        if not args.no_roofline:
+            fp32_mode["roofline"] = roofline_pass()
+        imitator.generator.precision = precision
 
     if rank == 0:
         frames = world * BATCH * args.steps
@@ -260,7 +334,9 @@ def main():
         if roofline is not None:
             line["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"], kept = cpu_baseline()
+            # self-check of the timed pipeline against the oracle, after and outside the timed region
+            line["parity"] = parity_block(imitator, src_img, bg_img, smpls, lanes, kept)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

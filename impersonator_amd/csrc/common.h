@@ -38,6 +38,30 @@ inline hipStream_t as_stream(lwg_stream_t s) { return reinterpret_cast<hipStream
         if (e_ != hipSuccess) LWG_FAIL(LWG_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// Per-device one-time setup (hipFuncSetAttribute opt-ins are per device; a process may switch GPUs).
+struct DeviceOnce {
+    unsigned long long done_mask = 0;   // bit d: set up on device d (callers are single-threaded per handle)
+    static int device()
+    {
+        int d = 0;
+        return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : 0;
+    }
+    bool done() const { return (done_mask >> device()) & 1ull; }
+    void mark() { done_mask |= 1ull << device(); }
+};
+
+// compute-unit count of the current device (cached per device)
+inline int device_cu_count()
+{
+    static int cus[64] = {0};
+    const int d = DeviceOnce::device();
+    if (!cus[d]) {
+        hipDeviceProp_t prop;
+        cus[d] = hipGetDeviceProperties(&prop, d) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    return cus[d];
+}
+
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

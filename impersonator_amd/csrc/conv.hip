@@ -1147,8 +1147,8 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
     const dim3 grid(a.mtiles, a.Cout / bn, a.fuse_phases ? 1 : a.nphase);
     const size_t lds = (size_t)2 * (BM + bn) * LDK * sizeof(float);
     // the 128-channel tile needs 72 KiB of LDS: above the 64 KiB default, well inside gfx950's 160 KiB per CU
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
+    static DeviceOnce lds_opt_in;
+    if (!lds_opt_in.done()) {
         const int l64 = 2 * (BM + 64) * LDK * (int)sizeof(float), l128 = 2 * (BM + 128) * LDK * (int)sizeof(float);
         LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, l64));
@@ -1156,12 +1156,12 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
                                     hipFuncAttributeMaxDynamicSharedMemorySize, l64));
         LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<128, 2, 2, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, l128));
-        lds_opt_in = true;
+        lds_opt_in.mark();
     }
     const bool small_cin = a.Cin < BK;
     if (a.general) {
-        static bool gen_opt_in = false;
-        if (!gen_opt_in) {
+        static DeviceOnce gen_opt_in;
+        if (!gen_opt_in.done()) {
             const int l64 = 2 * (BM + 64) * LDK * (int)sizeof(float), l128 = 2 * (BM + 128) * LDK * (int)sizeof(float);
             LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<64, 1, 2, false, 0, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, l64));
@@ -1169,7 +1169,7 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
                                         hipFuncAttributeMaxDynamicSharedMemorySize, l64));
             LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<128, 2, 2, false, 0, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, l128));
-            gen_opt_in = true;
+            gen_opt_in.mark();
         }
         if (small_cin && bn != 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d < %d is only built for the 64-channel tile", a.Cin, BK);
         for (int p = 0; p < a.nphase; ++p)
@@ -1201,13 +1201,13 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
                     LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: weight matrix too large for 32-bit lane offsets");
         }
         const size_t lds3 = (size_t)3 * (BM + bn) * BK * sizeof(float);
-        static bool opt16 = false;
-        if (!opt16) {
+        static DeviceOnce opt16;
+        if (!opt16.done()) {
             LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<64, 1, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 64) * BK * (int)sizeof(float)));
             LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<128, 2, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 128) * BK * (int)sizeof(float)));
-            opt16 = true;
+            opt16.mark();
         }
         for (int p = 0; p < a.nphase; ++p)
             if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the bf16x3 path");
@@ -1226,32 +1226,20 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
     // (the 96 KiB ring allows one per CU anyway: 127 vs 122) and register-staged when several rounds are queued
     // (74 KiB: two resident workgroups per CU, 130 vs 126).  Both kernels add the products of an output in the
     // same order, so the choice never changes a result bit.
-    int ncu = 256;
-    {
-        static int cached_cus = 0;
-        if (!cached_cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                cached_cus = prop.multiProcessorCount;
-            else
-                cached_cus = 256;
-        }
-        ncu = cached_cus;
-    }
+    const int ncu = device_cu_count();
     const long nblocks = (long)grid.x * grid.y * grid.z;
     const bool use_dma = !small_cin && a.zeros && (bn == 64 || nblocks <= ncu);
     if (a.fuse_phases && !use_dma) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: fused phases need the DMA-fed kernel (Cin >= 32, 64-channel tile)");
     if (use_dma) {
         // DMA-fed 3-stage ring: (BM + bn) * 32 floats per stage
         const size_t lds_dma = (size_t)3 * (BM + bn) * BK * sizeof(float);
-        static bool dma_opt_in = false;
-        if (!dma_opt_in) {
+        static DeviceOnce dma_opt_in;
+        if (!dma_opt_in.done()) {
             LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<64, 1, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 64) * BK * (int)sizeof(float)));
             LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<128, 2, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 128) * BK * (int)sizeof(float)));
-            dma_opt_in = true;
+            dma_opt_in.mark();
         }
         for (int p = 0; p < a.nphase; ++p)
             if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the DMA path");
@@ -1401,11 +1389,11 @@ int launch_unsplit(float *buf, size_t n, hipStream_t st)
 int launch_heads(const HeadsArgs &a, hipStream_t st)
 {
     if (a.pred && !a.bg) LWG_FAIL(LWG_ERR_INVALID_ARG, "heads: pred requested without a background image");
-    static bool opt_in = false;
-    if (!opt_in) {
+    static DeviceOnce opt_in;
+    if (!opt_in.done()) {
         LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     HEADS_LDS));
-        opt_in = true;
+        opt_in.mark();
     }
     const dim3 grid(ceil_div(a.W, HT), ceil_div(a.H, HT), a.N);
     heads_kernel<<<grid, 256, HEADS_LDS, st>>>(a);

@@ -205,18 +205,13 @@ int launch_stem_bf16x3(const StemArgs &a, hipStream_t st)
 {
     if (!a.x || !a.w || !a.y) LWG_FAIL(LWG_ERR_INVALID_ARG, "stem: NULL argument");
     if (a.W % ST_COLS || a.H % ST_ROWS) LWG_FAIL(LWG_ERR_UNSUPPORTED, "stem: %dx%d is not a multiple of the 2x128 tile", a.H, a.W);
-    static bool opt_in = false;
-    if (!opt_in) {
+    static DeviceOnce opt_in;
+    if (!opt_in.done()) {
         LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&stem_bf16x3_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS));
-        opt_in = true;
+        opt_in.mark();
     }
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = device_cu_count();
     const int ntiles = a.N * (a.H / ST_ROWS) * (a.W / ST_COLS);
     stem_bf16x3_kernel<<<ntiles < ncu ? ntiles : ncu, 256, ST_LDS, st>>>(a);
     LWG_LAUNCH_CHECK("stem_bf16x3_kernel");

@@ -1,24 +1,35 @@
-// raster.hip -- SMPL mesh rasteriser + flow/condition epilogue for gfx950 (MI355X).
+// raster.hip -- SMPL mesh rasteriser + flow/condition epilogue for gfx950 (MI355X): tile-owned z-buffer in LDS.
 //
-// Replaces, with bit-identical results, the brute-force CUDA rasteriser of the reference
+// Replaces the brute-force CUDA rasteriser of the reference
 //   thirdparty/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu:40-84   (per-face inverse)
 //   thirdparty/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu:86-186  (every pixel loops all faces)
-// and the python glue around it (utils/nmr.py:263-278,328-341,617-659; rasterize.py:50-52,334-338).
+// and the python glue around it (utils/nmr.py:263-278,328-341,617-659; rasterize.py:50-52,334-338), with results
+// bit-identical to the uncontracted (no fused multiply-add) evaluation of the .cu file's float expressions.
 //
-// Design (MI355X-first, not a translation): the reference tests 65536 x 13776 pixel/face pairs per frame.
-// SMPL faces cover ~2 pixels each, so this implementation is FACE-parallel:
-//   1. face kernel   : one lane per (frame, face): cull, inverse matrix, conservative pixel bounding box;
-//                      faces with a small box are scan-converted by their own lane,
-//   2.                 larger ones are parked in the workgroup's LDS and swept by its 256 lanes after a barrier;
-//   3. both resolve visibility with ONE 64-bit atomicMin per covering pixel on the key
-//                      (orderable(zp) << 32 | face_id) -- the lexicographic minimum is exactly the reference's
-//                      "strictly smaller depth, lowest face index wins ties" rule (hazard H6) independent of
-//                      evaluation order;
-//   4. resolve kernel: one lane per pixel decodes the winner, recomputes its barycentrics with the same
-//                      float expression sequence and writes fim/wim (vertically flipped, rasterize.py:334-338)
-//                      and, in the fused per-frame path, cond = map_fn[fim], the flow T, the warped source
-//                      image and the generator's NHWC8 input -- five reference passes in one.
-// Work per frame drops from 9.0e8 pair tests to ~2e5; traffic is the algorithmic minimum (faces in, maps out).
+// Design (MI355X-first, not a translation).  The reference tests 65536 x 13776 pixel/face pairs per frame; SMPL faces
+// cover ~2 pixels each.  Two launches, no global atomics, no depth buffer in memory, no clear pass:
+//   1. setup kernel, one lane per (frame, face): [vertex gather + orthographic projection + y flip + look_at shift,
+//      when called from lwg_transfer_frame], back-face cull, inverse matrix (.cu:40-84), conservative pixel box, and
+//      that box in units of tiles, packed in 4 bytes.  Culled / off-screen faces get an empty box.
+//   2. tile kernel, one workgroup per 32x8-pixel tile (a tile row is one 128-byte line of every per-pixel plane):
+//        a. the workgroup streams the frame's packed tile boxes (4 B per face, 16 B per lane and load, L2-resident:
+//           55 KB for SMPL) and appends the faces that touch its tile to a list in LDS;
+//        b. one lane per listed face clips the face's pixel box to the tile and scan-converts it, resolving
+//           visibility with a 64-bit LDS atomic min per covered pixel on the key (orderable(zp) << 32 | face_id):
+//           the lexicographic minimum is exactly the reference's "strictly smaller depth, lowest face index wins
+//           ties" rule (hazard H6), whatever the order faces are visited in.  The z-buffer (2 KB) lives and dies
+//           in the workgroup's LDS; faces whose clipped box is large are swept by all 256 lanes instead;
+//        c. one lane per pixel decodes the winner, recomputes its barycentrics with the same float expression
+//           sequence and writes fim/wim/depth (vertically flipped, rasterize.py:334-338) and, in the fused per-frame
+//           path, cond = map_fn[fim], the flow T, the warped source image and the generator's NHWC8 input --
+//           five reference passes -- with plain stores.
+//      The list holds 4096 faces; a tile that more faces touch (a mesh shrunk to a few pixels, a frame full of
+//      slivers) flushes it through step b and keeps scanning, so every face count is handled without a fallback.
+// Nothing a kernel of another stream could disturb survives between launches except the per-face records (plain
+// stores in launch 1, plain loads in launch 2, ordinary stream order), which makes the entry points re-entrant and
+// safe to overlap with anything: an earlier face-parallel version kept the depth keys in global memory and updated
+// them with device-scope atomics, and rarely showed a stale 128-byte line of keys when other streams were busy.
+// Work per frame drops from 9.0e8 pair tests to ~2e5 plus 3.5e6 four-byte box tests.
 //
 // Exactness: this file is compiled with -ffp-contract=off and evaluates the .cu file's expressions in the same
 // order.  The .cu file's double literals (hazard H5) promote four sub-expressions to double -- 0.5 * (...),
@@ -28,12 +39,12 @@
 // double quotient cannot differ from the correctly rounded float quotient, because a quotient that is not itself a
 // float rounding boundary stays at least 2^-49 (relative) away from every such boundary, far more than the 2^-53
 // the double rounding moves it (hipcc's float division is correctly rounded).  So the kernels use float
-// instructions only -- the CPU restatement the tests compare with keeps the doubles, and the bit-exact tests against it over
-// thousands of frames are the check of this paragraph (tests/test_raster_float_identities.py tries the identities
-// themselves on millions of values on the CPU).  (It also took the f64 divide sequences, the slowest
-// instructions of the face kernel, out of the per-pixel loop.)  Conservative boxes are safe because a pixel can only pass the three float edge tests if it
-// lies within float rounding (<< 1 px) of the triangle, except for degenerate / sliver faces whose edge
-// functions are ill-conditioned; those (and non-finite or huge coordinates) sweep the whole image.
+// instructions only -- the CPU restatement the tests compare with keeps the doubles, and the bit-exact tests against
+// it over thousands of frames are the check of this paragraph (tests/test_raster_float_identities.py tries the
+// identities themselves on millions of values on the CPU).  Conservative boxes are safe because a pixel can only
+// pass the three float edge tests if it lies within float rounding (<< 1 px) of the triangle, except for degenerate /
+// sliver faces whose edge functions are ill-conditioned; those (and non-finite or huge coordinates) get the whole
+// image as their box, i.e. every tile sweeps them over all its pixels, as brute force would.
 #include "common.h"
 #include "sample.h"
 
@@ -41,9 +52,16 @@ namespace lwg {
 namespace {
 
 constexpr unsigned long long kKeyEmpty = ~0ull;
-constexpr int kInlineBoxMax = 64;     // boxes up to this many pixels are scan-converted by the face's lane
-constexpr float kSliverRatio = 1e-4f; // |2*area| / extent^2 below this => ill-conditioned => full sweep
-constexpr float kHugeCoord = 1.0e6f;  // pixel coordinates beyond this => full sweep
+constexpr int kTileW = 32, kTileH = 8;     // pixels owned by one workgroup (one lane per pixel in the resolve step)
+constexpr int kTilePix = kTileW * kTileH;
+constexpr int kThreads = 256;
+constexpr int kListCap = 4096;             // faces a tile can hold before it flushes its list
+constexpr int kScanStep = 4 * kThreads;    // faces examined per scan step: 4 packed boxes (16 bytes) per lane
+constexpr int kInlineBoxMax = 64;          // clipped boxes up to this many pixels are scan-converted by the face's lane
+constexpr float kSliverRatio = 1e-4f;      // |2*area| / extent^2 below this => ill-conditioned => whole-image box
+constexpr float kHugeCoord = 1.0e6f;       // pixel coordinates beyond this => whole-image box
+constexpr unsigned kTileBoxEmpty = 0x0000ffffu;   // tx0 = ty0 = 255 > tx1 = ty1 = 0: touches no tile
+static_assert(kTilePix == kThreads, "the resolve step maps one lane to one pixel of the tile");
 
 struct Box {
     unsigned short x0, y0, x1, y1;
@@ -65,7 +83,7 @@ __device__ __forceinline__ float unorder_bits(unsigned o)
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-// .cu:64-81 -- returns false for culled faces; px/py are the pixel-space vertex positions
+// .cu:64-81; px/py are the pixel-space vertex positions
 __device__ __forceinline__ void face_inverse(const float v[9], int is, float px[3], float py[3], float inv[9],
                                              float &det)
 {
@@ -117,114 +135,93 @@ __device__ __forceinline__ float bary_depth(const float v[9], const float inv[9]
     return 1.f / (w[0] / v[2] + w[1] / v[5] + w[2] / v[8]);   // .cu: 1. / (double)(float sum), narrowed: same value
 }
 
-// Returns the key the pixel held before (all-ones when nothing was written): the callers fold it into a value the
-// kernel's last instructions depend on, which makes every atomic a *returning* one the wave has to wait for.  A
-// fire-and-forget atomicMin could still be on its way to memory when the kernel was reported complete, and land
-// after the next frame's clear had reset that key (seen with other kernels loading the fabric from a second and
-// third stream: a 16-pixel run -- one 128-byte request -- of the previous batch's hidden face showing through).
-__device__ __forceinline__ unsigned long long shade_pixel(const float v[9], const float inv[9], int fn, int xi, int yi,
-                                                          int is, float near_z, float far_z,
-                                                          unsigned long long *__restrict__ keys)
+// ------------------------------------------------------------------------------------------------ launch 1: faces
+struct Tiling {
+    int tiles_x, tiles_y;   // tiles of kTileW x kTileH pixels covering the image
+    int shx, shy;           // packed tile boxes count in units of (tile << sh): at most 256 units per axis
+};
+
+Tiling tiling_for(int is)
 {
-    const float xp = pixel_centre(xi, is), yp = pixel_centre(yi, is);
-    if (!inside(v, xp, yp)) return kKeyEmpty;
-    float w[3];
-    const float zp = bary_depth(v, inv, xi, yi, w);
-    // .cu:154-159: reject zp <= near, far <= zp; depth_min starts at far, so NaN never wins either
-    if (!(zp > near_z && zp < far_z)) return kKeyEmpty;
-    const unsigned long long key = ((unsigned long long)order_bits(zp) << 32) | (unsigned)fn;
-    return atomicMin(keys + (size_t)yi * is + xi, key);
+    Tiling t;
+    t.tiles_x = (is + kTileW - 1) / kTileW;
+    t.tiles_y = (is + kTileH - 1) / kTileH;
+    t.shx = t.shy = 0;
+    while (((t.tiles_x - 1) >> t.shx) > 255) ++t.shx;
+    while (((t.tiles_y - 1) >> t.shy) > 255) ++t.shy;
+    return t;
 }
 
-// One lane per face: inverse matrix, culling, conservative box.  Small boxes are scan-converted by the lane itself;
-// faces with a larger box are parked in the workgroup's own LDS list and, after a barrier, swept by all 256 lanes of
-// that workgroup.  (An earlier version handed the large faces to a second kernel through a queue in the workspace;
-// keeping them inside the workgroup drops that launch and every cross-kernel read of queue state.)
-__global__ __launch_bounds__(256) void raster_face_kernel(const float *__restrict__ faces, int total, int nf, int is,
-                                                          float near_z, float far_z, float *__restrict__ faces_inv,
-                                                          unsigned long long *__restrict__ keys)
+// One lane per (frame, face slot); slots nf .. nfp-1 of a frame are padding (nfp = nf rounded up to 4, so that the
+// tile kernel can fetch four packed boxes with one aligned 16-byte load) and only receive an empty box.
+// kProject: the face's vertices are gathered from the posed mesh and projected (utils/nmr.py:10-28 + :271, look_at.py
+// with the identity rotation of nmr.py:177, vertices_to_faces.py) and written to `faces` = f2verts; otherwise `faces`
+// is the input.
+template <bool kProject>
+__global__ __launch_bounds__(256) void raster_setup_kernel(const float *__restrict__ verts,
+                                                           const float *__restrict__ cam,
+                                                           const int32_t *__restrict__ faces_idx, int nv, float eye_z,
+                                                           float *__restrict__ faces, int bs, int nf, int nfp, int is,
+                                                           Tiling tl, float *__restrict__ faces_inv,
+                                                           Box *__restrict__ pbox, unsigned *__restrict__ tbox)
 {
-    __shared__ int sh_n;
-    __shared__ int sh_t[256];
-    __shared__ Box sh_box[256];
-    __shared__ float sh_v[256][9], sh_inv[256][9];
-    if (threadIdx.x == 0) sh_n = 0;
-    __syncthreads();
-
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    float v[9], inv[9];
-    unsigned long long seen = kKeyEmpty;
-    bool live = t < total;
-    if (live) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs * nfp) return;
+    const int b = i / nfp, fn = i - b * nfp;
+    unsigned packed = kTileBoxEmpty;
+    if (fn < nf) {
+        const size_t t = (size_t)b * nf + fn;
+        float v[9];
+        if (kProject) {
+            const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[k] = faces[(size_t)t * 9 + k];
-        live = !backside(v);
-    }
-    if (live) {
-        float px[3], py[3], det;
-        face_inverse(v, is, px, py, inv, det);
+            for (int k = 0; k < 3; ++k) {
+                const float *p = verts + ((size_t)b * nv + faces_idx[fn * 3 + k]) * 3;
+                v[3 * k + 0] = s * (p[0] + tx);          // utils/nmr.py:24
+                v[3 * k + 1] = -(s * (p[1] + ty));       // utils/nmr.py:24 then :271
+                v[3 * k + 2] = p[2] - eye_z;             // look_at.py:58-60 with the identity rotation of nmr.py:177
+            }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) faces_inv[(size_t)t * 9 + k] = inv[k];
-
-        const float xmn = fminf(fminf(px[0], px[1]), px[2]), xmx = fmaxf(fmaxf(px[0], px[1]), px[2]);
-        const float ymn = fminf(fminf(py[0], py[1]), py[2]), ymx = fmaxf(fmaxf(py[0], py[1]), py[2]);
-        const float ext = fmaxf(xmx - xmn, ymx - ymn);
-        bool finite = true;
+            for (int k = 0; k < 9; ++k) faces[t * 9 + k] = v[k];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) finite = finite && (px[k] - px[k] == 0.f) && (py[k] - py[k] == 0.f);
-        const bool sweep_all = !finite || !(fabsf(det) > kSliverRatio * ext * ext) ||
-                               fmaxf(fmaxf(fabsf(xmn), fabsf(xmx)), fmaxf(fabsf(ymn), fabsf(ymx))) > kHugeCoord;
-        int x0 = 0, y0 = 0, x1 = is - 1, y1 = is - 1;
-        if (!sweep_all) {
-            // pixel xi sits at pixel-space coordinate xi exactly; one extra pixel of margin on every side
-            x0 = max(0, (int)floorf(xmn) - 1);
-            y0 = max(0, (int)floorf(ymn) - 1);
-            x1 = min(is - 1, (int)ceilf(xmx) + 1);
-            y1 = min(is - 1, (int)ceilf(ymx) + 1);
+            for (int k = 0; k < 9; ++k) v[k] = faces[t * 9 + k];
         }
-        if (x0 <= x1 && y0 <= y1) {
-            const int b = t / nf, fn = t - b * nf;
-            const int bw = x1 - x0 + 1, area = bw * (y1 - y0 + 1);
-            if (area <= kInlineBoxMax) {
-                unsigned long long *kb = keys + (size_t)b * is * is;
-                for (int yi = y0; yi <= y1; ++yi)
-                    for (int xi = x0; xi <= x1; ++xi) seen &= shade_pixel(v, inv, fn, xi, yi, is, near_z, far_z, kb);
-            } else {
-                const int slot = atomicAdd(&sh_n, 1);
+        if (!backside(v)) {
+            float px[3], py[3], inv[9], det;
+            face_inverse(v, is, px, py, inv, det);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) faces_inv[t * 9 + k] = inv[k];
+
+            const float xmn = fminf(fminf(px[0], px[1]), px[2]), xmx = fmaxf(fmaxf(px[0], px[1]), px[2]);
+            const float ymn = fminf(fminf(py[0], py[1]), py[2]), ymx = fmaxf(fmaxf(py[0], py[1]), py[2]);
+            const float ext = fmaxf(xmx - xmn, ymx - ymn);
+            bool finite = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) finite = finite && (px[k] - px[k] == 0.f) && (py[k] - py[k] == 0.f);
+            const bool sweep_all = !finite || !(fabsf(det) > kSliverRatio * ext * ext) ||
+                                   fmaxf(fmaxf(fabsf(xmn), fabsf(xmx)), fmaxf(fabsf(ymn), fabsf(ymx))) > kHugeCoord;
+            int x0 = 0, y0 = 0, x1 = is - 1, y1 = is - 1;
+            if (!sweep_all) {
+                // pixel xi sits at pixel-space coordinate xi exactly; one extra pixel of margin on every side
+                x0 = max(0, (int)floorf(xmn) - 1);
+                y0 = max(0, (int)floorf(ymn) - 1);
+                x1 = min(is - 1, (int)ceilf(xmx) + 1);
+                y1 = min(is - 1, (int)ceilf(ymx) + 1);
+            }
+            if (x0 <= x1 && y0 <= y1) {
                 Box bx;
                 bx.x0 = (unsigned short)x0; bx.y0 = (unsigned short)y0; bx.x1 = (unsigned short)x1; bx.y1 = (unsigned short)y1;
-                sh_t[slot] = t;
-                sh_box[slot] = bx;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    sh_v[slot][k] = v[k];
-                    sh_inv[slot][k] = inv[k];
-                }
+                pbox[t] = bx;
+                packed = (unsigned)((x0 / kTileW) >> tl.shx) | (unsigned)((y0 / kTileH) >> tl.shy) << 8 |
+                         (unsigned)((x1 / kTileW) >> tl.shx) << 16 | (unsigned)((y1 / kTileH) >> tl.shy) << 24;
             }
         }
     }
-    __syncthreads();
-    const int n = sh_n;
-    for (int e = 0; e < n; ++e) {
-        const int tt = sh_t[e];
-        const Box bx = sh_box[e];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            v[k] = sh_v[e][k];
-            inv[k] = sh_inv[e][k];
-        }
-        const int b = tt / nf, fn = tt - b * nf;
-        unsigned long long *kb = keys + (size_t)b * is * is;
-        const int bw = bx.x1 - bx.x0 + 1, area = bw * (bx.y1 - bx.y0 + 1);
-        for (int p = threadIdx.x; p < area; p += blockDim.x) {
-            const int yy = p / bw;
-            seen &= shade_pixel(v, inv, fn, bx.x0 + (p - yy * bw), bx.y0 + yy, is, near_z, far_z, kb);
-        }
-    }
-    // the wave has to hold the returned keys in registers here, i.e. wait for every atomic it issued
-    asm volatile("" ::"v"((unsigned)seen), "v"((unsigned)(seen >> 32)));
+    tbox[i] = packed;
 }
 
+// ------------------------------------------------------------------------------------------------ launch 2: tiles
 struct ResolveOut {
     int32_t *fim;      // (bs,is,is)
     float *wim;        // (bs,is,is,3)
@@ -236,21 +233,127 @@ struct ResolveOut {
     float *x0;                                             // (bs,is,is,8)
 };
 
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__restrict__ faces,
-                                                             const float *__restrict__ faces_inv,
-                                                             unsigned long long *__restrict__ keys, int bs,
-                                                             int nf, int is, float far_z, ResolveOut o)
+// depth test of one (face, pixel) pair against the tile's z-buffer in LDS
+__device__ __forceinline__ void shade_pixel(const float v[9], const float inv[9], int fn, int xi, int yi, int is,
+                                            float near_z, float far_z, unsigned long long *key)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int npix = is * is;
-    if (i >= bs * npix) return;
-    const int b = i / npix, pn = i - b * npix;
-    const int yo = pn / is, xi = pn - yo * is;
-    const int yi = is - 1 - yo;  // the maps are flipped vertically on the way out (rasterize.py:334-338)
+    const float xp = pixel_centre(xi, is), yp = pixel_centre(yi, is);
+    if (!inside(v, xp, yp)) return;
+    float w[3];
+    const float zp = bary_depth(v, inv, xi, yi, w);
+    // .cu:154-159: reject zp <= near, far <= zp; depth_min starts at far, so NaN never wins either
+    if (!(zp > near_z && zp < far_z)) return;
+    atomicMin(key, ((unsigned long long)order_bits(zp) << 32) | (unsigned)fn);
+}
 
-    // the keys are only ever touched at agent scope (store in the clear kernel, atomicMin, this load): their lines
-    // never sit in one XCD's L2 waiting for a kernel-boundary write-back / invalidate
-    const unsigned long long key = atomicMax(keys + (size_t)b * npix + (size_t)yi * is + xi, 0ull);
+__global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__restrict__ faces,
+                                                               const float *__restrict__ faces_inv,
+                                                               const Box *__restrict__ pbox,
+                                                               const unsigned *__restrict__ tbox, int nf, int nfp, int is,
+                                                               Tiling tl, float near_z, float far_z, ResolveOut o)
+{
+    __shared__ unsigned long long sh_key[kTilePix];
+    __shared__ int sh_list[kListCap];
+    __shared__ int sh_n, sh_nbig;
+
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % (tl.tiles_x * tl.tiles_y), b = blockIdx.x / (tl.tiles_x * tl.tiles_y);
+    const int ty = tile / tl.tiles_x, tx = tile - ty * tl.tiles_x;
+    const int ox = tx * kTileW, oy = ty * kTileH;             // tile origin, pre-flip orientation (as the .cu tests)
+    const int ex = min(ox + kTileW, is) - 1, ey = min(oy + kTileH, is) - 1;
+    const unsigned cx = (unsigned)(tx >> tl.shx), cy = (unsigned)(ty >> tl.shy);
+
+    sh_key[tid] = kKeyEmpty;
+    if (tid == 0) sh_n = sh_nbig = 0;
+
+    const float *fv = faces + (size_t)b * nf * 9;
+    const float *fi = faces_inv + (size_t)b * nf * 9;
+    const Box *fb = pbox + (size_t)b * nf;
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tbox + (size_t)b * nfp);
+
+    // step b of the header: every listed face against the tile's pixels
+    auto flush = [&](int n) {
+        for (int e = tid; e < n; e += kThreads) {
+            const int fn = sh_list[e];
+            const Box bx = fb[fn];
+            const int x0 = max((int)bx.x0, ox), x1 = min((int)bx.x1, ex);
+            const int y0 = max((int)bx.y0, oy), y1 = min((int)bx.y1, ey);
+            if (x0 > x1 || y0 > y1) continue;      // the packed box is coarser than the pixel box
+            if ((x1 - x0 + 1) * (y1 - y0 + 1) > kInlineBoxMax) {
+                sh_list[e] = fn | (int)0x80000000;  // left for the cooperative sweep below
+                sh_nbig = 1;
+                continue;
+            }
+            float v[9], inv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                v[k] = fv[(size_t)fn * 9 + k];
+                inv[k] = fi[(size_t)fn * 9 + k];
+            }
+            for (int yi = y0; yi <= y1; ++yi)
+                for (int xi = x0; xi <= x1; ++xi)
+                    shade_pixel(v, inv, fn, xi, yi, is, near_z, far_z, &sh_key[(yi - oy) * kTileW + (xi - ox)]);
+        }
+        __syncthreads();
+        if (!sh_nbig) return;
+        // faces with a large footprint in this tile: all lanes, one pixel each
+        const int lx = tid & (kTileW - 1), ly = tid / kTileW;
+        for (int e = 0; e < n; ++e) {
+            const int tagged = sh_list[e];
+            if (tagged >= 0) continue;
+            const int fn = __builtin_amdgcn_readfirstlane(tagged & 0x7fffffff);
+            const Box bx = fb[fn];
+            const int xi = ox + lx, yi = oy + ly;
+            if (xi < (int)bx.x0 || xi > (int)bx.x1 || yi < (int)bx.y0 || yi > (int)bx.y1 || xi > ex || yi > ey) continue;
+            float v[9], inv[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                v[k] = fv[(size_t)fn * 9 + k];
+                inv[k] = fi[(size_t)fn * 9 + k];
+            }
+            shade_pixel(v, inv, fn, xi, yi, is, near_z, far_z, &sh_key[tid]);
+        }
+    };
+
+    // step a: stream the packed boxes; `room` scan steps are certain to fit the list before its length has to be read
+    int f0 = 0;
+    while (f0 < nfp) {
+        __syncthreads();
+        int n = sh_n;
+        if (kListCap - n < kScanStep) {
+            flush(n);
+            __syncthreads();
+            if (tid == 0) sh_n = sh_nbig = 0;
+            __syncthreads();
+            n = 0;
+        }
+        const int room = (kListCap - n) / kScanStep;
+        for (int s = 0; s < room && f0 < nfp; ++s, f0 += kScanStep) {
+            const int f = f0 + tid * 4;
+            if (f >= nfp) continue;
+            const uint4 q = tb[f >> 2];
+            const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned tb0 = qq[k];
+                if (cx >= (tb0 & 255u) && cy >= ((tb0 >> 8) & 255u) && cx <= ((tb0 >> 16) & 255u) && cy <= (tb0 >> 24))
+                    sh_list[atomicAdd(&sh_n, 1)] = f + k;
+            }
+        }
+    }
+    __syncthreads();
+    flush(sh_n);
+    __syncthreads();
+
+    // step c: one lane per pixel
+    const int xi = ox + (tid & (kTileW - 1)), yi = oy + tid / kTileW;
+    if (xi >= is || yi >= is) return;
+    const int npix = is * is;
+    const int yo = is - 1 - yi;  // the maps are flipped vertically on the way out (rasterize.py:334-338)
+    const int pn = yo * is + xi;
+    const size_t i = (size_t)b * npix + pn;
+
+    const unsigned long long key = sh_key[tid];
     int fn = -1;
     float w[3] = {0.f, 0.f, 0.f};
     float zp = far_z;
@@ -258,18 +361,17 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__rest
         fn = (int)(unsigned)(key & 0xffffffffull);
         zp = unorder_bits((unsigned)(key >> 32));
         float v[9], inv[9];
-        const size_t t = (size_t)b * nf + fn;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            v[k] = faces[t * 9 + k];
-            inv[k] = faces_inv[t * 9 + k];
+            v[k] = fv[(size_t)fn * 9 + k];
+            inv[k] = fi[(size_t)fn * 9 + k];
         }
         (void)bary_depth(v, inv, xi, yi, w);
     }
     o.fim[i] = fn;
-    o.wim[(size_t)i * 3 + 0] = w[0];
-    o.wim[(size_t)i * 3 + 1] = w[1];
-    o.wim[(size_t)i * 3 + 2] = w[2];
+    o.wim[i * 3 + 0] = w[0];
+    o.wim[i * 3 + 1] = w[1];
+    o.wim[i * 3 + 2] = w[2];
     if (o.depth) o.depth[i] = zp;
 
     float cnd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -283,17 +385,17 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__rest
         }
     }
     if (!o.T) return;
-    float tx = -2.f, ty = -2.f;  // utils/nmr.py:626
+    float tx_ = -2.f, ty_ = -2.f;  // utils/nmr.py:626
     if (fn >= 0) {
         const float *p = o.src_p2verts + (size_t)fn * 6;
-        tx = (p[0] * w[0] + p[2] * w[1]) + p[4] * w[2];
-        ty = (p[1] * w[0] + p[3] * w[1]) + p[5] * w[2];
+        tx_ = (p[0] * w[0] + p[2] * w[1]) + p[4] * w[2];
+        ty_ = (p[1] * w[0] + p[3] * w[1]) + p[5] * w[2];
     }
-    *reinterpret_cast<float2 *>(o.T + (size_t)i * 2) = make_float2(tx, ty);
+    *reinterpret_cast<float2 *>(o.T + i * 2) = make_float2(tx_, ty_);
 
     if (!(o.tsf_img || o.x0)) return;
     float rgb[3] = {0.f, 0.f, 0.f};
-    const GridTaps g = grid_taps(tx, ty, is, is, o.align_corners);
+    const GridTaps g = grid_taps(tx_, ty_, is, is, o.align_corners);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float *pl = o.src_img + (size_t)c * npix;
@@ -306,7 +408,7 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__rest
         if (o.tsf_img) o.tsf_img[((size_t)b * 3 + c) * npix + pn] = acc;
     }
     if (o.x0) {
-        float4 *dst = reinterpret_cast<float4 *>(o.x0 + (size_t)i * 8);
+        float4 *dst = reinterpret_cast<float4 *>(o.x0 + i * 8);
         dst[0] = make_float4(rgb[0], rgb[1], rgb[2], cnd[0]);
         dst[1] = make_float4(cnd[1], cnd[2], 0.f, 0.f);
     }
@@ -365,33 +467,33 @@ __global__ __launch_bounds__(256) void bc_transform_kernel(const float *__restri
 }
 
 struct RasterWs {
-    unsigned long long *keys;
-    float *faces_inv;
+    float *faces_inv;   // (bs,nf,9)
+    Box *pbox;          // (bs,nf) pixel boxes
+    unsigned *tbox;     // (bs,nfp) packed tile boxes
 };
+
+inline int padded_faces(int nf) { return (nf + 3) & ~3; }
 
 size_t raster_ws_bytes(int bs, int nf, int is)
 {
+    (void)is;
     size_t n = 0;
-    n += align_up((size_t)bs * is * is * sizeof(unsigned long long), 256);
     n += align_up((size_t)bs * nf * 9 * sizeof(float), 256);
+    n += align_up((size_t)bs * nf * sizeof(Box), 256);
+    n += align_up((size_t)bs * padded_faces(nf) * sizeof(unsigned), 256);
     return n;
 }
 
-RasterWs carve(void *ws, int bs, int nf, int is)
+RasterWs carve(void *ws, int bs, int nf)
 {
     char *p = static_cast<char *>(ws);
     RasterWs r;
-    r.keys = reinterpret_cast<unsigned long long *>(p);
-    p += align_up((size_t)bs * is * is * sizeof(unsigned long long), 256);
     r.faces_inv = reinterpret_cast<float *>(p);
+    p += align_up((size_t)bs * nf * 9 * sizeof(float), 256);
+    r.pbox = reinterpret_cast<Box *>(p);
+    p += align_up((size_t)bs * nf * sizeof(Box), 256);
+    r.tbox = reinterpret_cast<unsigned *>(p);
     return r;
-}
-
-// Depth keys to "empty": an ordinary kernel of the launch sequence rather than a hipMemsetAsync.
-__global__ __launch_bounds__(256) void raster_clear_kernel(unsigned long long *__restrict__ keys, long n)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicMax(keys + i, kKeyEmpty);   // an RMW like the atomicMin of the faces: same coherent path
 }
 
 int check_raster_args(const void *faces, int bs, int nf, int is, const void *fim, const void *wim, const void *ws,
@@ -407,19 +509,24 @@ int check_raster_args(const void *faces, int bs, int nf, int is, const void *fim
     return LWG_OK;
 }
 
-int run_raster(const float *faces, int bs, int nf, int is, float near_z, float far_z, const ResolveOut &out,
-               void *ws, hipStream_t st)
+// verts != nullptr: faces (= f2verts) is produced from the posed mesh by the setup kernel; otherwise it is the input
+int run_raster(const float *verts, const float *cam, const int32_t *faces_idx, int nv, float eye_z, float *faces,
+               int bs, int nf, int is, float near_z, float far_z, const ResolveOut &out, void *ws, hipStream_t st)
 {
-    const RasterWs w = carve(ws, bs, nf, is);
-    const long nkeys = (long)bs * is * is;
-    raster_clear_kernel<<<ceil_div(nkeys, 256), 256, 0, st>>>(w.keys, nkeys);
-    LWG_LAUNCH_CHECK("raster_clear_kernel");
-    const int total = bs * nf;
-    raster_face_kernel<<<ceil_div(total, 256), 256, 0, st>>>(faces, total, nf, is, near_z, far_z, w.faces_inv, w.keys);
-    LWG_LAUNCH_CHECK("raster_face_kernel");
-    raster_resolve_kernel<<<ceil_div((long)bs * is * is, 256), 256, 0, st>>>(faces, w.faces_inv, w.keys, bs, nf, is,
-                                                                            far_z, out);
-    LWG_LAUNCH_CHECK("raster_resolve_kernel");
+    const RasterWs w = carve(ws, bs, nf);
+    const Tiling tl = tiling_for(is);
+    const int nfp = padded_faces(nf);
+    const int setup_blocks = ceil_div((long)bs * nfp, 256);
+    if (verts)
+        raster_setup_kernel<true><<<setup_blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, nfp, is,
+                                                                 tl, w.faces_inv, w.pbox, w.tbox);
+    else
+        raster_setup_kernel<false><<<setup_blocks, 256, 0, st>>>(nullptr, nullptr, nullptr, 0, 0.f, faces, bs, nf, nfp,
+                                                                  is, tl, w.faces_inv, w.pbox, w.tbox);
+    LWG_LAUNCH_CHECK("raster_setup_kernel");
+    raster_tile_kernel<<<bs * tl.tiles_x * tl.tiles_y, kThreads, 0, st>>>(faces, w.faces_inv, w.pbox, w.tbox, nf, nfp, is,
+                                                                           tl, near_z, far_z, out);
+    LWG_LAUNCH_CHECK("raster_tile_kernel");
     return LWG_OK;
 }
 
@@ -456,7 +563,9 @@ int lwg_rasterize_fim_wim(const float *faces, int bs, int nf, int image_size, fl
     o.fim = fim;
     o.wim = wim;
     o.depth = depth;
-    return run_raster(faces, bs, nf, image_size, near_z, far_z, o, workspace, as_stream(stream));
+    // the setup kernel only reads `faces` on this path
+    return run_raster(nullptr, nullptr, nullptr, 0, 0.f, const_cast<float *>(faces), bs, nf, image_size, near_z, far_z, o,
+                      workspace, as_stream(stream));
 }
 
 int lwg_encode_fim(const int32_t *fim, const float *map_fn, int bs, int npix, int nrows, int nc, int transpose,
@@ -501,8 +610,6 @@ int lwg_transfer_frame(const float *verts, const float *cam, const int32_t *face
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "transfer_frame: the NHWC8 generator input needs nc == 3 (got %d)", nc);
     int rc = check_raster_args(verts, bs, nf, image_size, fim, wim, workspace, workspace_bytes);
     if (rc != LWG_OK) return rc;
-    rc = lwg_project_faces(verts, cam, faces_idx, bs, nv, nf, eye_z, f2verts, stream);
-    if (rc != LWG_OK) return rc;
     ResolveOut o = {};
     o.fim = fim;
     o.wim = wim;
@@ -516,7 +623,8 @@ int lwg_transfer_frame(const float *verts, const float *cam, const int32_t *face
     o.align_corners = align_corners;
     o.tsf_img = tsf_img;
     o.x0 = tsf_inputs_nhwc8;
-    return run_raster(f2verts, bs, nf, image_size, near_z, far_z, o, workspace, as_stream(stream));
+    return run_raster(verts, cam, faces_idx, nv, eye_z, f2verts, bs, nf, image_size, near_z, far_z, o, workspace,
+                      as_stream(stream));
 }
 
 }  // extern "C"

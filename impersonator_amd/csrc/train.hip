@@ -303,11 +303,11 @@ int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin,
     const dim3 grid(ceil_div(I, T), O / T, (unsigned)(ntaps * S));
     const size_t lds = (size_t)4 * WG_PX * (T + 4) * sizeof(float);
     if (T == 128) {
-        static bool opt_in = false;
-        if (!opt_in) {
+        static DeviceOnce opt_in;
+        if (!opt_in.done()) {
             LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
-            opt_in = true;
+            opt_in.mark();
         }
         wgrad_kernel<128><<<grid, 256, lds, st>>>(go, O, in, I, N, Hin, Win, Hg, Wg, stride, pad, per, wout, KWd, ntaps, oihw);
     } else {

@@ -212,7 +212,7 @@ class Imitator(BaseModel):
 
     # ------------------------------------------------------------------ stream pipeline over batches
     lanes = 2   # generator engines (and HIP streams) predict_batches deals consecutive batches to; env LWG_LANES
-    overlap_geometry = os.environ.get("LWG_OVERLAP_GEOMETRY", "0") == "1"   # see predict_batches
+    overlap_geometry = os.environ.get("LWG_OVERLAP_GEOMETRY", "1") == "1"   # A/B switch while the tiled rasteriser is validated
 
     def _lanes(self, n):
         """n (stream, generator) pairs, each with its own HIP stream; lane 0 drives self.generator, the others an

@@ -178,6 +178,10 @@ class ImpersonatorGenerator(NetworkBase):
         _lib.check(lib.lwg_generator_set_precision(self._handle, self.PRECISIONS[self.precision]))
         ver = self._weights_version()
         if self._uploaded_version != ver:
+            if self._uploaded_version is not None and torch.cuda.is_available():
+                # lwg_generator_load_weight copies on the null stream, which does not order against PyTorch's
+                # non-blocking lane / side streams: kernels of earlier batches may still be reading the old weights
+                torch.cuda.synchronize()
             for key, val in self.state_dict().items():
                 arr = val.detach().to("cpu", torch.float32).contiguous()
                 shape = (ctypes.c_int64 * arr.dim())(*arr.shape)
@@ -202,6 +206,8 @@ class ImpersonatorGenerator(NetworkBase):
 
     def release(self):
         if self._handle is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()   # kernels enqueued on any stream may still use the handle's scratch / weights
             _lib.load().lwg_generator_destroy(self._handle)
             self._handle = None
 

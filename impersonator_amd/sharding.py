@@ -83,6 +83,26 @@ def gather_in_frame_order(local_items, num_frames, batch, rank, world):
     return out
 
 
+def imitate_sharded(imitator, tgt_smpls, batch, cam_strategy='smooth', rank=0, world=1):
+    """Motion imitation of a whole sequence on `world` ranks (what run_imitator.py runs; the reference loops frames on
+    one device, models/imitator.py:157-214): this rank pushes its round-robin blocks through
+    Imitator.predict_batches (geometry stream + generator lanes), results go to the host once per block, and rank 0
+    gets the (H,W,3) frames of ALL ranks in frame order (None elsewhere).  `first_cam` is frame 0's camera on every
+    rank (the reference discovers it at t == 0, imitator.py:243-244).  No data-path collective."""
+    import numpy as np
+    smpls = torch.as_tensor(np.asarray(tgt_smpls), dtype=torch.float32).reshape(len(tgt_smpls), -1).cuda()
+    n = smpls.shape[0]
+    if cam_strategy == 'smooth' and n:
+        imitator.first_cam = smpls[0:1, 0:3].clone()
+    blocks = shard_blocks(n, batch, rank, world)
+    # t = 0 would re-derive first_cam from the chunk, which is only right for the block that starts the sequence
+    chunks = ((smpls[s:e], s) for s, e in blocks)
+    local = []
+    for _, preds in imitator.predict_batches(chunks, cam_strategy):
+        local += list(preds.permute(0, 2, 3, 1).cpu().numpy())
+    return gather_in_frame_order(local, n, batch, rank, world)
+
+
 def average_gradients(flat_grads):
     """Data-parallel training: averages a flat gradient tensor over the ranks in place (all-reduce SUM
     then divide) -- RCCL over xGMI for CUDA tensors, gloo on CPU.  No-op without an initialised multi-rank group.  The

@@ -228,6 +228,32 @@ def source_p2verts(f2verts):
     return p
 
 
+def personalize(sd, src_img, src_cam, src_verts, faces_idx, map_fn, ft_ks=3, image_size=256):
+    """Imitator.personalize (models/imitator.py:95-143) given the posed source vertices and an explicit background:
+    source face-index map, p2verts (H9), cond, the eroded front mask and the cached source features."""
+    sf2v, sfim, _ = render_fim_wim(src_cam, src_verts, faces_idx, image_size)
+    p2v = source_p2verts(sf2v)
+    scond = encode_fim(sfim, map_fn)
+    ft = 1 - morph(scond[:, -1:], ft_ks, "erode")
+    enc, res = encode_src(sd, torch.cat([src_img * ft, scond], 1))
+    return dict(fim=sfim, p2verts=p2v, cond=scond, enc=enc, res=res)
+
+
+def imitator_frames(sd, src, src_img, bg_img, cam, verts, faces_idx, map_fn, image_size=256, align_corners=False,
+                    chunk=8):
+    """Imitator.transfer_params_by_smpl after the SMPL stage + Imitator.forward (models/imitator.py:250-260, 326-336) for
+    a sequence of posed meshes; `src` = personalize(...).  Returns (per-frame dict of fim / T / tsf_inputs, preds)."""
+    outs, preds = [], []
+    with torch.no_grad():
+        for s in range(0, verts.shape[0], chunk):
+            fr = transfer_frame(src_img, src["p2verts"], cam[s:s + chunk], verts[s:s + chunk], faces_idx, map_fn,
+                                image_size, align_corners)
+            outs.append(fr)
+            preds.append(imitator_forward(sd, src["enc"], src["res"], bg_img, fr["tsf_inputs"], fr["T"], align_corners)[0])
+    keys = ("fim", "T", "tsf_inputs", "cond", "wim")
+    return {k: torch.cat([o[k] for o in outs], 0) for k in keys}, torch.cat(preds, 0)
+
+
 def state_dict_from_numpy(sd_np):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
 

@@ -63,15 +63,8 @@ def main():
         tgt_paths = scan_tgt_paths(opt.tgt_path, itv=1)
         tgt_smpls = np.stack([_smpl_of(p) for p in tgt_paths])
 
-    # frame sharding: every rank imitates its own blocks of `batch_size` frames; first_cam is frame 0's camera
-    n = len(tgt_smpls)
-    imitator.first_cam = torch.from_numpy(tgt_smpls[0:1, 0:3]).cuda()
-    local = []
-    for s, e in sharding.shard_blocks(n, opt.batch_size, rank, world):
-        x = imitator.transfer_params_by_smpl(tgt_smpls[s:e], opt.cam_strategy, t=s)
-        preds = imitator.forward(x, imitator.tsf_info['T'])
-        local += list(preds.permute(0, 2, 3, 1).cpu().numpy())
-    outs = sharding.gather_in_frame_order(local, n, opt.batch_size, rank, world)
+    # frame sharding: every rank imitates its own blocks of `batch_size` frames (first_cam = frame 0's camera everywhere)
+    outs = sharding.imitate_sharded(imitator, tgt_smpls, opt.batch_size, opt.cam_strategy, rank, world)
     if rank == 0 and opt.output_dir:
         out_dir = util.mkdir(opt.output_dir)
         for t, img in enumerate(outs):

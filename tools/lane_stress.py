@@ -1,7 +1,8 @@
-"""Stress check of Imitator.predict_batches (development aid): N passes of six 4-frame batches through the lane
-pipeline, every batch compared bit for bit with transfer_params_by_smpl + forward run one after the other.
-    python tools/lane_stress.py [passes=40] [lanes=2,3]
-This is the run that exposed (and now guards) the rasteriser glitch described in DESIGN.md section 5.1."""
+"""Stress check of Imitator.predict_batches (development aid): N passes of six batches through the lane pipeline,
+every batch compared bit for bit with transfer_params_by_smpl + forward run one after the other.
+    python tools/lane_stress.py [passes=40] [lanes=2,3] [batch=8]
+This is the run that exposed the stale-depth-key glitch of the round-1 rasteriser (global 64-bit atomics) and now
+guards its tile-owned replacement."""
 import os
 import sys
 
@@ -12,11 +13,12 @@ from impersonator_amd import demo  # noqa: E402
 
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 lane_counts = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2,3").split(",")]
-im, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=4, seed=0, affine="random")
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+im, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=B, seed=0, affine="random")
 im.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
-smpls = torch.from_numpy(demo.synthetic_smpls(24, seed=3)).cuda()
+smpls = torch.from_numpy(demo.synthetic_smpls(6 * B, seed=3)).cuda()
 im.first_cam = smpls[0:1, 0:3].clone()
-chunks = [(smpls[s:s + 4], s) for s in range(0, 24, 4)]
+chunks = [(smpls[s:s + B], s) for s in range(0, 6 * B, B)]
 seq = []
 for chunk, t in chunks:
     x = im.transfer_params_by_smpl(chunk, "smooth", t=t)

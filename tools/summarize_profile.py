@@ -76,12 +76,27 @@ def traffic(fetch_csv, write_csv, out_json, out_md):
         for k, (n, v) in agg.items():
             res.setdefault(k, {})["launches"] = n
             res[k][key] = v / n
+    # stamp: bench.py attaches these bytes only while the kernel sources are the ones they were measured on
+    import hashlib, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h, d = hashlib.sha256(), os.path.join(root, "impersonator_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    commit = os.environ.get("LWG_COMMIT", "")
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        except Exception:
+            commit = "unknown (no .git on the GPU box; see the commit that added this file)"
+    res["_stamp"] = {"csrc_sha256": h.hexdigest(), "commit": commit}
     json.dump(res, open(out_json, "w"), indent=1, sort_keys=True)
     with open(out_md, "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two own passes) -- bench.py --steps 2\n\n"
                 "Fabric-side bytes per launch (L2 misses, Infinity-Cache hits included); FETCH_SIZE x2 (gfx950 tallies the 128-B\n"
                 "requests of 16-B/lane loads at 64 B), WRITE_SIZE as reported.\n\n| kernel | launches | read MB | written MB |\n|---|---|---|---|\n")
-        for k, v in sorted(res.items(), key=lambda kv: -kv[1].get("fetch_bytes_per_launch", 0) * kv[1].get("launches", 0))[:16]:
+        rows = [(k, v) for k, v in res.items() if k != "_stamp"]
+        for k, v in sorted(rows, key=lambda kv: -kv[1].get("fetch_bytes_per_launch", 0) * kv[1].get("launches", 0))[:16]:
             f.write("| `%s` | %d | %.1f | %.1f |\n" % (k, v.get("launches", 0), v.get("fetch_bytes_per_launch", 0) / 1e6,
                                                    v.get("write_bytes_per_launch", 0) / 1e6))
 
