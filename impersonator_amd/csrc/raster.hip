@@ -135,6 +135,15 @@ __device__ __forceinline__ float bary_depth(const float v[9], const float inv[9]
     return 1.f / (w[0] / v[2] + w[1] / v[5] + w[2] / v[8]);   // .cu: 1. / (double)(float sum), narrowed: same value
 }
 
+__device__ __forceinline__ void load_face(const float *fv, const float *fi, int fn, float v[9], float inv[9])
+{
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        v[k] = fv[(size_t)fn * 9 + k];
+        inv[k] = fi[(size_t)fn * 9 + k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launch 1: faces
 struct Tiling {
     int tiles_x, tiles_y;   // tiles of kTileW x kTileH pixels covering the image
@@ -203,11 +212,15 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const float *__restri
                                    fmaxf(fmaxf(fabsf(xmn), fabsf(xmx)), fmaxf(fabsf(ymn), fabsf(ymx))) > kHugeCoord;
             int x0 = 0, y0 = 0, x1 = is - 1, y1 = is - 1;
             if (!sweep_all) {
-                // pixel xi sits at pixel-space coordinate xi exactly; one extra pixel of margin on every side
-                x0 = max(0, (int)floorf(xmn) - 1);
-                y0 = max(0, (int)floorf(ymn) - 1);
-                x1 = min(is - 1, (int)ceilf(xmx) + 1);
-                y1 = min(is - 1, (int)ceilf(ymx) + 1);
+                // pixel xi sits at pixel-space coordinate xi exactly.  A pixel outside the triangle's hull by more
+                // than float rounding cannot pass all three edge tests: the products of an edge test carry ~2^-22
+                // relative error, which moves an edge of a face with |2*area| > kSliverRatio * ext^2 by less than
+                // ext * 2.4e-3 pixels; the margin is ten times that (at least 1/50 pixel)
+                const float m = fmaxf(0.02f, ext * 0.025f);
+                x0 = max(0, (int)ceilf(xmn - m));
+                y0 = max(0, (int)ceilf(ymn - m));
+                x1 = min(is - 1, (int)floorf(xmx + m));
+                y1 = min(is - 1, (int)floorf(ymx + m));
             }
             if (x0 <= x1 && y0 <= y1) {
                 Box bx;
@@ -233,11 +246,10 @@ struct ResolveOut {
     float *x0;                                             // (bs,is,is,8)
 };
 
-// depth test of one (face, pixel) pair against the tile's z-buffer in LDS
-__device__ __forceinline__ void shade_pixel(const float v[9], const float inv[9], int fn, int xi, int yi, int is,
-                                            float near_z, float far_z, unsigned long long *key)
+// depth test of one (face, pixel) pair against the tile's z-buffer in LDS; xp / yp = pixel centre (.cu:113-114)
+__device__ __forceinline__ void shade_pixel(const float v[9], const float inv[9], int fn, int xi, int yi, float xp,
+                                            float yp, float near_z, float far_z, unsigned long long *key)
 {
-    const float xp = pixel_centre(xi, is), yp = pixel_centre(yi, is);
     if (!inside(v, xp, yp)) return;
     float w[3];
     const float zp = bary_depth(v, inv, xi, yi, w);
@@ -245,6 +257,8 @@ __device__ __forceinline__ void shade_pixel(const float v[9], const float inv[9]
     if (!(zp > near_z && zp < far_z)) return;
     atomicMin(key, ((unsigned long long)order_bits(zp) << 32) | (unsigned)fn);
 }
+
+constexpr int kBigCap = 256;   // faces with a large footprint in the tile that get a wave each (more: all-lane sweep)
 
 __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__restrict__ faces,
                                                                const float *__restrict__ faces_inv,
@@ -254,6 +268,8 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
 {
     __shared__ unsigned long long sh_key[kTilePix];
     __shared__ int sh_list[kListCap];
+    __shared__ int sh_big[kBigCap];
+    __shared__ float sh_xp[kTileW], sh_yp[kTileH];
     __shared__ int sh_n, sh_nbig;
 
     const int tid = threadIdx.x;
@@ -265,6 +281,8 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
 
     sh_key[tid] = kKeyEmpty;
     if (tid == 0) sh_n = sh_nbig = 0;
+    if (tid < kTileW) sh_xp[tid] = pixel_centre(ox + tid, is);
+    else if (tid < kTileW + kTileH) sh_yp[tid - kTileW] = pixel_centre(oy + tid - kTileW, is);
 
     const float *fv = faces + (size_t)b * nf * 9;
     const float *fi = faces_inv + (size_t)b * nf * 9;
@@ -280,23 +298,41 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
             const int y0 = max((int)bx.y0, oy), y1 = min((int)bx.y1, ey);
             if (x0 > x1 || y0 > y1) continue;      // the packed box is coarser than the pixel box
             if ((x1 - x0 + 1) * (y1 - y0 + 1) > kInlineBoxMax) {
-                sh_list[e] = fn | (int)0x80000000;  // left for the cooperative sweep below
-                sh_nbig = 1;
+                const int slot = atomicAdd(&sh_nbig, 1);
+                if (slot < kBigCap) sh_big[slot] = fn;            // a wave will sweep it
+                else sh_list[e] = fn | (int)0x80000000;           // left for the all-lane sweep
                 continue;
             }
             float v[9], inv[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                v[k] = fv[(size_t)fn * 9 + k];
-                inv[k] = fi[(size_t)fn * 9 + k];
-            }
-            for (int yi = y0; yi <= y1; ++yi)
+            load_face(fv, fi, fn, v, inv);
+            for (int yi = y0; yi <= y1; ++yi) {
+                const float yp = sh_yp[yi - oy];
                 for (int xi = x0; xi <= x1; ++xi)
-                    shade_pixel(v, inv, fn, xi, yi, is, near_z, far_z, &sh_key[(yi - oy) * kTileW + (xi - ox)]);
+                    shade_pixel(v, inv, fn, xi, yi, sh_xp[xi - ox], yp, near_z, far_z,
+                                &sh_key[(yi - oy) * kTileW + (xi - ox)]);
+            }
         }
         __syncthreads();
-        if (!sh_nbig) return;
-        // faces with a large footprint in this tile: all lanes, one pixel each
+        const int nbig = sh_nbig;
+        if (!nbig) return;
+        // faces with a large footprint in this tile (at most the 256 pixels of the tile each): one wave per face
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int e = wave; e < min(nbig, kBigCap); e += kThreads / 64) {
+            const int fn = __builtin_amdgcn_readfirstlane(sh_big[e]);
+            const Box bx = fb[fn];
+            const int x0 = max((int)bx.x0, ox), x1 = min((int)bx.x1, ex);
+            const int y0 = max((int)bx.y0, oy), y1 = min((int)bx.y1, ey);
+            const int bw = x1 - x0 + 1, area = bw * (y1 - y0 + 1);
+            float v[9], inv[9];
+            load_face(fv, fi, fn, v, inv);
+            for (int p = lane; p < area; p += 64) {
+                const int yy = p / bw, xi = x0 + (p - yy * bw), yi = y0 + yy;
+                shade_pixel(v, inv, fn, xi, yi, sh_xp[xi - ox], sh_yp[yi - oy], near_z, far_z,
+                            &sh_key[(yi - oy) * kTileW + (xi - ox)]);
+            }
+        }
+        if (nbig <= kBigCap) return;
+        // more of them than the wave list holds (a frame full of slivers): all lanes, one pixel each, entry by entry
         const int lx = tid & (kTileW - 1), ly = tid / kTileW;
         for (int e = 0; e < n; ++e) {
             const int tagged = sh_list[e];
@@ -306,20 +342,19 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
             const int xi = ox + lx, yi = oy + ly;
             if (xi < (int)bx.x0 || xi > (int)bx.x1 || yi < (int)bx.y0 || yi > (int)bx.y1 || xi > ex || yi > ey) continue;
             float v[9], inv[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                v[k] = fv[(size_t)fn * 9 + k];
-                inv[k] = fi[(size_t)fn * 9 + k];
-            }
-            shade_pixel(v, inv, fn, xi, yi, is, near_z, far_z, &sh_key[tid]);
+            load_face(fv, fi, fn, v, inv);
+            shade_pixel(v, inv, fn, xi, yi, sh_xp[lx], sh_yp[ly], near_z, far_z, &sh_key[tid]);
         }
     };
 
-    // step a: stream the packed boxes; `room` scan steps are certain to fit the list before its length has to be read
+    // step a: stream the packed boxes.  The list length is read between two barriers (every wave sees the same value);
+    // `room` scan steps are then certain to fit the list, and their loads are issued together.
+    constexpr int kMaxRoom = kListCap / kScanStep;
     int f0 = 0;
     while (f0 < nfp) {
         __syncthreads();
         int n = sh_n;
+        __syncthreads();
         if (kListCap - n < kScanStep) {
             flush(n);
             __syncthreads();
@@ -328,11 +363,16 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
             n = 0;
         }
         const int room = (kListCap - n) / kScanStep;
-        for (int s = 0; s < room && f0 < nfp; ++s, f0 += kScanStep) {
-            const int f = f0 + tid * 4;
-            if (f >= nfp) continue;
-            const uint4 q = tb[f >> 2];
-            const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+        uint4 q[kMaxRoom];
+#pragma unroll
+        for (int s = 0; s < kMaxRoom; ++s) {
+            const int f = f0 + s * kScanStep + tid * 4;
+            q[s] = (s < room && f < nfp) ? tb[f >> 2] : make_uint4(kTileBoxEmpty, kTileBoxEmpty, kTileBoxEmpty, kTileBoxEmpty);
+        }
+#pragma unroll
+        for (int s = 0; s < kMaxRoom; ++s) {
+            const int f = f0 + s * kScanStep + tid * 4;
+            const unsigned qq[4] = {q[s].x, q[s].y, q[s].z, q[s].w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned tb0 = qq[k];
@@ -340,6 +380,7 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
                     sh_list[atomicAdd(&sh_n, 1)] = f + k;
             }
         }
+        f0 += room * kScanStep;
     }
     __syncthreads();
     flush(sh_n);
@@ -361,11 +402,7 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
         fn = (int)(unsigned)(key & 0xffffffffull);
         zp = unorder_bits((unsigned)(key >> 32));
         float v[9], inv[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            v[k] = fv[(size_t)fn * 9 + k];
-            inv[k] = fi[(size_t)fn * 9 + k];
-        }
+        load_face(fv, fi, fn, v, inv);
         (void)bary_depth(v, inv, xi, yi, w);
     }
     o.fim[i] = fn;

@@ -212,7 +212,6 @@ class Imitator(BaseModel):
 
     # ------------------------------------------------------------------ stream pipeline over batches
     lanes = 2   # generator engines (and HIP streams) predict_batches deals consecutive batches to; env LWG_LANES
-    overlap_geometry = os.environ.get("LWG_OVERLAP_GEOMETRY", "1") == "1"   # A/B switch while the tiled rasteriser is validated
 
     def _lanes(self, n):
         """n (stream, generator) pairs, each with its own HIP stream; lane 0 drives self.generator, the others an
@@ -227,23 +226,25 @@ class Imitator(BaseModel):
         return have[:n]
 
     @torch.no_grad()
-    def predict_batches(self, batches, cam_strategy='smooth', lanes=None):
+    def predict_batches(self, batches, cam_strategy='smooth', lanes=None, _overlap_geometry=False):
         """Yields (t, preds) for every (tgt_smpls_chunk, t) of `batches`, in order.  Frames are independent once the
         source is personalised, so consecutive batches are processed in rounds of `lanes`:
-          1. the geometry of the round's batches (swap_smpl, SMPL, rasteriser, flow, image warp: a dozen small kernels
-             sharing one workspace) runs batch after batch on a side stream, *with nothing else on the GPU*;
+          1. the geometry of the round's batches (swap_smpl, SMPL, rasteriser, flow, image warp: a dozen small kernels)
+             runs as ONE launch sequence over all the round's frames on a side stream, *with no generator running*;
           2. their generators then run side by side, each on its own stream and engine (scratch): a layer is
              conv -> finalize -> apply, every launch waiting for the one before, and the idle tails and launch gaps
              of one chain are filled by the other's kernels (+15 % frames/s at batch 8 with two lanes; a third adds
              1 %).
-        The next round's geometry waits for this round's generators.  That barrier is deliberate: with the geometry
-        overlapping generator kernels of other streams (which bought another 7 %), about one batch in 150 came out
-        with one 16-pixel run of a hidden face of the *previous* batch in its face-index map -- inputs, kernel order
-        and key accesses all checked out, the generators alone never
-        differed in 1800 concurrent batches, so until that is understood the rasteriser gets the chip to itself.
-        Events order every hand-over; round r+1 is enqueued before round r is yielded, so a consumer that
-        synchronises on a result (device->host copy) does not drain the pipeline.  Same results as
-        transfer_params_by_smpl + forward per batch."""
+        The next round's geometry waits for this round's generators.  That barrier is deliberate and measured
+        (DESIGN.md section 5.1): while bf16x3 convolution kernels of *other* HIP queues are running, the per-face
+        records one geometry kernel hands to the next through memory are occasionally read stale in 16-lane groups
+        (wrong pixels in ~90 % of six-batch passes, tools/lane_stress.py with overlap=1) -- with exact-fp32
+        generators, with one hardware queue, or with the geometry on its own, never.  It is a property of the
+        platform under that load, not of the rasteriser's algorithm (the round-1 rasteriser with global atomics and
+        the tile-owned one show it alike), so the pipeline does not create the situation; `_overlap_geometry=True`
+        exists for tools/lane_stress.py to reproduce it.  Events order every hand-over; round r+1 is enqueued before
+        round r is yielded, so a consumer that synchronises on a result (device->host copy) does not drain the
+        pipeline.  Same results as transfer_params_by_smpl + forward per batch."""
         import os
         nl = max(1, int(lanes if lanes is not None else os.environ.get("LWG_LANES", self.lanes)))
         main = torch.cuda.current_stream()
@@ -260,7 +261,7 @@ class Imitator(BaseModel):
             per lane; returns [(t, preds, info, done_event)]"""
             prepared = []
             with torch.cuda.stream(side):
-                if not self.overlap_geometry:
+                if not _overlap_geometry:
                     for ev in prev_done:
                         side.wait_event(ev)
                 sizes = [int(chunk.shape[0]) if chunk.dim() > 1 else 1 for chunk, _ in items]

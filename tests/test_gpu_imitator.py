@@ -144,8 +144,9 @@ def test_stream_pipeline_equals_the_sequential_path(imi, lanes):
 
 def test_lane_pipeline_stress(imi):
     """Thirty passes of the two-lane pipeline with a consumer that never synchronises (tools/lane_stress.py in small):
-    with the geometry overlapping the generators of other streams about one batch in 150 differed in one 16-pixel
-    run of its face-index map; the round structure of predict_batches must keep it at zero."""
+    with the geometry overlapping bf16x3 generators of other streams the geometry kernels read stale per-face records
+    (DESIGN.md section 5.1); the round structure of predict_batches never creates that situation and must stay at
+    zero differences."""
     imitator = imi[0]
     smpls = torch.from_numpy(demo.synthetic_smpls(24, seed=5)).cuda()
     imitator.first_cam = smpls[0:1, 0:3].clone()

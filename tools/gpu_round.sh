@@ -10,7 +10,7 @@ mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
 tail -5 $O/pytest.log
-timeout 600 python tools/lane_stress.py $PASSES 2,3 8 > $O/stress.log 2>&1; echo "stress rc=$?" | tee -a $O/stress.log
+timeout 600 python tools/lane_stress.py $PASSES 2,3 8 0 > $O/stress.log 2>&1; echo "stress rc=$?" | tee -a $O/stress.log
 tail -3 $O/stress.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 cut -c1-600 $O/bench.json
