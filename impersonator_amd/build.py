@@ -25,6 +25,7 @@ SOURCES = [
     ("smpl.hip", []),
     ("conv.hip", []),
     ("direct.hip", []),
+    ("heads.hip", []),
     ("generator.hip", []),
     ("inpaint.hip", []),
     ("train.hip", []),

@@ -121,5 +121,10 @@ struct HeadsArgs {
     float *pred;                    // NCHW, optional
 };
 int launch_heads(const HeadsArgs &a, hipStream_t st);
+// the same on the bf16x3 matrix path (heads.hip): `wfrag` = the weights packed into MFMA B fragments by
+// launch_heads_pack(wh [49][64][4], wfrag) (heads_bf16x3_frag_bytes() bytes, device)
+size_t heads_bf16x3_frag_bytes();
+int launch_heads_pack(const float *wh, void *wfrag, hipStream_t st);
+int launch_heads_bf16x3(const HeadsArgs &a, const void *wfrag, hipStream_t st);
 
 }  // namespace lwg

@@ -43,7 +43,7 @@ constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B align
 // WIDE: the raw output goes through LDS (one 32x32 tile per wave at a time, 36-float pitch) so that it leaves as
 // 16-byte stores, 8 per tile, instead of 32 four-byte ones: the epilogue is store-ISSUE bound.  Callers must have a
 // barrier between their last LDS reads and this call; the statistics scratch sits behind the staging area.
-template <int BN, int WM, int WN, bool WIDE = false>
+template <int BN, int WM, int WN, bool WIDE = false, int NWAVES = 4>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, int phase, f32x16 (&acc)[WM][WN],
                                                float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0,
                                                int mtile)
@@ -71,7 +71,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                     *reinterpret_cast<float4 *>(a.y + opix * a.ldy + n0 + wave_n * 32 * WN + j * 32 + rcol) = v;
                 }
             }
-        smem += 4 * 32 * TP;   // statistics scratch behind the staging tiles
+        smem += NWAVES * 32 * TP;   // statistics scratch behind the staging tiles
     } else {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -608,11 +608,14 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
 // no bank conflicts; the matrix pipe is 49% busy at a power-limited 2.1-2.2 GHz (a pure MFMA loop on random operands
 // reaches 80% of the 2.5 PFLOP/s dense peak on this part, tools/mfma_peak.hip).
 template <int BN, int WM, int WN, int NS = 3, int DBG = 0>
-__global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
+__global__ __launch_bounds__(64 * (BM / (32 * WM)) * (BN / (32 * WN))) void conv_igemm_bf16x3(const ConvArgs a)
 {
-    constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BM / (32 * WM);
-    static_assert(WAVES_M * WAVES_N == 4 && NS >= 3, "wave layout");
-    constexpr int A_CH = 4, B_CH = BN / 32;               // 1-KiB DMA chunks (8 rows x 128 B) per wave per stage
+    constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BM / (32 * WM), NW = WAVES_M * WAVES_N;
+    // 4 waves: one per SIMD.  8 waves: two per SIMD, each owning half as many 32x32 tiles -- while one of a SIMD's
+    // two waves sits in a DMA issue (~60 cycles), a counted wait or the stage barrier, the other one's MFMAs keep the
+    // matrix pipe busy.
+    static_assert((NW == 4 || NW == 8) && NS >= 3, "wave layout");
+    constexpr int A_CH = BM / 8 / NW, B_CH = BN / 8 / NW;   // 1-KiB DMA chunks (8 rows x 128 B) per wave per stage
     constexpr int LPS = A_CH + B_CH;
     constexpr int STAGE = (BM + BN) * BK;                 // floats (4-byte units) per ring slot
     constexpr int TILES = WM * WN;
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvArgs a)
         if (++slot == NS) slot = 0;
     }
 
-    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN, !(DBG & 128)>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
+    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN, !(DBG & 128), NW>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
     if (DBG & 32) {   // bench only: keep every MFMA alive without an epilogue
         float keep = 0.f;
 #pragma unroll
@@ -1311,9 +1314,22 @@ static void launch_k_dbg(const ConvArgs &a, int bn, hipStream_t st)
         conv_igemm_bf16x3<128, 2, 2, NS, DBG><<<grid, 256, lds, st>>>(a);
     }
 }
+template <int BN, int WM, int WN, int DBG>
+static void launch_w_dbg(const ConvArgs &a, hipStream_t st)
+{
+    const dim3 grid(a.mtiles, a.Cout / BN, a.nphase);
+    const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<BN, WM, WN, 3, DBG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    conv_igemm_bf16x3<BN, WM, WN, 3, DBG><<<grid, 64 * (BM / (32 * WM)) * (BN / (32 * WN)), lds, st>>>(a);
+}
 int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
 {
     switch (dbg) {
+        // eight waves (two per SIMD) on the same tile: wave tile 64x32 / 32x64 (bn 128), 32x32 (bn 64)
+        case 821: if (bn == 128) launch_w_dbg<128, 2, 1, 0>(a, st); else launch_w_dbg<64, 1, 1, 0>(a, st); break;
+        case 812: if (bn == 128) launch_w_dbg<128, 1, 2, 0>(a, st); else launch_w_dbg<64, 1, 1, 0>(a, st); break;
+        case 831: if (bn == 128) launch_w_dbg<128, 2, 1, 1>(a, st); else launch_w_dbg<64, 1, 1, 1>(a, st); break;   // no DMA
         case 200: launch_k_dbg<3, 0>(a, bn, st); break;
         case 201: launch_k_dbg<3, 1>(a, bn, st); break;   // no DMA
         case 204: launch_k_dbg<3, 4>(a, bn, st); break;   // no barrier

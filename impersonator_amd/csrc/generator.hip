@@ -47,6 +47,8 @@ struct StreamNet {
     std::vector<Layer> res;  // 2 per block
     Layer dec[kNDown], skip[kNDown];
     float *heads_w = nullptr;  // [49][64][4]
+    void *heads_frag = nullptr;       // heads_w as bf16x3 MFMA B fragments (heads.hip), repacked on the device when stale
+    bool heads_frag_stale = true;
     bool got_img = false, got_att = false;
     bool has_skip = true;      // false: BGNet (ResNetGenerator): decoders without skip connections, one 3-channel head
 };
@@ -209,6 +211,8 @@ int build_stream(StreamNet &s, int in_dim, int cd, int repeat, bool with_decoder
         }
         if ((rc = dev_alloc(&s.heads_w, 49 * 64 * 4)) != LWG_OK) return rc;
         LWG_HIP(hipMemset(s.heads_w, 0, 49 * 64 * 4 * sizeof(float)));
+        LWG_HIP(hipMalloc(&s.heads_frag, heads_bf16x3_frag_bytes()));
+        s.heads_frag_stale = true;
     }
     return LWG_OK;
 }
@@ -221,6 +225,8 @@ void free_stream(StreamNet &s)
     for (auto &L : s.skip) free_layer(L);
     if (s.heads_w) (void)hipFree(s.heads_w);
     s.heads_w = nullptr;
+    if (s.heads_frag) (void)hipFree(s.heads_frag);
+    s.heads_frag = nullptr;
 }
 
 // device copy of a re-laid-out weight matrix, plus the same matrix in the split-bf16 format (every Kpad is a
@@ -299,6 +305,7 @@ int upload_head(StreamNet &s, const float *w, const int64_t *shape, int ndim, in
         for (int ci = 0; ci < cd; ++ci)
             for (int t = 0; t < 49; ++t) h[((size_t)t * 64 + ci) * 4 + c0 + c] = w[((size_t)c * cd + ci) * 49 + t];
     LWG_HIP(hipMemcpy(s.heads_w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    s.heads_frag_stale = true;
     return LWG_OK;
 }
 
@@ -586,7 +593,12 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
     h.bg = bg;
     h.bg_bs = bg_bs;
     h.pred = pred;
-    return launch_heads(h, st);
+    if (!g->split) return launch_heads(h, st);   // exact fp32 on the vector ALU
+    if (g->tsf.heads_frag_stale) {
+        if ((rc = launch_heads_pack(s.heads_w, s.heads_frag, st)) != LWG_OK) return rc;
+        g->tsf.heads_frag_stale = false;
+    }
+    return launch_heads_bf16x3(h, s.heads_frag, st);
 }
 
 }  // namespace

@@ -8,8 +8,8 @@
 //                      6890-vertex regression is folded into two tiny host-precomputed tables), the kinematic
 //                      chain walked with 12 lanes (one per element of the 3x4 affine product) and the relative
 //                      bone transforms A (batch_smpl.py:193-216).
-//   smpl_verts_kernel  one lane per (frame, vertex): shape blend (10 terms), pose blend (207 terms, the only
-//                      real traffic: posedirs, 17 MB, L2-resident across the batch), skinning T = sum_j W_j A_j,
+//   smpl_verts_kernel  one lane per vertex coordinate and four frames: shape blend (10 terms), pose blend (207 terms,
+//                      the only real traffic: posedirs, 17 MB, streamed bs/4 times), skinning T = sum_j W_j A_j,
 //                      verts = T [v;1].
 //   smpl_joints_kernel 19 keypoints = joint_regressor^T verts (block reduction), part of the reference's
 //                      get_details() dictionary (hmr.py:302-330).
@@ -21,6 +21,7 @@ namespace {
 
 constexpr int NJ = 24;        // SMPL joints
 constexpr int NPF = 207;      // pose feature length = 23 * 9
+static_assert(NPF % 23 == 0, "the pose-blend loop walks 23 terms at a time");
 
 // workspace: pose feature (bs, 207) then A (bs, 24, 12)
 __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__ theta, int nb,
@@ -89,55 +90,90 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict__ theta, int nb, int nv,
-                                                         const float *__restrict__ v_template,
-                                                         const float *__restrict__ shapedirs,
-                                                         const float *__restrict__ posedirs,
-                                                         const float *__restrict__ weights,
-                                                         const float *__restrict__ pf, const float *__restrict__ A,
-                                                         float *__restrict__ verts)
+// One lane per vertex COORDINATE (v*3 + c) and up to VF frames of the batch: the pose-blend tables (posedirs, 207 rows
+// of nv*3 floats -- the only real traffic of SMPL) are read with fully coalesced 4-byte-per-lane loads and every
+// loaded value feeds VF frames' accumulators, so a batch streams them bs/VF times instead of bs times.  The three
+// coordinates of a vertex meet through LDS for the skinning: lane (v, c) builds row c of T = sum_j W_j A_j (24 x 4
+// terms instead of 24 x 12) and writes verts[v][c].  Every multiply-add is an explicit fmaf: left to the compiler,
+// the four frames of a lane were contracted differently (packed v_pk_fma for some, mul + add for others) and a
+// frame's vertices depended on its position in the batch in the last bit.  With fmaf every frame sees one fixed
+// operation sequence: results do not depend on the batch size or on the frame's position (tested bit for bit).
+constexpr int VB = 64;          // vertices per workgroup (192 lanes)
+constexpr int VF = 4;           // frames per lane
+__global__ __launch_bounds__(3 * VB) void smpl_verts_kernel(const float *__restrict__ theta, int nb, int nv, int bs,
+                                                            const float *__restrict__ v_template,
+                                                            const float *__restrict__ shapedirs,
+                                                            const float *__restrict__ posedirs,
+                                                            const float *__restrict__ weights,
+                                                            const float *__restrict__ pf, const float *__restrict__ A,
+                                                            float *__restrict__ verts)
 {
-    __shared__ float s_pf[NPF];
-    __shared__ float s_A[NJ * 12];
-    __shared__ float s_beta[16];
-    const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < NPF; i += 256) s_pf[i] = pf[(size_t)b * NPF + i];
-    for (int i = threadIdx.x; i < NJ * 12; i += 256) s_A[i] = A[(size_t)b * NJ * 12 + i];
-    if (threadIdx.x < nb && threadIdx.x < 16) s_beta[threadIdx.x] = theta[(size_t)b * (75 + nb) + 75 + threadIdx.x];
+    __shared__ float s_pf[VF][NPF];
+    __shared__ float s_A[VF][NJ * 12];
+    __shared__ float s_beta[VF][16];
+    __shared__ float s_p[VF][3 * VB];
+    const int b0 = blockIdx.y * VF, tid = threadIdx.x;
+    for (int i = tid; i < VF * NPF; i += 3 * VB) {
+        const int f = i / NPF, k = i - f * NPF;
+        s_pf[f][k] = b0 + f < bs ? pf[(size_t)(b0 + f) * NPF + k] : 0.f;
+    }
+    for (int i = tid; i < VF * NJ * 12; i += 3 * VB) {
+        const int f = i / (NJ * 12), k = i - f * NJ * 12;
+        s_A[f][k] = b0 + f < bs ? A[(size_t)(b0 + f) * NJ * 12 + k] : 0.f;
+    }
+    if (tid < VF * 16) {
+        const int f = tid >> 4, k = tid & 15;
+        s_beta[f][k] = (b0 + f < bs && k < nb) ? theta[(size_t)(b0 + f) * (75 + nb) + 75 + k] : 0.f;
+    }
     __syncthreads();
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= nv) return;
-    const size_t row = (size_t)nv * 3, col = (size_t)v * 3;
-
-    float p0 = v_template[col], p1 = v_template[col + 1], p2 = v_template[col + 2];
-    for (int k = 0; k < nb; ++k) {
-        const float *sd = shapedirs + k * row + col;
-        p0 += s_beta[k] * sd[0];
-        p1 += s_beta[k] * sd[1];
-        p2 += s_beta[k] * sd[2];
-    }
-#pragma unroll 4
-    for (int k = 0; k < NPF; ++k) {
-        const float *pd = posedirs + k * row + col;
-        const float f = s_pf[k];
-        p0 += f * pd[0];
-        p1 += f * pd[1];
-        p2 += f * pd[2];
-    }
-    float T[12];
+    const size_t row = (size_t)nv * 3;
+    const int e = blockIdx.x * 3 * VB + tid;
+    const bool ok = e < nv * 3;
+    float p[VF];
+    if (ok) {
+        const float vt = v_template[e];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int f = 0; f < VF; ++f) p[f] = vt;
+        for (int k = 0; k < nb; ++k) {
+            const float sd = shapedirs[k * row + e];
+#pragma unroll
+            for (int f = 0; f < VF; ++f) p[f] = fmaf(s_beta[f][k], sd, p[f]);
+        }
+        // 207 = 9 x 23: 23 independent loads in flight per lane (the kernel runs at ~3 waves per CU: latency-bound)
+        for (int k0 = 0; k0 < NPF; k0 += 23) {
+            float pd[23];
+#pragma unroll
+            for (int j = 0; j < 23; ++j) pd[j] = posedirs[(k0 + j) * row + e];
+#pragma unroll
+            for (int j = 0; j < 23; ++j)
+#pragma unroll
+                for (int f = 0; f < VF; ++f) p[f] = fmaf(s_pf[f][k0 + j], pd[j], p[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < VF; ++f) s_p[f][tid] = p[f];
+    }
+    __syncthreads();
+    if (!ok) return;
+    const int v = e / 3, c = e - v * 3, vl = (tid / 3) * 3;
+    float T[VF][4];
+#pragma unroll
+    for (int f = 0; f < VF; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[f][q] = 0.f;
     const float *w = weights + (size_t)v * NJ;
 #pragma unroll 4
     for (int j = 0; j < NJ; ++j) {
         const float wj = w[j];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] += wj * s_A[j * 12 + e];
+        for (int f = 0; f < VF; ++f)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[f][q] = fmaf(wj, s_A[f][j * 12 + c * 4 + q], T[f][q]);
     }
-    float *o = verts + ((size_t)b * nv + v) * 3;
-    o[0] = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
-    o[1] = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
-    o[2] = T[8] * p0 + T[9] * p1 + T[10] * p2 + T[11];
+#pragma unroll
+    for (int f = 0; f < VF; ++f)
+        if (b0 + f < bs)
+            verts[((size_t)(b0 + f) * nv + v) * 3 + c] =
+                fmaf(T[f][2], s_p[f][vl + 2], fmaf(T[f][1], s_p[f][vl + 1], T[f][0] * s_p[f][vl])) + T[f][3];
 }
 
 // grid (n_out_joints, bs): joints[b][j][:] = sum_v verts[b][v][:] * joint_regressor[v][j]
@@ -200,8 +236,8 @@ int lwg_smpl_forward(const float *theta, int bs, int num_betas, int nv, int num_
     float *A = pf + (size_t)bs * NPF;
     smpl_pose_kernel<<<bs, 64, 0, st>>>(theta, num_betas, J_template, J_shapedirs, parents, pf, A, Rs);
     LWG_LAUNCH_CHECK("smpl_pose_kernel");
-    smpl_verts_kernel<<<dim3(ceil_div(nv, 256), bs), 256, 0, st>>>(theta, num_betas, nv, v_template, shapedirs,
-                                                                   posedirs, weights, pf, A, verts);
+    smpl_verts_kernel<<<dim3(ceil_div((long)nv * 3, 3 * VB), ceil_div(bs, VF)), 3 * VB, 0, st>>>(
+        theta, num_betas, nv, bs, v_template, shapedirs, posedirs, weights, pf, A, verts);
     LWG_LAUNCH_CHECK("smpl_verts_kernel");
     if (joints) {
         smpl_joints_kernel<<<dim3(num_out_joints, bs), 256, 0, st>>>(verts, joint_regressor, nv, num_out_joints, joints);

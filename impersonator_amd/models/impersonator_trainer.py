@@ -31,6 +31,13 @@ class Impersonator(BaseModel):
         for flag in ('use_vgg', 'use_style', 'use_face'):
             if getattr(opt, flag, False):
                 raise NotImplementedError("--%s needs a pretrained network that is a download of the reference" % flag)
+        # impersonator_trainer.py:251-254 switches the mask criterion to BCELoss under --mask_bce and :333-337 runs BGNet on
+        # both backgrounds under --bg_both; GeneratorTrainer implements the MSE mask loss and one background stream, so
+        # these flags must not be silently ignored (the reference's train_iPER.sh passes --mask_bce)
+        for flag in ('mask_bce', 'bg_both'):
+            if getattr(opt, flag, False):
+                raise NotImplementedError("--%s is not implemented in the MI355X generator update (MSE mask loss, one "
+                                          "background stream); training with it would diverge from the reference" % flag)
         self._g_trainer = None
         self._real_src = self._bg_mask = None
 

@@ -61,7 +61,11 @@ LWG_API int lwg_project_faces(const float *verts, const float *cam, const int32_
  * rasterize_cuda_kernel.cu:40-186) together with the fills of rasterize.py:50-52 and the vertical
  * flips of rasterize.py:334-338.  faces (bs,nf,3,3) -> fim int32 (bs,is,is) [-1 = background],
  * wim (bs,is,is,3) [0 where uncovered], depth (bs,is,is) [far where uncovered] or NULL.
- * Results are bit-identical to the reference algorithm (lowest face index wins depth ties). */
+ * Results are bit-identical to the UNcontracted (no fused multiply-add) evaluation of the .cu file's float
+ * expressions, lowest face index winning depth ties; nvcc contracts a*b+c by default, which moves the barycentric
+ * weights of a CUDA build by the amounts tabulated in profiles/r02_fma_sensitivity.md (coverage and face indices: 0).
+ * Stateless between calls (the workspace is scratch for the duration of one call): no global atomics, no depth buffer
+ * in memory.  workspace: lwg_rasterize_workspace_bytes, 256-byte aligned. */
 LWG_API size_t lwg_rasterize_workspace_bytes(int bs, int nf, int image_size);
 LWG_API int lwg_rasterize_fim_wim(const float *faces, int bs, int nf, int image_size, float near_z, float far_z,
                                   int32_t *fim, float *wim, float *depth, void *workspace, size_t workspace_bytes,

@@ -112,9 +112,11 @@ def test_smpl_device_kernels_match_tensor_op_formulation():
     assert float((dv.cpu() - v).abs().max()) <= 1e-5
     assert float((dj.cpu() - j).abs().max()) <= 2e-5
     assert float((dRs.cpu() - Rs).abs().max()) <= 1e-6
-    # batch-size invariance of the device kernels (bit for bit)
-    dv1, _, _ = md(beta[2:3].cuda(), theta[2:3].cuda(), get_skin=True)
-    assert torch.equal(dv1, dv[2:3])
+    # batch-size / batch-position invariance of the device kernels, bit for bit (the vertex kernel handles four frames
+    # per lane: every position of a group, and a second group, must give the numbers of a batch of one)
+    for i in range(5):
+        dv1, dj1, _ = md(beta[i:i + 1].cuda(), theta[i:i + 1].cuda(), get_skin=True)
+        assert torch.equal(dv1, dv[i:i + 1]) and torch.equal(dj1, dj[i:i + 1]), "frame %d depends on its batch" % i
 
 
 @pytest.mark.parametrize("lanes", [1, 2, 3])

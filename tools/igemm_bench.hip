@@ -24,7 +24,7 @@ int main(int argc, char **argv)
         {"skip2 128->64 @256 (bn64)", 8, 256, 128, 64, 3, 1, 64},
         {"enc3 256->512 s2 @64 (bn64)", 8, 64, 256, 512, 3, 2, 64},
     };
-    const int dbgs[] = {100, 200, 456, 264, 232, 201, 213, 200};
+    const int dbgs[] = {100, 200, 821, 812, 831, 201, 200, 821};
     hipStream_t st;
     hipStreamCreate(&st);
     hipEvent_t e0, e1;
@@ -96,9 +96,17 @@ int main(int argc, char **argv)
             a.x = xs;
             a.zeros = xs + xin;
             hipMemset(y, 0, yout * 4);
-            launch_conv_igemm_dbg(a, s.bn, 200, st);
+            launch_conv_igemm_dbg(a, s.bn, 821, st);   // the 8-wave variant must reproduce the 4-wave numbers (checked below too)
             hipStreamSynchronize(st);
             hipMemcpy(y1.data(), y, yout * 4, hipMemcpyDeviceToHost);
+            std::vector<float> y2(yout);
+            hipMemset(y, 0, yout * 4);
+            launch_conv_igemm_dbg(a, s.bn, 200, st);
+            hipStreamSynchronize(st);
+            hipMemcpy(y2.data(), y, yout * 4, hipMemcpyDeviceToHost);
+            size_t nbad = 0;
+            for (size_t i = 0; i < yout; ++i) nbad += y1[i] != y2[i];
+            printf("  8w!=4w: %zu", nbad);
             double md = 0, mx = 0;
             for (size_t i = 0; i < yout; ++i) {
                 md = fmax(md, fabs((double)y0[i] - y1[i]));

@@ -17,6 +17,16 @@ im.first_cam = smpls[0:1, 0:3].clone()
 for bs in (1, 8, 16):
     tsf = im.swap_smpl(im.src_info['cam'], im.src_info['shape'], smpls[8:8 + bs])
     info = im.hmr.get_details(tsf)
+    for _ in range(10):
+        im.hmr.get_details(tsf)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        im.hmr.get_details(tsf)
+    e1.record()
+    torch.cuda.synchronize()
+    print("get_details (SMPL) bs=%2d: %.1f us per call" % (bs, e0.elapsed_time(e1) * 1e3 / iters))
     r = im.render
     for _ in range(10):
         r.transfer(info['cam'], info['verts'], im.src_info['p2verts_c'], im.src_info['img'])
