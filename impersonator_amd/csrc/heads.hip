@@ -23,7 +23,10 @@
 //     (one spare, so that the row loop unrolls eight times: ring positions and the two alternating load buffers are
 //     all compile-time);
 //   * a finished output row leaves through 4 KiB of wave-private LDS for the horizontal sum, then tanh / sigmoid /
-//     blend and plain stores to the NCHW planes.
+//     blend and plain stores to the NCHW planes;
+//   * each step is one basic block in which the MFMAs of row r, the loads of row r + 2, the conversion of row r + 1
+//     and the reduction of the previous output row are interleaved (sched_group_barrier): with the phases one after
+//     the other the matrix pipe idled 65 % of the time.
 // Products are evaluated as lo*hi + hi*lo + hi*hi with fp32 accumulation, as in conv_igemm_bf16x3 (conv.h).
 #include <type_traits>
 
@@ -106,108 +109,149 @@ __global__ __launch_bounds__(64) void heads_bf16x3_kernel(const HeadsArgs a, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
-    RowRegs buf[2];   // rows of even / odd steps; the load issued in step `it` (after its row was converted) fetches row it + 2
-#pragma unroll
-    for (int q = 0; q < 2 * HS_KS; ++q) buf[0].raw[q] = buf[1].raw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Software pipeline (a wave is alone on its SIMD: only its own instruction stream can overlap the matrix pipe, and
+    // every s_waitcnt is dead time -- a first version that loaded the background value right before the blend and read
+    // each B-lo fragment right before its MFMA sat in s_waitcnt 47 % of the time).  Step `it` (input row r = y0 - 3 + it):
+    //     at the top: loads of input row r + 2 (into the raw buffer row r has left) and of the background pixels the
+    //                 step will blend at its end; accumulator tile of the output row finished by step it - 1 -> LDS;
+    //     four k-step blocks: 7 B-lo fragment reads (LDS) issued ahead of the 21 MFMAs that cover their latency
+    //                 (lo*hi, hi*hi, then hi*lo), then the same k-step of row r + 1 is converted IN PLACE (raw fp32 ->
+    //                 normalise, ReLU, bf16 hi / lo), its fragment registers being dead by then;
+    //     between them: horizontal sum + activations of the finished output row; plain stores at the end.
+    // Rows outside the image take the same path with their fragments forced to zero (no branch splits the block);
+    // loads clamp their address instead of being predicated.
+    struct Frag { bf16x8_t hi[HS_KS], lo[HS_KS]; };
+    RowRegs raw[2];
+    Frag frag;
     auto load_row = [&](int r, RowRegs &dst) {
-        if (col_ok && r >= 0 && r < a.H) {
-            const float *p = xin + (size_t)r * row_stride;
+        const int rc = min(max(r, 0), a.H - 1);
+        const float *p = xin + (size_t)rc * row_stride;
 #pragma unroll
-            for (int ks = 0; ks < HS_KS; ++ks) {
-                dst.raw[2 * ks] = *reinterpret_cast<const float4 *>(p + ks * 16);
-                dst.raw[2 * ks + 1] = *reinterpret_cast<const float4 *>(p + ks * 16 + 4);
-            }
+        for (int ks = 0; ks < HS_KS; ++ks) {
+            dst.raw[2 * ks] = *reinterpret_cast<const float4 *>(p + ks * 16);
+            dst.raw[2 * ks + 1] = *reinterpret_cast<const float4 *>(p + ks * 16 + 4);
         }
+    };
+    auto convert = [&](int r, const RowRegs &src, int ks, Frag &f) {
+        const bool ok = col_ok && r >= 0 && r < a.H;   // zero padding applies to the NORMALISED activation
+        const float4 q0 = src.raw[2 * ks], q1 = src.raw[2 * ks + 1];
+        const float raw8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const float4 *ssp = reinterpret_cast<const float4 *>(s_ss + ks * 16 + kh2 * 8);
+        bf16x8_t h, l;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const float4 ss2 = ssp[e2];   // (scale, shift) of channels 2*e2, 2*e2 + 1
+            const float v0 = fmaxf(fmaf(raw8[2 * e2], ss2.x, ss2.y), 0.f);
+            const float v1 = fmaxf(fmaf(raw8[2 * e2 + 1], ss2.z, ss2.w), 0.f);
+            const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+            h[2 * e2] = h0;
+            h[2 * e2 + 1] = h1;
+            l[2 * e2] = (__bf16)(v0 - (float)h0);
+            l[2 * e2 + 1] = (__bf16)(v1 - (float)h1);
+        }
+        const uint4 hz = __builtin_bit_cast(uint4, h), lz = __builtin_bit_cast(uint4, l);
+        f.hi[ks] = __builtin_bit_cast(bf16x8_t, ok ? hz : make_uint4(0u, 0u, 0u, 0u));
+        f.lo[ks] = __builtin_bit_cast(bf16x8_t, ok ? lz : make_uint4(0u, 0u, 0u, 0u));
     };
 
     const size_t hw = (size_t)a.H * a.W;
-    // a finished output row: accumulator tile -> LDS -> horizontal sum over kw -> activations, blend, stores
-    auto emit = [&](const f32x16 &u, int y) {
+    const int xl = lane & 31, half = lane >> 5;               // half 0: colour 0, 1;  half 1: colour 2, mask
+    const int oxc = min(xs0 + min(xl, HS_OUT - 1), a.W - 1);  // clamped output column (address of the background prefetch)
+    // background pixels of one output row for this lane's two channels (channel 3 is the mask: reads channel 2's, unused)
+    const float *bgp = a.pred ? a.bg + (size_t)(a.bg_bs > 1 ? n : 0) * 3 * hw : a.x;
+    struct Bg { float v[2]; };
+    auto load_bg = [&](int y) {
+        const size_t p = (size_t)min(max(y, 0), a.H - 1) * a.W + oxc;
+        Bg b;
+        b.v[0] = bgp[(size_t)(half * 2) * hw + p];
+        b.v[1] = bgp[(size_t)(half ? 2 : 1) * hw + p];
+        return b;
+    };
+    struct Out { float c0, c1, msk; };
+    auto tile_to_lds = [&](const f32x16 &u) {
         const int col = lane & 31, rsel = 4 * (lane >> 5);   // C/D layout: column n = lane & 31, row as below
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_u[((r & 3) + 8 * (r >> 2) + rsel) * HS_UP + col] = u[r];
-        const int xl = lane & 31, half = lane >> 5;           // half 0: colour 0, 1;  half 1: colour 2, mask
+    };
+    auto reduce_row = [&]() {
+        const int xr = min(xl, HS_OUT - 1);
         float s0 = 0.f, s1 = 0.f;
-        if (xl < HS_OUT) {
 #pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-                s0 += s_u[(xl + kw) * HS_UP + kw * 4 + half * 2];
-                s1 += s_u[(xl + kw) * HS_UP + kw * 4 + half * 2 + 1];
-            }
+        for (int kw = 0; kw < 7; ++kw) {
+            s0 += s_u[(xr + kw) * HS_UP + kw * 4 + half * 2];
+            s1 += s_u[(xr + kw) * HS_UP + kw * 4 + half * 2 + 1];
         }
-        const float v0 = tanhf(s0);
-        const float v1 = half ? 1.f / (1.f + expf(-s1)) : tanhf(s1);
-        const float msk = __shfl(v1, 32 + xl);                // the mask sits in the upper half's v1
+        // tanh(x) = 1 - 2 / (1 + e^{2x}), sigmoid(x) = 1 / (1 + e^{-x}) on the hardware exp2 / rcp (~1e-6 absolute)
+        const float e0 = __expf(2.f * s0);
+        const float e1 = __expf(half ? -s1 : 2.f * s1);
+        const float r0 = __builtin_amdgcn_rcpf(1.f + e0), r1 = __builtin_amdgcn_rcpf(1.f + e1);
+        Out o;
+        o.c0 = fmaf(-2.f, r0, 1.f);
+        o.c1 = half ? r1 : fmaf(-2.f, r1, 1.f);
+        o.msk = __shfl(o.c1, 32 + xl);                        // the mask sits in the upper half's c1
+        return o;
+    };
+    auto store_row = [&](const Out &o, const Bg &b, int y) {
         const int ox = xs0 + xl;
-        if (xl >= HS_OUT || ox >= a.W) return;
+        if (y < y0 || y >= y1 || xl >= HS_OUT || ox >= a.W) return;
         const size_t p = (size_t)y * a.W + ox;
-        const int c0 = half * 2;
-        const float cv[2] = {v0, v1};
+        const float cv[2] = {o.c0, o.c1};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int c = c0 + k;
+            const int c = half * 2 + k;
             if (c == 3) {
-                if (a.mask) a.mask[(size_t)n * hw + p] = msk;
+                if (a.mask) a.mask[(size_t)n * hw + p] = o.msk;
                 continue;
             }
             if (a.color) a.color[((size_t)n * 3 + c) * hw + p] = cv[k];
-            if (a.pred) {
-                const float b = a.bg[((size_t)(a.bg_bs > 1 ? n : 0) * 3 + c) * hw + p];
-                a.pred[((size_t)n * 3 + c) * hw + p] = msk * b + (1.f - msk) * cv[k];
-            }
+            if (a.pred) a.pred[((size_t)n * 3 + c) * hw + p] = o.msk * b.v[k] + (1.f - o.msk) * cv[k];
         }
     };
 
     const int niter = y1 - y0 + 6;   // input rows y0-3 .. y1+2
-    load_row(y0 - 3, buf[0]);
-    load_row(y0 - 2, buf[1]);
+    load_row(y0 - 3, raw[0]);
+    load_row(y0 - 2, raw[1]);
+#pragma unroll
+    for (int ks = 0; ks < HS_KS; ++ks) convert(y0 - 3, raw[0], ks, frag);
 
-    // one input row; PH = (iteration index) mod 8 fixes every ring position and the load buffer at compile time
+    // PH = (iteration index) mod 8 fixes every ring position and the buffer parity at compile time
     auto row_step = [&](int it, auto ph_c) {
         constexpr int PH = decltype(ph_c)::value;
-        RowRegs &cur = buf[PH & 1];
+        constexpr int PREV = (PH + RING - 1) % RING;
         const int r = y0 - 3 + it;
-        if (r >= 0 && r < a.H) {   // wave-uniform
-            bf16x8_t ah[HS_KS], al[HS_KS];
+        const Bg bgv = load_bg(r - 4);
+        load_row(r + 2, raw[PH & 1]);
+        // the output row the PREVIOUS step completed (y = r - 4): its ring slot is not touched by this step's MFMAs
+        tile_to_lds(acc[PREV]);
 #pragma unroll
-            for (int ks = 0; ks < HS_KS; ++ks) {
-                const float4 q0 = cur.raw[2 * ks], q1 = cur.raw[2 * ks + 1];
-                const float raw8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                const float4 *ssp = reinterpret_cast<const float4 *>(s_ss + ks * 16 + kh2 * 8);
+        for (int q = 0; q < 16; ++q) acc[PREV][q] = 0.f;
+        Out o;
 #pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) {
-                    const float4 ss2 = ssp[e2];   // (scale, shift) of channels 2*e2, 2*e2 + 1
-                    float v0 = fmaxf(raw8[2 * e2] * ss2.x + ss2.y, 0.f);
-                    float v1 = fmaxf(raw8[2 * e2 + 1] * ss2.z + ss2.w, 0.f);
-                    if (!col_ok) v0 = v1 = 0.f;   // zero padding applies to the NORMALISED activation
-                    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
-                    ah[ks][2 * e2] = h0;
-                    ah[ks][2 * e2 + 1] = h1;
-                    al[ks][2 * e2] = (__bf16)(v0 - (float)h0);
-                    al[ks][2 * e2 + 1] = (__bf16)(v1 - (float)h1);
+        for (int ks = 0; ks < HS_KS; ++ks) {
+            bf16x8_t bl[7];
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) bl[kh] = __builtin_bit_cast(bf16x8_t, s_bl[(kh * HS_KS + ks) * 64 + lane]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)   // lo*hi, hi*hi, hi*lo: the LDS-fed product last
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh) {
+                    const int slot = (PH - kh + 6 + RING) % RING;   // output row r - kh + 3
+                    const bf16x8_t av = t == 0 ? frag.lo[ks] : frag.hi[ks];
+                    const bf16x8_t bv = t == 2 ? bl[kh] : bh[kh * HS_KS + ks];
+                    acc[slot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[slot], 0, 0, 0);
                 }
+            if (ks == 1) o = reduce_row();
+            convert(r + 1, raw[(PH + 1) & 1], ks, frag);
+            // one MFMA, then a few of the independent vector / LDS instructions of this block
+#pragma unroll
+            for (int g2 = 0; g2 < 21; ++g2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            load_row(r + 2, cur);   // this buffer is free again: its next use is two steps away
-#pragma unroll
-            for (int t = 0; t < 3; ++t)   // cross terms first, hi*hi last (as conv_igemm_bf16x3)
-#pragma unroll
-                for (int ks = 0; ks < HS_KS; ++ks)
-#pragma unroll
-                    for (int kh = 0; kh < 7; ++kh) {
-                        const int slot = (PH - kh + 6 + RING) % RING;   // output row r - kh + 3
-                        const bf16x8_t av = t == 0 ? al[ks] : ah[ks];
-                        const bf16x8_t bv = t == 1 ? __builtin_bit_cast(bf16x8_t, s_bl[(kh * HS_KS + ks) * 64 + lane])
-                                                   : bh[kh * HS_KS + ks];
-                        acc[slot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[slot], 0, 0, 0);
-                    }
-        } else {
-            load_row(r + 2, cur);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // output row r - 3 has received all seven input rows
-        const int y = r - 3;
-        if (y >= y0 && y < y1) emit(acc[PH], y);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[PH][q] = 0.f;
+        store_row(o, bgv, r - 4);
     };
 
     for (int it = 0; it < niter; it += RING) {
@@ -219,6 +263,23 @@ __global__ __launch_bounds__(64) void heads_bf16x3_kernel(const HeadsArgs a, con
         if (it + 5 < niter) row_step(it + 5, std::integral_constant<int, 5>{});
         if (it + 6 < niter) row_step(it + 6, std::integral_constant<int, 6>{});
         if (it + 7 < niter) row_step(it + 7, std::integral_constant<int, 7>{});
+    }
+    // the last step's output row (y1 - 1) is still in its ring slot
+    {
+        const int last = niter - 1, y = y0 - 3 + last - 3;
+        const Bg bgv = load_bg(y);
+        switch (last % RING) {
+            case 0: tile_to_lds(acc[0]); break;
+            case 1: tile_to_lds(acc[1]); break;
+            case 2: tile_to_lds(acc[2]); break;
+            case 3: tile_to_lds(acc[3]); break;
+            case 4: tile_to_lds(acc[4]); break;
+            case 5: tile_to_lds(acc[5]); break;
+            case 6: tile_to_lds(acc[6]); break;
+            default: tile_to_lds(acc[7]); break;
+        }
+        const Out o = reduce_row();
+        store_row(o, bgv, y);
     }
 }
 
