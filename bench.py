@@ -134,8 +134,9 @@ def cpu_baseline(seed=0, batches=2):
     line = {"value": round(batches * BATCH / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d batches of %d frames (256x256) after warm-up, best of 16/32/64 intra-op threads on a box with %d "
                       "logical cores, torch %s CPU fp32 + OpenMP C rasteriser" % (batches, BATCH, os.cpu_count(), torch.__version__),
-            "port_vs_reference": "the port runs at 1.00x +- 0.03 of the reference's own modules on the same batch "
-                                 "(profiles/r02_port_vs_reference.md, measured where /root/reference exists)"}
+            "port_vs_reference": "calibration where /root/reference exists (8-core build container, 5 batches each): the "
+                                 "port runs at 0.90x the speed of the reference's own modules (median; per-batch spread "
+                                 "0.76-1.06x) with bit-identical outputs -- profiles/r02_port_vs_reference.md"}
     return line, {"fim": torch.cat([k[0] for k in kept]), "pred": torch.cat([k[1] for k in kept]), "first_batch": 1}
 
 

@@ -23,8 +23,13 @@ int main(int argc, char **argv)
         {"skip1 256->128 @128 (bn128)", 8, 128, 256, 128, 3, 1, 128},
         {"skip2 128->64 @256 (bn64)", 8, 256, 128, 64, 3, 1, 64},
         {"enc3 256->512 s2 @64 (bn64)", 8, 64, 256, 512, 3, 2, 64},
+        {"enc3 256->512 s2 @64 (bn128)", 8, 64, 256, 512, 3, 2, 128},
+        {"enc2 128->256 s2 @128 (bn64)", 8, 128, 128, 256, 3, 2, 64},
+        {"enc2 128->256 s2 @128 (bn128)", 8, 128, 128, 256, 3, 2, 128},
+        {"enc1 64->128 s2 @256 (bn64)", 8, 256, 64, 128, 3, 2, 64},
+        {"enc1 64->128 s2 @256 (bn128)", 8, 256, 64, 128, 3, 2, 128},
     };
-    const int dbgs[] = {100, 200, 821, 812, 831, 201, 200, 821};
+    const int dbgs[] = {100, 200, 821, 812, 240, 201, 200, 821};
     hipStream_t st;
     hipStreamCreate(&st);
     hipEvent_t e0, e1;

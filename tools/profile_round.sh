@@ -7,6 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/$TAG/bench.json 2> $R/gpurun_out/$TAG/bench.err
+python $R/bench.py --lanes 3 --no-cpu-baseline --no-roofline --no-fp32-mode > $R/gpurun_out/$TAG/bench_lanes3.json 2>/dev/null
+python $R/bench.py --lanes 1 --no-cpu-baseline --no-roofline --no-fp32-mode > $R/gpurun_out/$TAG/bench_lanes1.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats -o k -- \
     python $R/bench.py --lanes 1 --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode > $R/gpurun_out/$TAG/stats.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
