@@ -43,7 +43,7 @@ constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B align
 // WIDE: the raw output goes through LDS (one 32x32 tile per wave at a time, 36-float pitch) so that it leaves as
 // 16-byte stores, 8 per tile, instead of 32 four-byte ones: the epilogue is store-ISSUE bound.  Callers must have a
 // barrier between their last LDS reads and this call; the statistics scratch sits behind the staging area.
-template <int BN, int WM, int WN, bool WIDE = false, int NWAVES = 4>
+template <int BN, int WM, int WN, bool WIDE = false, int NWAVES = 4, int BMT = BM>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, int phase, f32x16 (&acc)[WM][WN],
                                                float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0,
                                                int mtile)
@@ -111,20 +111,22 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                 if (lane < 32) red[(wave_m * WM + i) * BN + wave_n * 32 * WN + j * 32 + col] = make_float2(mu, q);
             }
         __syncthreads();
-        if (tid < BN) {
+        // one (mean, M2) per 128 output pixels, whatever the workgroup's tile height: a 256-row tile writes two
+        if (tid < BN * (BMT / BM)) {
             constexpr int RT = BM / 32;
+            const int sub = tid / BN, ch = tid - sub * BN;
             float mean = 0.f;
 #pragma unroll
-            for (int w = 0; w < RT; ++w) mean += red[w * BN + tid].x;
+            for (int w = 0; w < RT; ++w) mean += red[(sub * RT + w) * BN + ch].x;
             mean *= 1.f / RT;
             float m2 = 0.f;
 #pragma unroll
             for (int w = 0; w < RT; ++w) {
-                const float2 p = red[w * BN + tid];
+                const float2 p = red[(sub * RT + w) * BN + ch];
                 const float d = p.x - mean;
                 m2 += p.y + 32.f * d * d;
             }
-            a.partials[((size_t)phase * a.mtiles + mtile) * a.Cout + n0 + tid] = make_float2(mean, m2);
+            a.partials[((size_t)phase * a.mtiles + (size_t)mtile * (BMT / BM) + sub) * a.Cout + n0 + ch] = make_float2(mean, m2);
         }
     }
 }
@@ -607,23 +609,25 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(const ConvArgs a)
 // that an XCD (own L2) covers 2 n-tiles x 16 m-tiles instead of 4 x 8 (fabric reads 107 -> ~71 MB per trunk launch) -2%.  rocprofv3: LDS 18% busy,
 // no bank conflicts; the matrix pipe is 49% busy at a power-limited 2.1-2.2 GHz (a pure MFMA loop on random operands
 // reaches 80% of the 2.5 PFLOP/s dense peak on this part, tools/mfma_peak.hip).
-template <int BN, int WM, int WN, int NS = 3, int DBG = 0>
-__global__ __launch_bounds__(64 * (BM / (32 * WM)) * (BN / (32 * WN))) void conv_igemm_bf16x3(const ConvArgs a)
+template <int BN, int WM, int WN, int NS = 3, int DBG = 0, int BMT = BM>
+__global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void conv_igemm_bf16x3(const ConvArgs a)
 {
-    constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BM / (32 * WM), NW = WAVES_M * WAVES_N;
+    // BMT = output pixels per workgroup tile: 128, or 256 for the 64-channel layers (256x64: the 2x2 wave tile of the
+    // 128x128 kernel, i.e. one B fragment read per two MFMAs instead of one per MFMA on the 128x64 tile)
+    constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BMT / (32 * WM), NW = WAVES_M * WAVES_N;
     // 4 waves: one per SIMD.  8 waves: two per SIMD, each owning half as many 32x32 tiles -- while one of a SIMD's
     // two waves sits in a DMA issue (~60 cycles), a counted wait or the stage barrier, the other one's MFMAs keep the
     // matrix pipe busy.
     static_assert((NW == 4 || NW == 8) && NS >= 3, "wave layout");
-    constexpr int A_CH = BM / 8 / NW, B_CH = BN / 8 / NW;   // 1-KiB DMA chunks (8 rows x 128 B) per wave per stage
+    constexpr int A_CH = BMT / 8 / NW, B_CH = BN / 8 / NW;   // 1-KiB DMA chunks (8 rows x 128 B) per wave per stage
     constexpr int LPS = A_CH + B_CH;
-    constexpr int STAGE = (BM + BN) * BK;                 // floats (4-byte units) per ring slot
+    constexpr int STAGE = (BMT + BN) * BK;                // floats (4-byte units) per ring slot
     constexpr int TILES = WM * WN;
     constexpr int Q = 6 * TILES;                          // MFMAs of a wave per stage
-    static_assert(Q % LPS == 0, "DMA pieces must spread evenly over the MFMAs of a stage");
-    constexpr int QP = Q / LPS;
+    static_assert(Q >= LPS, "at most one DMA piece per MFMA");
     constexpr int QB = Q * 3 / 4;                         // stage barrier before this MFMA (2/3 measured no better)
-    constexpr int ISSUED = QB / QP;                       // pieces of the stage already issued by then
+    // piece p is issued behind MFMA (p + 1) * Q / LPS - 1: evenly spread, the last one behind the last MFMA
+    constexpr int ISSUED = (QB * LPS) / Q;                // pieces of the stage already issued before the barrier
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(64 * (BM / (32 * WM)) * (BN / (32 * WN))) void conv
     int bx = blockIdx.x;
     const int by = blockIdx.y;
     if (!(DBG & 64) && !a.natural_order && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int m0 = bx * BM, n0 = by * BN;
+    const int m0 = bx * BMT, n0 = by * BN;
     const int hw_m = a.Hm * a.Wm, img = m0 / hw_m, rem0 = m0 - img * hw_m;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     auto uniform_ptr = [](const void *p) {   // wave-uniform pointer pinned to SGPRs (the "s" asm operand below)
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(64 * (BM / (32 * WM)) * (BN / (32 * WN))) void conv
     };
     retap();
     const unsigned wave_a = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * A_CH * 8 * BK * 4));
-    const unsigned wave_b = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((BM * BK + wave * B_CH * 8 * BK) * 4));
+    const unsigned wave_b = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((BMT * BK + wave * B_CH * 8 * BK) * 4));
     // piece p of stage kt into ring slot `slot`: p < A_CH activation chunks, then the weight chunks
     auto dma_piece = [&](int p, int kt, int slot) {
         const unsigned slot_byte = (unsigned)(slot * STAGE * 4);
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(64 * (BM / (32 * WM)) * (BN / (32 * WN))) void conv
     // fragments: row = base + (lane&31); hi operand of k-block kb = 16-B column 2*kb + (lane>>5), lo = 4 + that
     const int frow = lane & 31, fsw = (frow >> 1) & 7;
     const int a_row = (wave_m * 32 * WM + frow) * BK;
-    const int b_row = BM * BK + (wave_n * 32 * WN + frow) * BK;
+    const int b_row = BMT * BK + (wave_n * 32 * WN + frow) * BK;
     int fcol[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) fcol[c] = (((2 * c + (lane >> 5)) ^ fsw) * 4);
@@ -814,10 +818,14 @@ __global__ __launch_bounds__(64 * (BM / (32 * WM)) * (BN / (32 * WN))) void conv
                     __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
                 }
             }
-            if (decltype(do_dma)::value && q % QP == QP - 1 && !(DBG & 1)) {
-                __builtin_amdgcn_sched_barrier(0);
-                dma_piece(q / QP, kt + (NS - 1), slot2);
-                __builtin_amdgcn_sched_barrier(0);
+            if (decltype(do_dma)::value && !(DBG & 1)) {
+                const int pc = ((q + 1) * LPS) / Q;           // pieces due once MFMA q is issued ...
+                const int pb = (q * LPS) / Q;                 // ... and before it: equal unless a piece rides behind q
+                if (pc != pb) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_piece(pb, kt + (NS - 1), slot2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (!(DBG & 8)) fr = nx;
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(64 * (BM / (32 * WM)) * (BN / (32 * WN))) void conv
         if (++slot == NS) slot = 0;
     }
 
-    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN, !(DBG & 128), NW>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
+    if (!(DBG & 32)) igemm_epilogue<BN, WM, WN, !(DBG & 128), NW, BMT>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
     if (DBG & 32) {   // bench only: keep every MFMA alive without an epilogue
         float keep = 0.f;
 #pragma unroll
@@ -1330,6 +1338,15 @@ int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
         case 821: if (bn == 128) launch_w_dbg<128, 2, 1, 0>(a, st); else launch_w_dbg<64, 1, 1, 0>(a, st); break;
         case 812: if (bn == 128) launch_w_dbg<128, 1, 2, 0>(a, st); else launch_w_dbg<64, 1, 1, 0>(a, st); break;
         case 831: if (bn == 128) launch_w_dbg<128, 2, 1, 1>(a, st); else launch_w_dbg<64, 1, 1, 1>(a, st); break;   // no DMA
+        case 856: {   // 256x64 tile (bn 64 only)
+            if (bn != 64 || (a.mtiles & 1)) return LWG_ERR_INVALID_ARG;
+            const dim3 grid(a.mtiles / 2, a.Cout / 64, a.nphase);
+            const size_t lds = (size_t)3 * (256 + 64) * BK * sizeof(float);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<64, 2, 2, 3, 0, 256>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            conv_igemm_bf16x3<64, 2, 2, 3, 0, 256><<<grid, 256, lds, st>>>(a);
+            break;
+        }
         case 200: launch_k_dbg<3, 0>(a, bn, st); break;
         case 201: launch_k_dbg<3, 1>(a, bn, st); break;   // no DMA
         case 204: launch_k_dbg<3, 4>(a, bn, st); break;   // no barrier

@@ -212,6 +212,10 @@ class Imitator(BaseModel):
 
     # ------------------------------------------------------------------ stream pipeline over batches
     lanes = 2   # generator engines (and HIP streams) predict_batches deals consecutive batches to; env LWG_LANES
+    # batches per lane and round: the geometry of lanes * round_depth batches is one launch sequence (the kernels are
+    # latency-bound at these sizes) and the lanes drain once per round; tools/depth_bench.py at batch 8, two lanes:
+    # depth 1 2709, 2 2772, 3 2799, 4 2811 frames/s in one process.  env LWG_ROUND_DEPTH
+    round_depth = 4
 
     def _lanes(self, n):
         """n (stream, generator) pairs, each with its own HIP stream; lane 0 drives self.generator, the others an
@@ -229,8 +233,9 @@ class Imitator(BaseModel):
     def predict_batches(self, batches, cam_strategy='smooth', lanes=None, _overlap_geometry=False):
         """Yields (t, preds) for every (tgt_smpls_chunk, t) of `batches`, in order.  Frames are independent once the
         source is personalised, so consecutive batches are processed in rounds of `lanes`:
-          1. the geometry of the round's batches (swap_smpl, SMPL, rasteriser, flow, image warp: a dozen small kernels)
-             runs as ONE launch sequence over all the round's frames on a side stream, *with no generator running*;
+          1. the geometry of the round's batches (`lanes * round_depth` of them: swap_smpl, SMPL, rasteriser, flow, image
+             warp -- a dozen small, latency-bound kernels) runs as ONE launch sequence over all the round's frames on a
+             side stream, *with no generator running*;
           2. their generators then run side by side, each on its own stream and engine (scratch): a layer is
              conv -> finalize -> apply, every launch waiting for the one before, and the idle tails and launch gaps
              of one chain are filled by the other's kernels (+15 % frames/s at batch 8 with two lanes; a third adds
@@ -247,6 +252,7 @@ class Imitator(BaseModel):
         pipeline.  Same results as transfer_params_by_smpl + forward per batch."""
         import os
         nl = max(1, int(lanes if lanes is not None else os.environ.get("LWG_LANES", self.lanes)))
+        depth = max(1, int(os.environ.get("LWG_ROUND_DEPTH", self.round_depth)))
         main = torch.cuda.current_stream()
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
@@ -284,7 +290,8 @@ class Imitator(BaseModel):
                 ready = torch.cuda.Event()
                 ready.record(side)
             out = []
-            for (t, tsf_inputs, info), (st, gen) in zip(prepared, lane_list):
+            for k, (t, tsf_inputs, info) in enumerate(prepared):
+                st, gen = lane_list[k % nl]   # batch k of the round goes to lane k mod lanes, in order
                 with torch.cuda.stream(st):
                     st.wait_event(ready)
                     self.tsf_info = info
@@ -301,7 +308,7 @@ class Imitator(BaseModel):
             group = []
             for item in batches:
                 group.append(item)
-                if len(group) == nl:
+                if len(group) == nl * depth:
                     yield group
                     group = []
             if group:
