@@ -14,9 +14,85 @@ from .generator_trainer import GeneratorTrainer
 from .models import BaseModel
 
 
+class BodyRecoveryFlow(torch.nn.Module):
+    """models/impersonator_trainer.py:13-170: turns a (source image, target image, source SMPL, target SMPL) batch into
+    the tensors a training iteration reads -- the three streams' generator inputs, the flow T, the crop masks and the
+    head / body boxes.  Every device step is the inference path's: SMPL skinning (smpl.hip), the rasteriser with
+    per-sample sources (raster.hip), `encode_fim`, `cal_bc_transform`, `grid_sample` (warp.hip) and `util.morph`."""
+
+    def __init__(self, opt, hmr=None, render=None):
+        super().__init__()
+        self._name = 'BodyRecoveryFlow'
+        self._opt = opt
+        if hmr is None:
+            from ..networks.batch_smpl import HumanModelRecovery
+            hmr = HumanModelRecovery(smpl_pkl_path=opt.smpl_model)      # :22-27 (the image regressor's weights are not used)
+        if render is None:
+            from ..utils.nmr import SMPLRenderer
+            render = SMPLRenderer(map_name=opt.map_name, uv_map_path=opt.uv_mapping, tex_size=opt.tex_size,
+                                  image_size=opt.image_size, fill_back=False, anti_aliasing=True,
+                                  background_color=(0, 0, 0), has_front=False)     # :29-36
+        self._hmr, self._render = hmr, render
+
+    @torch.no_grad()
+    def forward(self, src_img, ref_img, src_smpl, ref_smpl):
+        """:44-87, same return tuple."""
+        from ..utils import util
+        r = self._render
+        src_info = self._hmr.get_details(src_smpl)
+        ref_info = self._hmr.get_details(ref_smpl)
+        src_f2verts, src_fim, _ = r.render_fim_wim(src_info['cam'], src_info['verts'])
+        src_f2verts = src_f2verts[:, :, :, 0:2]
+        src_f2verts[:, :, :, 1] *= -1
+        src_cond, _ = r.encode_fim(src_info['cam'], src_info['verts'], fim=src_fim, transpose=True)
+        src_crop_mask = util.morph(src_cond[:, -1:, :, :], ks=3, mode='erode')
+        _, ref_fim, ref_wim = r.render_fim_wim(ref_info['cam'], ref_info['verts'])
+        ref_cond, _ = r.encode_fim(ref_info['cam'], ref_info['verts'], fim=ref_fim, transpose=True)
+        T = r.cal_bc_transform(src_f2verts, ref_fim, ref_wim)
+        syn_img = r.grid_sample(src_img, T)
+        input_G_src = torch.cat([src_img * (1 - src_crop_mask), src_cond], dim=1)
+        input_G_tsf = torch.cat([syn_img, ref_cond], dim=1)
+        src_bg_mask = util.morph(src_cond[:, -1:, :, :], ks=15, mode='erode')
+        input_G_src_bg = torch.cat([src_img * src_bg_mask, src_bg_mask], dim=1)
+        if getattr(self._opt, 'bg_both', False):
+            ref_bg_mask = util.morph(ref_cond[:, -1:, :, :], ks=15, mode='erode')
+            input_G_tsf_bg = torch.cat([ref_img * ref_bg_mask, ref_bg_mask], dim=1)
+        else:
+            input_G_tsf_bg = None
+        tsf_crop_mask = util.morph(ref_cond[:, -1:, :, :], ks=3, mode='erode')
+        return (input_G_src_bg, input_G_tsf_bg, input_G_src, input_G_tsf, T, src_crop_mask, tsf_crop_mask,
+                self.cal_head_bbox(ref_info['j2d']), self.cal_body_bbox(ref_info['j2d']))
+
+    def cal_head_bbox(self, kps):
+        """:89-130: kps (N,19,2) in [-1,1] -> (N,4) long [min_x, max_x, min_y, max_y]; the head joints are 12.. (NECK_IDS)."""
+        size = self._opt.image_size
+        kps = (kps + 1) / 2.0
+        zeros, ones = torch.zeros_like(kps[:, 12, 0]), torch.ones_like(kps[:, 12, 0])
+        min_x = torch.max(torch.min(kps[:, 12:, 0] - 0.05, dim=1)[0], zeros)
+        max_x = torch.min(torch.max(kps[:, 12:, 0] + 0.05, dim=1)[0], ones)
+        min_y = torch.max(torch.min(kps[:, 12:, 1] - 0.05, dim=1)[0], zeros)
+        max_y = torch.min(torch.max(kps[:, 12:, 1], dim=1)[0], ones)
+        return torch.stack([(v * size).long() for v in (min_x, max_x, min_y, max_y)], dim=1)
+
+    def cal_body_bbox(self, kps, factor=1.2):
+        """:132-170."""
+        size = self._opt.image_size
+        kps = (kps + 1) / 2.0
+        zeros = torch.zeros((kps.shape[0],), device=kps.device)
+        ones = torch.ones((kps.shape[0],), device=kps.device)
+        out = []
+        for c in (0, 1):
+            lo, hi = kps[:, :, c].min(dim=1)[0], kps[:, :, c].max(dim=1)[0]
+            mid, ext = (lo + hi) / 2, (hi - lo) * factor
+            out += [torch.max(zeros, mid - ext / 2), torch.min(ones, mid + ext / 2)]
+        return torch.stack([(v * size).long() for v in out], dim=1)
+
+
 class Impersonator(BaseModel):
-    def __init__(self, opt):
+    def __init__(self, opt, bdr=None):
         super(Impersonator, self).__init__(opt)
+        self._bdr = bdr     # BodyRecoveryFlow (impersonator_trainer.py:201-207); built on first use when not injected
+        self._head_bbox = self._body_bbox = None
         self._name = 'Impersonator'
         self._D_cond_nc = self._G_cond_nc          # models/models.py:85-94: same condition map for G and D
         if getattr(opt, 'lambda_D_prob', 1) != 1:
@@ -68,10 +144,25 @@ class Impersonator(BaseModel):
                                   n_layers=4, use_sigmoid=False, image_size=self._opt.image_size,
                                   max_batch=getattr(self._opt, 'batch_size', 4)).cuda()
 
-    def set_input(self, input_G_tsf, real_tsf, input_G_bg=None, input_G_src=None, T=None, real_src=None, bg_mask=None):
-        """The tensors a training iteration reads (impersonator_trainer.py:300-319), as the reference's BodyRecoveryFlow
-        (`self._bdr`) produces them: the generator inputs of the three streams, the flow T and the real target image.
-        `_optimize_D` alone needs input_G_tsf and real_tsf."""
+    @torch.no_grad()
+    def set_input(self, input_G_tsf, real_tsf=None, input_G_bg=None, input_G_src=None, T=None, real_src=None, bg_mask=None):
+        """impersonator_trainer.py:289-319.  Called as the reference calls it -- `set_input(sample)` with
+        sample['images'] (N,2,3,H,W) and sample['smpls'] (N,2,85): source / target pairs of a dataset batch -- the inputs
+        are derived on the device by BodyRecoveryFlow.  Called with explicit tensors (extension) it takes what
+        BodyRecoveryFlow would have produced: the generator inputs of the three streams, the flow T and the real images
+        (`_optimize_D` alone needs input_G_tsf and real_tsf)."""
+        if isinstance(input_G_tsf, dict):
+            sample = input_G_tsf
+            images, smpls = sample['images'], sample['smpls']
+            src_img, src_smpl = images[:, 0, ...].float().cuda(), smpls[:, 0, ...].float().cuda()
+            tsf_img, tsf_smpl = images[:, 1, ...].float().cuda(), smpls[:, 1, ...].float().cuda()
+            if self._bdr is None:
+                self._bdr = BodyRecoveryFlow(self._opt)
+            (input_G_src_bg, input_G_tsf_bg, input_G_src, input_G_tsf, T, src_crop_mask, tsf_crop_mask, self._head_bbox,
+             self._body_bbox) = self._bdr(src_img, tsf_img, src_smpl, tsf_smpl)
+            real_src, real_tsf = src_img, tsf_img
+            bg_mask = torch.cat((src_crop_mask, tsf_crop_mask), dim=0)
+            input_G_bg = input_G_src_bg     # bg_both is rejected in __init__
         self._input_G_tsf, self._real_tsf = input_G_tsf, real_tsf
         self._input_G_bg, self._input_G_src, self._T = input_G_bg, input_G_src, T
         self._real_src, self._bg_mask = real_src, bg_mask

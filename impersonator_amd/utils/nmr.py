@@ -181,6 +181,18 @@ class SMPLRenderer(nn.Module):
                                                     src.shape[1], self.image_size, _lib.ptr(T), _lib.stream_ptr()))
         return T
 
+    @torch.no_grad()
+    def grid_sample(self, x, T):
+        """F.grid_sample(x, T) as the reference calls it (models/imitator.py:259, impersonator_trainer.py:62): bilinear,
+        zeros padding, the renderer's align_corners; x (1|n, C, H, W), T (n, Ho, Wo, 2)."""
+        x, T = self._cuda(x), self._cuda(T)
+        n, ho, wo, _ = T.shape
+        xn, c, h, w = x.shape
+        out = torch.empty((n, c, ho, wo), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().lwg_grid_sample(_lib.ptr(x), xn, c, h, w, _lib.ptr(T), n, ho, wo, int(self.align_corners),
+                                               _lib.ptr(out), _lib.stream_ptr()))
+        return out
+
     @staticmethod
     @torch.no_grad()
     def get_vis_f2pts(f2pts, fims):

@@ -254,6 +254,55 @@ def imitator_frames(sd, src, src_img, bg_img, cam, verts, faces_idx, map_fn, ima
     return {k: torch.cat([o[k] for o in outs], 0) for k in keys}, torch.cat(preds, 0)
 
 
+def cal_head_bbox(kps, image_size):
+    """models/impersonator_trainer.py:89-130 (NECK_IDS = 12; kps (N,19,2) in [-1,1]) -> (N,4) long [min_x,max_x,min_y,max_y]."""
+    kps = (kps + 1) / 2.0
+    zeros, ones = torch.zeros_like(kps[:, 12, 0]), torch.ones_like(kps[:, 12, 0])
+    min_x = torch.max(torch.min(kps[:, 12:, 0] - 0.05, dim=1)[0], zeros)
+    max_x = torch.min(torch.max(kps[:, 12:, 0] + 0.05, dim=1)[0], ones)
+    min_y = torch.max(torch.min(kps[:, 12:, 1] - 0.05, dim=1)[0], zeros)
+    max_y = torch.min(torch.max(kps[:, 12:, 1], dim=1)[0], ones)
+    return torch.stack([(v * image_size).long() for v in (min_x, max_x, min_y, max_y)], dim=1)
+
+
+def cal_body_bbox(kps, image_size, factor=1.2):
+    """models/impersonator_trainer.py:132-170."""
+    kps = (kps + 1) / 2.0
+    zeros, ones = torch.zeros(kps.shape[0]), torch.ones(kps.shape[0])
+    out = []
+    for c in (0, 1):
+        lo, hi = kps[:, :, c].min(dim=1)[0], kps[:, :, c].max(dim=1)[0]
+        mid, ext = (lo + hi) / 2, (hi - lo) * factor
+        out += [torch.max(zeros, mid - ext / 2), torch.min(ones, mid + ext / 2)]
+    return torch.stack([(v * image_size).long() for v in out], dim=1)
+
+
+def body_recovery_flow(get_details, faces_idx, map_fn, src_img, ref_img, src_smpl, ref_smpl, image_size=256, bg_both=False,
+                       align_corners=False):
+    """BodyRecoveryFlow.forward (models/impersonator_trainer.py:44-87): what the trainer's set_input derives from a pair
+    of images and SMPL vectors.  `get_details` = HumanModelRecovery.get_details on CPU tensors."""
+    src_info, ref_info = get_details(src_smpl), get_details(ref_smpl)
+    src_f2verts, src_fim, _ = render_fim_wim(src_info['cam'], src_info['verts'], faces_idx, image_size)
+    src_f2pts = source_p2verts(src_f2verts)
+    src_cond = encode_fim(src_fim, map_fn)
+    src_crop_mask = morph(src_cond[:, -1:], 3, 'erode')
+    _, ref_fim, ref_wim = render_fim_wim(ref_info['cam'], ref_info['verts'], faces_idx, image_size)
+    ref_cond = encode_fim(ref_fim, map_fn)
+    T = cal_bc_transform(src_f2pts, ref_fim, ref_wim)
+    syn_img = grid_sample(src_img, T, align_corners)
+    input_G_src = torch.cat([src_img * (1 - src_crop_mask), src_cond], dim=1)
+    input_G_tsf = torch.cat([syn_img, ref_cond], dim=1)
+    src_bg_mask = morph(src_cond[:, -1:], 15, 'erode')
+    input_G_src_bg = torch.cat([src_img * src_bg_mask, src_bg_mask], dim=1)
+    input_G_tsf_bg = None
+    if bg_both:
+        ref_bg_mask = morph(ref_cond[:, -1:], 15, 'erode')
+        input_G_tsf_bg = torch.cat([ref_img * ref_bg_mask, ref_bg_mask], dim=1)
+    tsf_crop_mask = morph(ref_cond[:, -1:], 3, 'erode')
+    return (input_G_src_bg, input_G_tsf_bg, input_G_src, input_G_tsf, T, src_crop_mask, tsf_crop_mask,
+            cal_head_bbox(ref_info['j2d'], image_size), cal_body_bbox(ref_info['j2d'], image_size))
+
+
 def state_dict_from_numpy(sd_np):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
 

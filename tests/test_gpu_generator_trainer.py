@@ -110,3 +110,102 @@ def test_trainer_mirror_full_iteration(setup):
     assert abs(losses["d_loss"] - float(d_ref)) < 2e-3 * max(1.0, float(d_ref))
     model.sync_generator()
     assert float((model._G.state_dict()["tsf_model.img_reg.0.weight"].cpu() - setup["gsd"]["tsf_model.img_reg.0.weight"]).abs().max()) > 1e-5
+
+
+def _synthetic_bdr(image_size):
+    import types
+    from impersonator_amd.models.impersonator_trainer import BodyRecoveryFlow
+    from impersonator_amd.networks.batch_smpl import HumanModelRecovery, synthetic_smpl_params
+    from impersonator_amd.utils import synthetic
+    from impersonator_amd.utils.nmr import SMPLRenderer
+    rest, faces = synthetic.body_mesh()
+    map_fn = synthetic.uv_seg_map_fn(rest, faces)
+    render = SMPLRenderer(image_size=image_size, faces=faces, map_fn=map_fn, has_front=False).cuda()
+    hmr = HumanModelRecovery(smpl_params=synthetic_smpl_params(0)).cuda()
+    opt = types.SimpleNamespace(image_size=image_size, bg_both=False)
+    return BodyRecoveryFlow(opt, hmr=hmr, render=render), hmr, torch.from_numpy(faces), torch.from_numpy(map_fn)
+
+
+def test_body_recovery_flow_on_device_matches_oracle():
+    """The trainer's input preparation (impersonator_trainer.py:44-87) through the device kernels, per-sample sources:
+    against the CPU restatement (pinned bit-identically to the reference's own BodyRecoveryFlow.forward in
+    tests/test_oracle_vs_reference.py), restarted from the device's SMPL details."""
+    from impersonator_amd import demo
+    bdr, hmr, faces_t, map_fn = _synthetic_bdr(256)
+    smpls = torch.from_numpy(demo.synthetic_smpls(64, seed=2))
+    src_smpl, ref_smpl = smpls[[3, 20, 33]], smpls[[40, 55, 9]]
+    gen = torch.Generator().manual_seed(1)
+    src_img, ref_img = torch.rand(3, 3, 256, 256, generator=gen) * 2 - 1, torch.rand(3, 3, 256, 256, generator=gen) * 2 - 1
+    got = bdr(src_img.cuda(), ref_img.cuda(), src_smpl.cuda(), ref_smpl.cuda())
+    details = lambda smpl: {k: v.cpu() for k, v in hmr.get_details(smpl.cuda()).items()}
+    with torch.no_grad():
+        want = torch_ref.body_recovery_flow(details, faces_t, map_fn, src_img, ref_img, src_smpl, ref_smpl)
+    names = ("input_G_src_bg", "input_G_tsf_bg", "input_G_src", "input_G_tsf", "T", "src_crop_mask", "tsf_crop_mask",
+             "head_bbox", "body_bbox")
+    for name, a, b in zip(names, got, want):
+        if b is None:
+            assert a is None
+            continue
+        assert a.shape == b.shape, name
+        if b.dtype == torch.int64:
+            assert torch.equal(a.cpu(), b), name
+        else:
+            assert float((a.cpu() - b).abs().max()) <= 2e-6, (name, float((a.cpu() - b).abs().max()))
+    # masks and the condition channels are exact
+    assert torch.equal(got[5].cpu(), want[5]) and torch.equal(got[6].cpu(), want[6])
+    assert torch.equal(got[2][:, 3:].cpu(), want[2][:, 3:])
+
+
+def test_set_input_from_a_dataset_sample_and_one_iteration():
+    """Impersonator.set_input(sample) as the reference's training loop calls it (impersonator_trainer.py:289-319),
+    followed by optimize_parameters: losses finite, generator and discriminator both move."""
+    import types
+    from impersonator_amd import demo
+    from impersonator_amd.models.impersonator_trainer import Impersonator
+    bdr, _, _, _ = _synthetic_bdr(64)
+    opt = types.SimpleNamespace(image_size=64, batch_size=2, map_name='uv_seg', norm_type='instance', repeat_num=6, is_train=True)
+    model = Impersonator(opt, bdr=bdr)
+    model._G.init_weights()
+    model._D.init_weights()
+    gen = torch.Generator().manual_seed(3)
+    smpls = torch.from_numpy(demo.synthetic_smpls(16, seed=4))
+    sample = {"images": torch.rand(2, 2, 3, 64, 64, generator=gen) * 2 - 1,
+              "smpls": torch.stack([smpls[[0, 5]], smpls[[9, 14]]])}
+    model.set_input(sample)
+    assert model._input_G_src.shape == (2, 6, 64, 64) and model._T.shape == (2, 64, 64, 2)
+    assert model._bg_mask.shape == (4, 1, 64, 64) and model._head_bbox.shape == (2, 4)
+    before = model._generator_trainer().state_dict()["tsf_model.img_reg.0.weight"].clone()
+    losses = model.optimize_parameters()
+    assert all(torch.isfinite(torch.tensor(float(v))) for v in losses.values()) and "d_loss" in losses
+    after = model._generator_trainer().state_dict()["tsf_model.img_reg.0.weight"]
+    assert float((after - before).abs().max()) > 0
+
+
+def test_config5_image_size_512():
+    """BASELINE.json config 5 runs the trainer at 512x512: the generator update at that size (batch 1) against float32
+    autograd on the CPU oracle -- fake images, every loss term, the head gradients."""
+    from impersonator_amd.models.generator_trainer import GeneratorTrainer
+    from impersonator_amd.networks.discriminator import PatchDiscriminator
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    gsd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=4, affine="random"))
+    dsd = helpers.discriminator_state_dict(seed=5)
+    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, image_size=512, max_batch=1)
+    G.load_state_dict(gsd)
+    D = PatchDiscriminator(6, 64, 4, 'instance', False, image_size=512, max_batch=1)
+    D.load_state_dict(dsd)
+    tr = GeneratorTrainer(G, D.cuda())
+    batch = helpers.train_batch(seed=6, n=1, size=512)
+    fake = tr.forward(batch)
+    mine = tr.backward()
+    hist, grads, _ = torch_ref.generator_train_steps(gsd, dsd, [batch])
+    with torch.no_grad():
+        _, terms, ref_fake = torch_ref.generator_train_loss(gsd, dsd, batch)
+    for name, a, c in zip(("fake_bg", "fake_src", "fake_tsf", "masks"), fake, ref_fake):
+        assert a.shape == c.shape and float((a.cpu() - c).abs().max()) < 2e-4, (name, float((a.cpu() - c).abs().max()))
+    for k, v in terms.items():
+        assert abs(float(mine[k]) - float(v)) < 2e-4 * max(1.0, abs(float(v))), k
+    g = tr.gradients()
+    for k in ("tsf_model.img_reg.0.weight", "tsf_model.attetion_reg.0.weight", "src_model.img_reg.0.weight", "bg_model.model.27.weight"):
+        # a head gradient is a sum over 262144 pixels: two float32 evaluations of it scatter by ~2e-3 of its largest entry
+        assert _rel(g[k], grads[k]) < 5e-3, (k, _rel(g[k], grads[k]))
+    G.release()

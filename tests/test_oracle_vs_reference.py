@@ -184,3 +184,38 @@ def test_generator_train_loss_matches_reference_trainer(ref):
     _, grads, _ = torch_ref.generator_train_steps(gsd, dsd, [b])
     for k, p in G.named_parameters():
         assert torch.allclose(p.grad, grads[k], atol=1e-6 + 1e-4 * float(p.grad.abs().max()), rtol=0), k
+
+
+def test_body_recovery_flow_restatement_matches_reference(ref):
+    """BodyRecoveryFlow.forward (models/impersonator_trainer.py:44-87), the trainer's input preparation, run unbound on a
+    stub that carries the reference's own SMPLRenderer methods and the CPU SMPL (batch of 2 source / target pairs)."""
+    from impersonator_amd.networks.batch_smpl import HumanModelRecovery, synthetic_smpl_params
+    from impersonator_amd import demo
+    s = helpers.scene()
+    R, B = ref.nmr.SMPLRenderer, ref.trainer.BodyRecoveryFlow
+    rs = types.SimpleNamespace(faces=helpers.t(s["faces"]), image_size=256, map_fn=helpers.t(s["map_fn"]),
+                               proj_func=ref.nmr.orthographic_proj_withz_idrot,
+                               eye=[0, 0, -(1. / np.tan(np.radians(30)) + 1)])
+    render = types.SimpleNamespace(
+        render_fim_wim=lambda cam, verts: R.render_fim_wim(rs, cam, verts),
+        encode_fim=lambda cam, verts, fim=None, transpose=True: R.encode_fim(rs, cam, verts, fim=fim, transpose=transpose),
+        cal_bc_transform=lambda a, b, c: R.cal_bc_transform(rs, a, b, c))
+    hmr = HumanModelRecovery(smpl_params=synthetic_smpl_params(0))
+    stub = types.SimpleNamespace(_hmr=hmr, _render=render, _opt=types.SimpleNamespace(bg_both=False, image_size=256))
+    stub.cal_head_bbox = types.MethodType(B.cal_head_bbox, stub)
+    stub.cal_body_bbox = types.MethodType(B.cal_body_bbox, stub)
+    smpls = torch.from_numpy(demo.synthetic_smpls(64, seed=2))
+    src_smpl, ref_smpl = smpls[[3, 20]], smpls[[40, 55]]
+    gen = torch.Generator().manual_seed(1)
+    src_img, ref_img = torch.rand(2, 3, 256, 256, generator=gen) * 2 - 1, torch.rand(2, 3, 256, 256, generator=gen) * 2 - 1
+    with torch.no_grad():
+        theirs = B.forward(stub, src_img, ref_img, src_smpl, ref_smpl)
+        mine = torch_ref.body_recovery_flow(hmr.get_details, helpers.t(s["faces"]), helpers.t(s["map_fn"]), src_img, ref_img,
+                                            src_smpl, ref_smpl)
+    assert len(theirs) == len(mine) == 9
+    for i, (a, b) in enumerate(zip(theirs, mine)):
+        if a is None:
+            assert b is None
+            continue
+        assert a.shape == b.shape and a.dtype == b.dtype, i
+        assert torch.equal(a, b), "output %d differs by %g" % (i, float((a.float() - b.float()).abs().max()))

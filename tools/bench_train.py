@@ -40,6 +40,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps({"metric": "training iteration (G update + D update)", "ms_per_iteration": round(dt * 1e3, 2),
+                      "note": "BASELINE.json config 5 is --image-size 512 (--batch 1..4 per GPU)",
                       "images_per_s": round(n / dt, 2), "batch": n, "image_size": s, "dtype": "f32", "losses": losses}))
 
 
