@@ -188,6 +188,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count() and os.environ.get("LWG_DIST_BACKEND") == "gloo":
+        local_rank %= torch.cuda.device_count()   # test hook: N ranks sharing the visible GPU(s), see sharding.init_process_group
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -111,6 +111,13 @@ def load():
     # import torch first so that its libamdhip64 is the one already mapped when liblwg's dependency is resolved
     # (loading liblwg first binds a second runtime that sees no device context: "no ROCm-capable device").
     import torch  # noqa: F401
+    # a library older than the kernel sources next to it must not run silently (the build stamps what it compiled)
+    stamp = os.path.join(_HERE, "_C", "liblwg.sha256")
+    if os.path.isdir(os.path.join(_HERE, "csrc")) and os.path.exists(stamp) and not os.environ.get("LWG_ALLOW_STALE_LIB"):
+        from . import build as _build
+        if open(stamp).read().strip() != _build._digest():
+            raise ImportError("liblwg.so was built from other sources than impersonator_amd/csrc + include/ hold now: "
+                              "run `python -m impersonator_amd.build` (LWG_ALLOW_STALE_LIB=1 overrides)")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -26,7 +26,9 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # LWG_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL wants a GPU per rank) -- how the multi-rank code
+            # paths are exercised where only one device is visible
+            backend = os.environ.get("LWG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
