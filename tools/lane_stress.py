@@ -19,6 +19,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 OVERLAP = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
 im, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=B, seed=0, affine="random")
 im.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+if OVERLAP:
+    im.round_depth = 1   # rounds of `lanes` batches: with deeper rounds a six-batch pass is one round and nothing overlaps
 smpls = torch.from_numpy(demo.synthetic_smpls(6 * B, seed=3)).cuda()
 im.first_cam = smpls[0:1, 0:3].clone()
 chunks = [(smpls[s:s + B], s) for s in range(0, 6 * B, B)]

@@ -15,6 +15,8 @@ OVERLAP = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
 KEYS = ("theta", "verts", "cam", "f2verts", "fim", "wim", "cond", "T", "tsf_img")
 im, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=B, seed=0, affine="random")
 im.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+if OVERLAP:
+    im.round_depth = 1   # rounds of `lanes` batches: with deeper rounds a six-batch pass is one round and nothing overlaps
 _orig_transfer = im.render.transfer
 _orig_tp = im.transfer_params_by_smpl
 
