@@ -54,24 +54,35 @@ __global__ __launch_bounds__(256) void stem_bf16x3_kernel(const StemArgs a)
 
     const int tiles_x = a.W / ST_COLS, tiles_y = a.H / ST_ROWS;
     const int ntiles = a.N * tiles_y * tiles_x;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // The halo of the NEXT tile is fetched into registers before the MFMAs of the current one (its global-load latency
+    // rides under ~4.5 us of matrix work) and converted / written to LDS once every wave has left the current halo.
+    constexpr int HE = (ST_HH * ST_HW + 255) / 256;   // halo entries (8 channels, 32 B of fp32) per thread
+    float4 pre[HE][2];
+    auto fetch_halo = [&](int tile) {
         const int img = tile / (tiles_y * tiles_x);
         const int trem = tile - img * (tiles_y * tiles_x);
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
         const int h0 = ty * ST_ROWS, c0 = tx * ST_COLS;
-
-        // ---- halo: fp32 NHWC8 -> two bf16 planes (zeros outside the image)
         const float *xin = a.x + (size_t)img * a.H * a.W * 8;
-        for (int e = tid; e < ST_HH * ST_HW; e += 256) {
+#pragma unroll
+        for (int k = 0; k < HE; ++k) {
+            const int e = tid + k * 256;
             const int hy = e / ST_HW, hx = e - hy * ST_HW;
             const int gy = h0 - 3 + hy, gx = c0 - 3 + hx;
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+            pre[k][0] = pre[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < ST_HH * ST_HW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
                 const float *p = xin + ((size_t)gy * a.W + gx) * 8;
-                v0 = *reinterpret_cast<const float4 *>(p);
-                v1 = *reinterpret_cast<const float4 *>(p + 4);
+                pre[k][0] = *reinterpret_cast<const float4 *>(p);
+                pre[k][1] = *reinterpret_cast<const float4 *>(p + 4);
             }
-            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        }
+    };
+    auto store_halo = [&]() {   // fp32 NHWC8 -> two bf16 planes (zeros outside the image)
+#pragma unroll
+        for (int k = 0; k < HE; ++k) {
+            const int e = tid + k * 256;
+            if (e >= ST_HH * ST_HW) break;
+            const float f[8] = {pre[k][0].x, pre[k][0].y, pre[k][0].z, pre[k][0].w, pre[k][1].x, pre[k][1].y, pre[k][1].z, pre[k][1].w};
             bf16x8_t hi, lo;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -81,7 +92,17 @@ __global__ __launch_bounds__(256) void stem_bf16x3_kernel(const StemArgs a)
             *reinterpret_cast<bf16x8_t *>(halo + e * 16) = hi;
             *reinterpret_cast<bf16x8_t *>(halo + ST_HPLANE + e * 16) = lo;
         }
+    };
+    if ((int)blockIdx.x < ntiles) fetch_halo(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / (tiles_y * tiles_x);
+        const int trem = tile - img * (tiles_y * tiles_x);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int h0 = ty * ST_ROWS, c0 = tx * ST_COLS;
+
+        store_halo();
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch_halo(tile + gridDim.x);
 
         // ---- 7 kernel rows x 4 tap pairs, 12 MFMAs each (2 x 2 tiles x {lo*hi, hi*lo, hi*hi})
         f32x16 acc[2][2];
