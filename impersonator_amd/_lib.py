@@ -65,6 +65,9 @@ _PROTOS = {
     "lwg_conv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "lwg_conv2d_backward_data": (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     "lwg_conv2d_backward_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    "lwg_heads_workspace_bytes": (_c.c_size_t, [_i, _i, _i]),
+    "lwg_heads_forward": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    "lwg_heads_backward_weight": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _c.c_size_t, _vp]),
     "lwg_discriminator_input_grad": (_i, [_vp, _vp, _i, _c.c_float, _vp, _vp, _vp]),
     "lwg_grid_sample_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lwg_instance_norm_scratch_bytes": (_c.c_size_t, [_i, _i, _i]),

@@ -46,7 +46,8 @@ struct ConvArgs {
     const float *w;
     const float *w_split;           // w in the split-bf16 format below (same offsets, opaque 4-byte units), or null
     int precision;                  // 0: exact fp32 MFMA on x / w;  1: bf16x3 on SPLIT x / w_split
-    const float *zeros;             // >= 16 bytes of zeros (source of out-of-image taps on the DMA path), may be null
+    const float *zeros;             // source of out-of-image taps on the DMA paths, may be null: >= 16 bytes of zeros
+                                    // (fp32); Cin floats behind the input tensor (bf16x3: read at the stage's channel offset)
     float *y; int ldy;              // raw (pre-norm) output NHWC
     int Ho, Wo, Cout;
     int Hm, Wm, stride, pad, os;

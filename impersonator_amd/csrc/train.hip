@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restr
 // to LDS as loaded, no transpose.  Workgroup = 64 co x 64 ci of one tap over a slice of the pixels, four waves of
 // 32 x 32; the slices' partial results are summed in a fixed order by reduce_slices_kernel (deterministic).
 constexpr int WG_PX = 32;
+constexpr long kWgradMaxSlices = 256;   // split-K bound (the partial buffer may hold fewer)
 // KWd x (ntaps / KWd) filter taps; oihw = 0: out[slice][Cout][ntaps][Cin] (matrix layout), 1: out[slice][Cout][Cin][ntaps].
 // T = 64: four waves of one 32x32 tile; T = 128 (both channel counts multiples of 128): four waves of 2x2 tiles -- four
 // times the MFMA work per byte staged through LDS.
@@ -293,11 +294,22 @@ int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin,
     const size_t w_floats = (size_t)O * ntaps * I;
     const int T = (O % 128 == 0 && I % 128 == 0) ? 128 : 64;
     const long tiles = (long)(O / T) * ceil_div(I, T) * ntaps;
-    long S = ceil_div(512, tiles);
-    if (S > 32) S = 32;
-    if (S > ceil_div(P, WG_PX)) S = ceil_div(P, WG_PX);
-    const long per = ceil_div(ceil_div(P, S), WG_PX) * (long)WG_PX;
-    S = ceil_div(P, per);
+    // Pixel slices (split-K).  The grid runs in rounds of `slots` resident workgroups (LDS: two 128-wide or four
+    // 64-wide ones per CU), each walking its slice in steps of WG_PX pixels: take the slice count with the fewest
+    // steps end to end (a 9-tap 512x512 layer is 144 tiles: 4 slices = 576 workgroups is two rounds of 32 steps,
+    // 3 slices one round of 43), within what the partial buffer holds.
+    const long slots = (long)device_cu_count() * (T == 128 ? 2 : 4);
+    long cap = (long)(part_floats / w_floats);
+    if (cap > kWgradMaxSlices) cap = kWgradMaxSlices;
+    if (cap > ceil_div(P, WG_PX)) cap = ceil_div(P, WG_PX);
+    if (cap < 1) cap = 1;
+    long S = 1, per = 0, best = -1;
+    for (long s = 1; s <= cap; ++s) {
+        const long ps = ceil_div(ceil_div(P, s), WG_PX) * (long)WG_PX;
+        const long se = ceil_div(P, ps);
+        const long cost = ceil_div(tiles * se, slots) * (ps / WG_PX + 2) + (se > 1 ? se / 8 : 0);   // + prologue/epilogue, + reduce
+        if (best < 0 || cost < best) { best = cost; S = se; per = ps; }
+    }
     if (S > 1 && (size_t)S * w_floats > part_floats) LWG_FAIL(LWG_ERR_STATE, "wgrad: partial buffer too small");
     float *wout = S == 1 ? out : part;
     const dim3 grid(ceil_div(I, T), O / T, (unsigned)(ntaps * S));
@@ -612,9 +624,9 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float *__restr
     if (mode == 0) {          // A = Cout, B = Cin: dst[a*pitch + t*B + b]
         const int b = (int)(i % B), t = (int)((i / B) % taps), a = (int)(i / ((long)B * taps));
         dst[(size_t)a * pitch + (size_t)t * B + b] = w[((size_t)a * B + b) * taps + t];
-    } else if (mode == 1) {   // A = Cout, B = Cin: dst[(b*taps + t)*A + a]
+    } else if (mode == 1) {   // A = Cout, B = Cin: dst[b*pitch + t*A + a]
         const int a = (int)(i % A), t = (int)((i / A) % taps), b = (int)(i / ((long)A * taps));
-        dst[i] = w[((size_t)a * B + b) * taps + (taps - 1 - t)];
+        dst[(size_t)b * pitch + (size_t)t * A + a] = w[((size_t)a * B + b) * taps + (taps - 1 - t)];
     } else {                  // four phases with 1, 2, 2, 4 taps, rows of B outputs x (t, a)
         long j = i;
         int phase = 0, nt = 1;
@@ -1070,9 +1082,67 @@ int conv_geom(const lwg_conv2d_desc *d, ConvGeom *g)
     return LWG_OK;
 }
 
-// plain conv through the general implicit GEMM: x (N,H,W,Cin) * wmat [Cout][k*k][Cin] -> y (N,Ho,Wo,Cout)
+// Scratch of the bf16x3 route (precision 1): the operand tensor and the weight matrices are re-written in the
+// split-bf16 format of conv.h ([hi x32 | lo x32] per 32 values, same offsets as fp32) and the DMA-fed kernel of the
+// inference path runs on them.  The zero run the kernel reads out-of-image taps from sits right behind the operand.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+struct SplitWs {
+    float *w = nullptr;       // split weight matrices (as many floats as the fp32 ones)
+    float *x = nullptr;       // split operand tensor
+    float *zeros = nullptr;   // one pixel's worth of channels (the kernel reads the zero run at the channel offset it is at)
+    size_t zero_floats = 0;
+};
+
+__global__ __launch_bounds__(256) void split_pack_kernel(const float4 *__restrict__ src, float *__restrict__ dst, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = src[i];
+    const size_t e = i * 4;
+    const size_t soff = (e >> 5) * 32 + ((e & 31) >> 1);   // 4-byte units: 8 bytes of hi, 8 of lo 64 B further
+    bf16x4_t h, l;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+    *reinterpret_cast<bf16x4_t *>(dst + soff) = h;
+    *reinterpret_cast<bf16x4_t *>(dst + soff + 16) = l;
+}
+
+int split_pack(const float *src, float *dst, size_t n, hipStream_t st)
+{
+    if (n % 32) LWG_FAIL(LWG_ERR_INVALID_ARG, "split: %zu floats is not a whole number of 32-value groups", n);
+    split_pack_kernel<<<(unsigned)ceil_div((long)(n / 4), 256), 256, 0, st>>>(reinterpret_cast<const float4 *>(src), dst, n / 4);
+    LWG_LAUNCH_CHECK("split_pack_kernel");
+    return LWG_OK;
+}
+
+// the DMA-fed bf16x3 kernel wants: 32-channel granularity on the reduction side, whole 128-pixel tiles per image,
+// at most 32 taps, no bias
+bool split_route_ok(int precision, int Cin, int Hm, int Wm, int taps, const float *bias)
+{
+    return precision == 1 && !bias && Cin % 32 == 0 && (Hm * Wm) % kConvBM == 0 && taps <= 32;
+}
+
+// operand + weights -> split copies; fills in the ConvArgs fields of the bf16x3 route
+int to_split_route(ConvArgs &a, const float *x, size_t x_floats, const float *wmat, size_t w_floats, const SplitWs &sw,
+                   hipStream_t st)
+{
+    int rc;
+    if ((rc = split_pack(x, sw.x, x_floats, st)) != LWG_OK) return rc;
+    if ((rc = split_pack(wmat, sw.w, w_floats, st)) != LWG_OK) return rc;
+    LWG_HIP(hipMemsetAsync(sw.zeros, 0, sw.zero_floats * sizeof(float), st));
+    a.x = sw.x;
+    a.w_split = sw.w;
+    a.zeros = sw.zeros;
+    a.precision = 1;
+    a.general = 0;
+    a.mtiles = a.N * a.Hm * a.Wm / kConvBM;
+    return LWG_OK;
+}
+
+// plain conv through the implicit GEMM: x (N,H,W,Cin) * wmat [Cout][k*k][Cin] -> y (N,Ho,Wo,Cout)
 int op_conv(const float *x, int N, int H, int W, int Cin, const float *wmat, const float *bias, int Cout, int k, int stride,
-            int pad, float *y, hipStream_t st)
+            int pad, float *y, hipStream_t st, int precision = 0, const SplitWs *sw = nullptr)
 {
     if (Cout % 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d: this direction needs a multiple of 64 output channels, got %d", Cout);
     ConvArgs a = base_args(x, Cin, N, H, Cin, wmat, y, Cout);
@@ -1084,11 +1154,17 @@ int op_conv(const float *x, int N, int H, int W, int Cin, const float *wmat, con
     a.nphase = 1;
     a.ph[0] = ConvPhase{k, k, k * k, (int)align_up((size_t)k * k * Cin, kConvBK), 0, 0, 0, 0, 0};   // wmat rows have this pitch
     a.mtiles = ceil_div((long)N * a.Hm * a.Wm, kConvBM);
+    if (sw && split_route_ok(precision, Cin, a.Hm, a.Wm, k * k, bias)) {
+        const int rc = to_split_route(a, x, (size_t)N * H * W * Cin, wmat, (size_t)Cout * a.ph[0].Kpad, *sw, st);
+        if (rc != LWG_OK) return rc;
+        return launch_conv_igemm(a, Cout % 128 == 0 ? 128 : 64, st);
+    }
     return launch_conv_igemm(a, (Cout % 128 == 0 && Cin >= kConvBK) ? 128 : 64, st);
 }
 
 // "transposed conv forward" through the 4-phase decomposition: x (N,H,W,Cin) * phase matrices -> y (N,2H,2W,Cout)
-int op_convT(const float *x, int N, int H, int W, int Cin, const float *wph, int Cout, float *y, hipStream_t st)
+int op_convT(const float *x, int N, int H, int W, int Cin, const float *wph, int Cout, float *y, hipStream_t st,
+             int precision = 0, const SplitWs *sw = nullptr)
 {
     if (Cout % 64 || Cin < kConvBK) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d: this direction needs Cout %% 64 == 0 and Cin >= 32");
     ConvArgs a = base_args(x, Cin, N, H, Cin, wph, y, Cout);
@@ -1103,26 +1179,75 @@ int op_convT(const float *x, int N, int H, int W, int Cin, const float *wph, int
         off += (long)Cout * nt * Cin;
     }
     a.mtiles = ceil_div((long)N * H * W, kConvBM);
+    if (sw && split_route_ok(precision, Cin, H, W, 4, nullptr)) {
+        const int rc = to_split_route(a, x, (size_t)N * H * W * Cin, wph, (size_t)off, *sw, st);
+        if (rc != LWG_OK) return rc;
+        a.fuse_phases = 0;
+        return launch_conv_igemm(a, Cout % 128 == 0 ? 128 : 64, st);
+    }
     return launch_conv_igemm(a, Cout % 128 == 0 ? 128 : 64, st);
 }
 
+// `pitch` (floats, 0 = dense): row pitch of the matrix -- rows are output channels: A of them with taps*B entries in
+// mode 0, B of them with taps*A entries in mode 1
 int relayout(const float *w, float *dst, int mode, int A, int B, int taps, long total, hipStream_t st, int pitch = 0)
 {
-    if (pitch && pitch != taps * B) LWG_HIP(hipMemsetAsync(dst, 0, (size_t)A * pitch * sizeof(float), st));
-    weight_layout_kernel<<<ceil_div(total, 256), 256, 0, st>>>(w, dst, mode, A, B, taps, total, pitch ? pitch : taps * B);
+    const int rows = mode == 1 ? B : A, dense = taps * (mode == 1 ? A : B);
+    if (pitch && pitch != dense) LWG_HIP(hipMemsetAsync(dst, 0, (size_t)rows * pitch * sizeof(float), st));
+    weight_layout_kernel<<<ceil_div(total, 256), 256, 0, st>>>(w, dst, mode, A, B, taps, total, pitch ? pitch : dense);
     LWG_LAUNCH_CHECK("weight_layout_kernel");
     return LWG_OK;
 }
 
 }  // namespace
 
+namespace {
+// floats of the fp32 part of the workspace: one re-laid-out weight matrix, or up to 32 split-K partial gradients + the
+// column-sum scratch (+ row padding of the matrix)
+// split-K partial gradients: 32 slices always, up to 256 for small filters (the 64-channel 256x256 layers have a quarter
+// of a million pixels to slice and 36 k weights), within 32 MiB
+size_t wgrad_part_floats(const ConvGeom &g)
+{
+    const size_t want = (size_t)kWgradMaxSlices * g.w_floats, lim = (size_t)8 << 20;
+    const size_t least = 32 * g.w_floats;
+    return want < lim ? want : (least > lim ? least : lim);
+}
+
+size_t base_ws_floats(const lwg_conv2d_desc *d, const ConvGeom &g)
+{
+    const size_t cmax = (size_t)(d->Cout > d->Cin ? d->Cout : d->Cin);
+    return align_up(wgrad_part_floats(g) + g.w_floats + (32 + kConvBK) * cmax + (size_t)CS_SLICES * cmax, (size_t)32);
+}
+
+// the larger of the two tensors a conv of this geometry touches (the forward's operand is x, the data gradient's is dy)
+size_t operand_floats(const lwg_conv2d_desc *d, const ConvGeom &g)
+{
+    const size_t xin = (size_t)d->N * d->H * d->W * d->Cin, yout = (size_t)d->N * g.Ho * g.Wo * d->Cout;
+    return align_up(xin > yout ? xin : yout, (size_t)32);
+}
+
+size_t zero_run_floats(const lwg_conv2d_desc *d) { return (size_t)(d->Cout > d->Cin ? d->Cout : d->Cin) + 32; }
+
+SplitWs carve_split(const lwg_conv2d_desc *d, const ConvGeom &g, void *ws)
+{
+    SplitWs sw;
+    // 128-byte aligned: the split format is addressed in 128-byte groups
+    float *p = reinterpret_cast<float *>(align_up((size_t)(uintptr_t)ws, (size_t)128)) + base_ws_floats(d, g);
+    sw.w = p;
+    sw.x = p + align_up(g.w_floats, (size_t)32);
+    sw.zeros = sw.x + operand_floats(d, g);
+    sw.zero_floats = zero_run_floats(d);
+    return sw;
+}
+}  // namespace
+
 size_t lwg_conv2d_workspace_bytes(const lwg_conv2d_desc *d)
 {
     ConvGeom g;
     if (conv_geom(d, &g) != LWG_OK) return 0;
-    // one re-laid-out weight matrix, or up to 32 split-K partial gradients + the column-sum scratch
-    return (33 * g.w_floats + (size_t)32 * (d->Cout > d->Cin ? d->Cout : d->Cin) +
-            (size_t)CS_SLICES * (d->Cout > d->Cin ? d->Cout : d->Cin)) * sizeof(float);   // + row padding of the matrix
+    size_t floats = base_ws_floats(d, g);
+    if (d->precision == 1) floats += align_up(g.w_floats, (size_t)32) + operand_floats(d, g) + zero_run_floats(d) + 32;   // + alignment slack
+    return floats * sizeof(float);
 }
 
 int lwg_conv2d_forward(const lwg_conv2d_desc *d, const float *x, const float *w, const float *bias, float *y, void *ws,
@@ -1135,14 +1260,16 @@ int lwg_conv2d_forward(const lwg_conv2d_desc *d, const float *x, const float *w,
     if (ws_bytes < lwg_conv2d_workspace_bytes(d)) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv2d_forward: workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *wm = static_cast<float *>(ws);
+    SplitWs sw_, *sw = nullptr;
+    if (d->precision == 1) { sw_ = carve_split(d, g, ws); sw = &sw_; }
     if (d->transposed) {
         if (bias) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_forward: bias on a transposed conv");
         if ((rc = relayout(w, wm, 2, d->Cin, d->Cout, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
-        return op_convT(x, d->N, d->H, d->W, d->Cin, wm, d->Cout, y, st);
+        return op_convT(x, d->N, d->H, d->W, d->Cin, wm, d->Cout, y, st, d->precision, sw);
     }
     const int pitch = (int)align_up((size_t)d->k * d->k * d->Cin, kConvBK);   // 7x7x8 = 392 -> 416
     if ((rc = relayout(w, wm, 0, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st, pitch)) != LWG_OK) return rc;
-    return op_conv(x, d->N, d->H, d->W, d->Cin, wm, bias, d->Cout, d->k, d->stride, d->pad, y, st);
+    return op_conv(x, d->N, d->H, d->W, d->Cin, wm, bias, d->Cout, d->k, d->stride, d->pad, y, st, d->precision, sw);
 }
 
 int lwg_conv2d_backward_data(const lwg_conv2d_desc *d, const float *dy, const float *w, float *dx, void *ws, size_t ws_bytes,
@@ -1155,21 +1282,25 @@ int lwg_conv2d_backward_data(const lwg_conv2d_desc *d, const float *dy, const fl
     if (ws_bytes < lwg_conv2d_workspace_bytes(d)) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv2d_backward_data: workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *wm = static_cast<float *>(ws);
+    SplitWs sw_, *sw = nullptr;
+    if (d->precision == 1) { sw_ = carve_split(d, g, ws); sw = &sw_; }
     if (d->transposed) {
         // gradient of ConvTranspose2d(k3,s2,p1,op1) = Conv2d(k3,s2,p1) of dy whose OIHW tensor is the (Cin,Cout,3,3) one
         if ((rc = relayout(w, wm, 0, d->Cin, d->Cout, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
-        return op_conv(dy, d->N, g.Ho, g.Wo, d->Cout, wm, nullptr, d->Cin, 3, 2, 1, dx, st);
+        return op_conv(dy, d->N, g.Ho, g.Wo, d->Cout, wm, nullptr, d->Cin, 3, 2, 1, dx, st, d->precision, sw);
     }
     if (d->stride == 1) {
         if (2 * d->pad != d->k - 1) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_data: stride-1 convs need 'same' padding");
-        if ((rc = relayout(w, wm, 1, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st)) != LWG_OK) return rc;
-        return op_conv(dy, d->N, g.Ho, g.Wo, d->Cout, wm, nullptr, d->Cin, d->k, 1, d->k - 1 - d->pad, dx, st);
+        // rows of k*k*Cout entries, padded to the reduction slice (the heads' data gradient: 49 x 8 = 392 -> 416)
+        const int pitch = (int)align_up((size_t)d->k * d->k * d->Cout, kConvBK);
+        if ((rc = relayout(w, wm, 1, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st, pitch)) != LWG_OK) return rc;
+        return op_conv(dy, d->N, g.Ho, g.Wo, d->Cout, wm, nullptr, d->Cin, d->k, 1, d->k - 1 - d->pad, dx, st, d->precision, sw);
     }
     if (d->k != 3 || d->pad != 1 || (d->H & 1) || (d->W & 1))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_data: stride-2 convs are k3 p1 on even sizes (the discriminator's k4 has its own path)");
     // gradient of Conv2d(k3,s2,p1) = ConvTranspose2d(k3,s2,p1,op1) forward of dy with the same tensor read as (Cout,Cin,3,3)
     if ((rc = relayout(w, wm, 2, d->Cout, d->Cin, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
-    return op_convT(dy, d->N, g.Ho, g.Wo, d->Cout, wm, d->Cin, dx, st);
+    return op_convT(dy, d->N, g.Ho, g.Wo, d->Cout, wm, d->Cin, dx, st, d->precision, sw);
 }
 
 int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const float *dy, float *dw, float *dbias, void *ws,
@@ -1191,15 +1322,220 @@ int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const f
     const int stride = d->transposed ? 2 : d->stride, pad = d->pad, taps = d->k * d->k;
     if (O % 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_weight: needs a multiple of 64 channels on the gradient side, got %d", O);
     const long P = (long)d->N * Hg * Wg;
-    if ((rc = launch_wgrad(go, O, in, I, d->N, Hin, Win, Hg, Wg, stride, pad, d->k, taps, 1, dw, part, 32 * g.w_floats, st)) != LWG_OK) return rc;
+    if ((rc = launch_wgrad(go, O, in, I, d->N, Hin, Win, Hg, Wg, stride, pad, d->k, taps, 1, dw, part, wgrad_part_floats(g), st)) != LWG_OK) return rc;
     if (dbias) {
         if (d->transposed) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_weight: bias gradient of a transposed conv");
-        float *cs = part + 32 * g.w_floats;
+        float *cs = part + wgrad_part_floats(g);
         col_sum_partial_kernel<<<dim3(d->Cout / 64, CS_SLICES), 256, 0, st>>>(dy, P, d->Cout, cs);
         LWG_LAUNCH_CHECK("col_sum_partial_kernel");
         reduce_slices_kernel<<<ceil_div(d->Cout, 256), 256, 0, st>>>(cs, CS_SLICES, d->Cout, dbias);
         LWG_LAUNCH_CHECK("reduce_slices_kernel");
     }
+    return LWG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The regression heads in the training step (generator.py:142-152: 7x7 conv of the 64-channel decoder output to 3
+// colour channels + 1 mask channel).  As 64-output convolutions (their first form here) they cost 16 x their arithmetic.
+//   forward        : the inference path's fp32 heads kernel (conv.hip) behind an identity InstanceNorm
+//   data gradient  : lwg_conv2d_backward_data with Cout = 8 (a 7x7 conv of an 8-channel tensor: the stem's kernel)
+//   weight gradient: below
+namespace {
+
+// wh[tap][c][o] (o < 4) from w (R >= 4 rows, 64, 7, 7)
+__global__ __launch_bounds__(256) void heads_weight_kernel(const float *__restrict__ w, float *__restrict__ wh)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 49 * 64 * 4) return;
+    const int o = i & 3, c = (i >> 2) & 63, tap = i >> 8;
+    wh[i] = w[((size_t)o * 64 + c) * 49 + tap];
+}
+__global__ __launch_bounds__(256) void fill_identity_norm_kernel(float2 *ss, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ss[i] = make_float2(1.f, 0.f);
+}
+
+// dW[o][c][ky][kx] = sum_p dY[p][o] * X[p + (ky-3, kx-3)][c]  with dY (N,H,W,8) and X (N,H,W,64), as the GEMM
+//   OUT[m = (ky', kx', o)][c] = sum_q dY[q + (ky'-3, kx'-3)][o] * X[q][c]      (q = p + tap - 3, so tap' = 6 - tap)
+// M = 49 x 8 = 392 (13 tiles of 32), N = 64, K = the pixels.  A workgroup walks a slice of the pixels in steps of 32
+// consecutive pixels of one image row: the A operand of a step is a 7 x 38-pixel band of dY in LDS (8.5 KiB) read in
+// place -- row m of the im2col matrix is the band at offset ky'*304 + kx'*8 + o, stride 8 per pixel -- so nothing is
+// gathered; v_mfma_f32_32x32x2_f32 takes one ds_read_b32 per lane from it.  Four waves: wave (wm, wn) owns column tile wn
+// and the row tiles wm, wm+2, ...  The slices' partial results are summed in a fixed order by heads_wgrad_reduce_kernel,
+// which also undoes the tap flip and writes PyTorch's (8,64,7,7) layout.
+constexpr int HG_PX = 32, HG_BAND_ROW = (HG_PX + 6) * 8, HG_BAND = 7 * HG_BAND_ROW, HG_XP = 64 + 4, HG_M = 392, HG_MT = 13;
+constexpr int HG_BUF = HG_BAND + HG_PX * HG_XP;   // floats per LDS buffer
+
+__global__ __launch_bounds__(256) void wgrad_heads_kernel(const float *__restrict__ x, const float *__restrict__ dy, int N, int H,
+                                                          int W, long steps_per_slice, float *__restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) float sm[2 * HG_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int row_steps = (W + HG_PX - 1) / HG_PX;
+    const long total = (long)N * H * row_steps;
+    const long g0 = (long)blockIdx.x * steps_per_slice, g1 = g0 + steps_per_slice < total ? g0 + steps_per_slice : total;
+
+    float4 rd[3], rx[2];
+    auto load = [&](long g) {
+        const int n = (int)(g / ((long)H * row_steps));
+        const int r = (int)(g - (long)n * H * row_steps);
+        const int qy = r / row_steps, qx0 = (r - qy * row_steps) * HG_PX;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + 256 * k;   // band: 7 rows x 76 float4 (38 pixels x 8 channels)
+            rd[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < 7 * 76) {
+                const int br = idx / 76, f4 = idx - br * 76;
+                const int sy = qy + br - 3, sx = qx0 - 3 + (f4 >> 1);
+                if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+                    rd[k] = ld4(dy + (((size_t)n * H + sy) * W + sx) * 8 + (f4 & 1) * 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + 256 * k;   // x tile: 32 pixels x 16 float4
+            const int px = idx >> 4, f4 = idx & 15;
+            rx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qx0 + px < W) rx[k] = ld4(x + (((size_t)n * H + qy) * W + qx0 + px) * 64 + f4 * 4);
+        }
+    };
+    auto store = [&](int buf) {
+        float *b = sm + buf * HG_BUF;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < 7 * 76) *reinterpret_cast<float4 *>(b + idx * 4) = rd[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + 256 * k;
+            *reinterpret_cast<float4 *>(b + HG_BAND + (idx >> 4) * HG_XP + (idx & 15) * 4) = rx[k];
+        }
+    };
+    // LDS offsets of this lane's A rows: m -> (tap' = m >> 3, o = m & 7); rows past 391 repeat the last one (never stored)
+    int abase[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        int m = (wm + 2 * i) * 32 + (lane & 31);
+        if (m > HG_M - 1) m = HG_M - 1;
+        const int tap = m >> 3, o = m & 7, ky = tap / 7, kx = tap - ky * 7;
+        abase[i] = ky * HG_BAND_ROW + kx * 8 + o + 8 * (lane >> 5);
+    }
+    const int bbase = HG_BAND + (lane >> 5) * HG_XP + wn * 32 + (lane & 31);
+    f32x16 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    int buf = 0;
+    if (g0 < g1) {
+        load(g0);
+        store(0);
+    }
+    __syncthreads();
+    for (long g = g0; g < g1; ++g) {
+        const bool more = g + 1 < g1;
+        if (more) load(g + 1);
+        const float *b = sm + buf * HG_BUF;
+#pragma unroll
+        for (int kk = 0; kk < HG_PX / 2; ++kk) {
+            const float bv = b[bbase + 2 * kk * HG_XP];
+            float av[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) av[i] = b[abase[i] + 16 * kk];
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                if (wm + 2 * i < HG_MT) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C/D layout: col = lane&31 -> channel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> m inside the tile
+    float *o = part + (size_t)blockIdx.x * HG_M * 64;
+    const int c = wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        if (wm + 2 * i >= HG_MT) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (wm + 2 * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < HG_M) o[(size_t)m * 64 + c] = acc[i][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void heads_wgrad_reduce_kernel(const float *__restrict__ part, int S, float *__restrict__ dw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HG_M * 64) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * HG_M * 64 + i];
+    const int c = i & 63, m = i >> 6, o = m & 7, tap = m >> 3;
+    const int ky = 6 - tap / 7, kx = 6 - tap % 7;
+    dw[(((size_t)o * 64 + c) * 7 + ky) * 7 + kx] = s;
+}
+
+constexpr long kHeadsMaxSlices = 512;   // two workgroups per CU of a 256-CU part
+long heads_wgrad_slices(int N, int H, int W, long *steps_per_slice)
+{
+    const long total = (long)N * H * ceil_div(W, HG_PX);
+    long S = kHeadsMaxSlices;
+    if (S > total) S = total;
+    *steps_per_slice = ceil_div(total, S);
+    return ceil_div(total, *steps_per_slice);
+}
+constexpr size_t kHeadsWFloats = 49 * 64 * 4;
+
+}  // namespace
+
+size_t lwg_heads_workspace_bytes(int N, int H, int W)
+{
+    if (N < 1 || H < 1 || W < 1) return 0;
+    // the larger of: forward (re-laid-out weights + identity scale/shift) and weight gradient (slice partials)
+    const size_t fwd = kHeadsWFloats + (size_t)N * 64 * 2, wg = (size_t)kHeadsMaxSlices * HG_M * 64;
+    return (fwd > wg ? fwd : wg) * sizeof(float);
+}
+
+int lwg_heads_forward(const float *x, int N, int H, int W, const float *w, int w_rows, float *color, float *mask, void *ws,
+                      size_t ws_bytes, lwg_stream_t stream)
+{
+    LWG_REQUIRE(x && w && ws && (color || mask), "heads_forward: NULL argument");
+    if (w_rows < 4) LWG_FAIL(LWG_ERR_INVALID_ARG, "heads_forward: the weight tensor needs >= 4 rows (3 colour + 1 mask), got %d", w_rows);
+    if (ws_bytes < lwg_heads_workspace_bytes(N, H, W)) LWG_FAIL(LWG_ERR_INVALID_ARG, "heads_forward: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *wh = static_cast<float *>(ws);
+    float2 *ss = reinterpret_cast<float2 *>(wh + kHeadsWFloats);
+    heads_weight_kernel<<<ceil_div((long)kHeadsWFloats, 256), 256, 0, st>>>(w, wh);
+    LWG_LAUNCH_CHECK("heads_weight_kernel");
+    fill_identity_norm_kernel<<<ceil_div((long)N * 64, 256), 256, 0, st>>>(ss, N * 64);
+    LWG_LAUNCH_CHECK("fill_identity_norm_kernel");
+    HeadsArgs h = {};
+    h.x = x; h.N = N; h.H = H; h.W = W;
+    h.scale_shift = ss;
+    h.wh = wh;
+    h.color = color;
+    h.mask = mask;
+    return launch_heads(h, st);
+}
+
+int lwg_heads_backward_weight(const float *x, const float *dy8, int N, int H, int W, float *dw, void *ws, size_t ws_bytes,
+                              lwg_stream_t stream)
+{
+    LWG_REQUIRE(x && dy8 && dw && ws, "heads_backward_weight: NULL argument");
+    if (N < 1 || H < 1 || W < 1) LWG_FAIL(LWG_ERR_INVALID_ARG, "heads_backward_weight: empty tensor");
+    if (ws_bytes < lwg_heads_workspace_bytes(N, H, W)) LWG_FAIL(LWG_ERR_INVALID_ARG, "heads_backward_weight: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    long per = 0;
+    const long S = heads_wgrad_slices(N, H, W, &per);
+    float *part = static_cast<float *>(ws);
+    wgrad_heads_kernel<<<(unsigned)S, 256, 0, st>>>(x, dy8, N, H, W, per, part);
+    LWG_LAUNCH_CHECK("wgrad_heads_kernel");
+    heads_wgrad_reduce_kernel<<<ceil_div((long)HG_M * 64, 256), 256, 0, st>>>(part, (int)S, dw);
+    LWG_LAUNCH_CHECK("heads_wgrad_reduce_kernel");
     return LWG_OK;
 }
 

@@ -38,7 +38,7 @@ class _ConvIN(object):
     def forward(self, x):
         P = self.tr.P
         self.x = x
-        self.raw = ops.conv2d_forward(x, P[self.wkey], None, self.stride, self.pad, self.transposed)
+        self.raw = ops.conv2d_forward(x, P[self.wkey], None, self.stride, self.pad, self.transposed, self.tr.conv_precision)
         self.y, self.stats = ops.instance_norm_forward(self.raw, P[self.gkey], P[self.bkey], self.relu)
         return self.y
 
@@ -50,7 +50,8 @@ class _ConvIN(object):
         G[self.wkey].add_(ops.conv2d_backward_weight(self.x, draw, tuple(P[self.wkey].shape), self.stride, self.pad, self.transposed))
         if not need_dx:
             return None
-        return ops.conv2d_backward_data(draw, P[self.wkey], tuple(self.x.shape), self.stride, self.pad, self.transposed)
+        return ops.conv2d_backward_data(draw, P[self.wkey], tuple(self.x.shape), self.stride, self.pad, self.transposed,
+                                        self.tr.conv_precision)
 
 
 class _Res(object):
@@ -67,20 +68,33 @@ class _Res(object):
         return dy + self.a.backward(self.b.backward(dy))
 
 
+HEAD_ROWS = 8   # device rows of a head's weight tensor: 3 colour + 1 mask (+ zero rows up to the kernels' granularity)
+
+
 class _Head(object):
-    """7x7 conv to a few channels (+tanh / sigmoid outside): run as a 64-output conv whose extra rows are zero."""
+    """The 7x7 regression heads (generator.py:142-152) on their own kernels: tanh(conv) / sigmoid(conv) fused in the
+    forward; the gradients take d(pre-activation) as an 8-channel NHWC tensor."""
 
     def __init__(self, tr, key):
         self.tr, self.key = tr, key
 
     def forward(self, x):
+        """x (N,H,W,64) -> (img (N,H,W,3) = tanh, mask (N,H,W,1) = sigmoid), NHWC like every tensor of the trainer."""
         self.x = x
-        return ops.conv2d_forward(x, self.tr.P[self.key], None, 1, 3)
+        color, mask = ops.heads_forward(x, self.tr.P[self.key])
+        self.img = color.permute(0, 2, 3, 1).contiguous()
+        self.mask = mask.permute(0, 2, 3, 1).contiguous()
+        return self.img, self.mask
 
-    def backward(self, dy64):
+    def backward(self, d_img, d_mask=None):
+        """gradients wrt the activated outputs -> dW accumulated, returns d x"""
         P, G = self.tr.P, self.tr.G
-        G[self.key].add_(ops.conv2d_backward_weight(self.x, dy64, tuple(P[self.key].shape), 1, 3))
-        return ops.conv2d_backward_data(dy64, P[self.key], tuple(self.x.shape), 1, 3)
+        d8 = torch.zeros(self.img.shape[:-1] + (HEAD_ROWS,), device=self.img.device, dtype=torch.float32)
+        d8[..., 0:3] = d_img * (1 - self.img * self.img)
+        if d_mask is not None:
+            d8[..., 3:4] = d_mask * self.mask * (1 - self.mask)
+        G[self.key].add_(ops.heads_backward_weight(self.x, d8))
+        return ops.conv2d_backward_data(d8, P[self.key], tuple(self.x.shape), 1, 3)
 
 
 class _ResUnet(object):
@@ -104,17 +118,12 @@ class _ResUnet(object):
             skip = enc_outs[N_DOWN - 1 - i]
             self.cat_c.append(skip.shape[-1])
             d = self.skip[i].forward(torch.cat([skip, d], dim=-1))
-        out = self.head.forward(d)
-        self.img = torch.tanh(out[..., 0:3])
-        self.mask = torch.sigmoid(out[..., 3:4])
+        self.img, self.mask = self.head.forward(d)
         return self.img, self.mask
 
     def decode_regress_backward(self, d_img, d_mask):
         """-> (d trunk output, [d enc_outs[0..N_DOWN-1]])"""
-        d_out = torch.zeros(self.img.shape[:-1] + (64,), device=self.img.device, dtype=torch.float32)
-        d_out[..., 0:3] = d_img * (1 - self.img * self.img)
-        d_out[..., 3:4] = d_mask * self.mask * (1 - self.mask)
-        d = self.head.backward(d_out)
+        d = self.head.backward(d_img, d_mask)
         d_skips = [None] * N_DOWN
         for i in reversed(range(N_DOWN)):
             d_cat = self.skip[i].backward(d)
@@ -128,7 +137,12 @@ class GeneratorTrainer(object):
     """One Adam optimiser over the ImpersonatorGenerator's 194 parameter tensors with a hand-written backward pass."""
 
     def __init__(self, generator, discriminator, lambda_D_prob=1.0, lambda_rec=10.0, lambda_tsf=10.0, lambda_mask=0.1,
-                 lambda_mask_smooth=1e-5, lr=0.0002, betas=(0.5, 0.999), eps=1e-8):
+                 lambda_mask_smooth=1e-5, lr=0.0002, betas=(0.5, 0.999), eps=1e-8, conv_precision="fp32"):
+        """conv_precision 'bf16x3': the forward and data-gradient convolutions of the three streams run the inference
+        path's split-bf16 kernel (include/lwg.h, lwg_conv2d_desc.precision); weight gradients, norms, heads, Adam: fp32."""
+        if conv_precision not in ops.PRECISIONS:
+            raise ValueError("conv_precision must be one of %s" % sorted(ops.PRECISIONS))
+        self.conv_precision = conv_precision
         self.generator, self.D = generator, discriminator
         self.lam = dict(adv=lambda_D_prob, rec=lambda_rec, tsf=lambda_tsf, mask=lambda_mask, smooth=lambda_mask_smooth)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
@@ -137,16 +151,16 @@ class GeneratorTrainer(object):
         dev = torch.device("cuda", torch.cuda.current_device())
         sd = {k: v.detach().float() for k, v in generator.state_dict().items()}
         # device layout of every trainable tensor: state_dict layout, except 7x7 stems (input channels padded to 8)
-        # and the few-channel 7x7 heads (combined / padded to 64 output rows)
+        # and the few-channel 7x7 heads (colour + mask combined, padded to HEAD_ROWS output rows)
         self.spec = []   # (device key, shape, [(state_dict key, row slice, in-channel count)])
         for k, v in sd.items():
             if k.endswith("img_reg.0.weight"):
                 p = k[:-len(".img_reg.0.weight")]
-                self.spec.append(("heads:" + p, (64, 64, 7, 7), [(k, slice(0, 3), 64), (p + ".attetion_reg.0.weight", slice(3, 4), 64)]))
+                self.spec.append(("heads:" + p, (HEAD_ROWS, 64, 7, 7), [(k, slice(0, 3), 64), (p + ".attetion_reg.0.weight", slice(3, 4), 64)]))
             elif k.endswith("attetion_reg.0.weight"):
                 continue
             elif k == "bg_model.model.%d.weight" % (3 + 3 * N_DOWN + self.repeat + 3 * N_DOWN):
-                self.spec.append(("heads:bg", (64, 64, 7, 7), [(k, slice(0, 3), 64)]))
+                self.spec.append(("heads:bg", (HEAD_ROWS, 64, 7, 7), [(k, slice(0, 3), 64)]))
             elif v.dim() == 4 and v.shape[2] == 7:
                 self.spec.append((k, (v.shape[0], 8, 7, 7), [(k, slice(0, v.shape[0]), v.shape[1])]))
             else:
@@ -208,7 +222,7 @@ class GeneratorTrainer(object):
         x = _nhwc(b["input_G_bg"], 8)
         for m in self.bg_enc + self.bg_res + self.bg_dec:
             x = m.forward(x)
-        self.bg_img = torch.tanh(self.bg_head.forward(x)[..., 0:3])
+        self.bg_img = self.bg_head.forward(x)[0]
         # --- source stream (features kept for the Liquid Warping Block)
         x = _nhwc(b["input_G_src"], 8)
         self.src_enc = []
@@ -302,9 +316,7 @@ class GeneratorTrainer(object):
             d = self.src.enc[i].backward(d)
         self.src.enc[0].backward(d + d_skips[0], need_dx=False)
         # --- BGNet
-        d_out = torch.zeros(bg.shape[:-1] + (64,), device=bg.device, dtype=torch.float32)
-        d_out[..., 0:3] = d_bg * (1 - bg * bg)
-        d = self.bg_head.backward(d_out)
+        d = self.bg_head.backward(d_bg)
         mods = self.bg_enc + self.bg_res + self.bg_dec
         for j in reversed(range(len(mods))):
             d = mods[j].backward(d) if j > 0 else mods[j].backward(d, need_dx=False)

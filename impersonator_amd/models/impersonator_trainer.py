@@ -124,7 +124,8 @@ class Impersonator(BaseModel):
                 self._G, self._D, lambda_D_prob=getattr(o, 'lambda_D_prob', 1), lambda_rec=getattr(o, 'lambda_rec', 10),
                 lambda_tsf=getattr(o, 'lambda_tsf', 10), lambda_mask=getattr(o, 'lambda_mask', 0.1),
                 lambda_mask_smooth=getattr(o, 'lambda_mask_smooth', 1e-5), lr=getattr(o, 'lr_G', 0.0002),
-                betas=(getattr(o, 'G_adam_b1', 0.5), getattr(o, 'G_adam_b2', 0.999)))
+                betas=(getattr(o, 'G_adam_b1', 0.5), getattr(o, 'G_adam_b2', 0.999)),
+                conv_precision=getattr(o, 'conv_precision', 'fp32'))
         return self._g_trainer
 
     def sync_generator(self):

@@ -10,12 +10,15 @@ from . import _lib
 
 
 class _Desc(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int) for n in ("N", "H", "W", "Cin", "Cout", "k", "stride", "pad", "transposed")]
+    _fields_ = [(n, ctypes.c_int) for n in ("N", "H", "W", "Cin", "Cout", "k", "stride", "pad", "transposed", "precision")]
 
 
-def _desc(x_shape, cin, cout, k, stride, pad, transposed):
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
+
+def _desc(x_shape, cin, cout, k, stride, pad, transposed, precision="fp32"):
     n, h, w, _ = x_shape
-    return _Desc(n, h, w, cin, cout, k, stride, pad, int(transposed))
+    return _Desc(n, h, w, cin, cout, k, stride, pad, int(transposed), PRECISIONS[precision])
 
 
 def _ws(d, dev):
@@ -36,11 +39,12 @@ def _chk(*ts):
 
 
 @torch.no_grad()
-def conv2d_forward(x, w, bias=None, stride=1, pad=0, transposed=False):
-    """x (N,H,W,Cin) -> (N,Ho,Wo,Cout); F.conv2d / F.conv_transpose2d(stride 2, padding 1, output_padding 1)."""
+def conv2d_forward(x, w, bias=None, stride=1, pad=0, transposed=False, precision="fp32"):
+    """x (N,H,W,Cin) -> (N,Ho,Wo,Cout); F.conv2d / F.conv_transpose2d(stride 2, padding 1, output_padding 1).
+    precision 'bf16x3': the inference path's split-bf16 kernel where the layer fits it (include/lwg.h)."""
     _chk(x, w, bias)
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-    d = _desc(x.shape, cin, cout, w.shape[2], stride, pad, transposed)
+    d = _desc(x.shape, cin, cout, w.shape[2], stride, pad, transposed, precision)
     ho, wo = _out_hw(x.shape[1], x.shape[2], w.shape[2], stride, pad, transposed)
     y = torch.empty((x.shape[0], ho, wo, cout), device=x.device, dtype=torch.float32)
     ws, nb = _ws(d, x.device)
@@ -50,11 +54,11 @@ def conv2d_forward(x, w, bias=None, stride=1, pad=0, transposed=False):
 
 
 @torch.no_grad()
-def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, transposed=False):
+def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, transposed=False, precision="fp32"):
     """Gradient wrt the input: dy (N,Ho,Wo,Cout) -> dx of shape x_shape (N,H,W,Cin)."""
     _chk(dy, w)
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-    d = _desc(x_shape, cin, cout, w.shape[2], stride, pad, transposed)
+    d = _desc(x_shape, cin, cout, w.shape[2], stride, pad, transposed, precision)
     dx = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
     ws, nb = _ws(d, dy.device)
     _lib.check(_lib.load().lwg_conv2d_backward_data(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(ws), nb,
@@ -74,6 +78,40 @@ def conv2d_backward_weight(x, dy, w_shape, stride=1, pad=0, transposed=False, wi
     _lib.check(_lib.load().lwg_conv2d_backward_weight(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db),
                                                       _lib.ptr(ws), nb, _lib.stream_ptr()))
     return (dw, db) if with_bias else dw
+
+
+def _heads_ws(n, h, w, dev):
+    nbytes = _lib.load().lwg_heads_workspace_bytes(n, h, w)
+    return torch.empty(nbytes // 4 + 1, device=dev, dtype=torch.float32), nbytes
+
+
+@torch.no_grad()
+def heads_forward(x, w):
+    """Regression heads: x (N,H,W,64), w (>=4,64,7,7) -> (tanh(conv rows 0-2) (N,3,H,W), sigmoid(conv row 3) (N,1,H,W))."""
+    _chk(x, w)
+    n, h, wd, c = x.shape
+    if c != 64 or tuple(w.shape[1:]) != (64, 7, 7) or w.shape[0] < 4:
+        raise RuntimeError("heads_forward: x (N,H,W,64) and w (>=4,64,7,7) expected")
+    color = torch.empty((n, 3, h, wd), device=x.device, dtype=torch.float32)
+    mask = torch.empty((n, 1, h, wd), device=x.device, dtype=torch.float32)
+    ws, nb = _heads_ws(n, h, wd, x.device)
+    _lib.check(_lib.load().lwg_heads_forward(_lib.ptr(x), n, h, wd, _lib.ptr(w), int(w.shape[0]), _lib.ptr(color), _lib.ptr(mask),
+                                             _lib.ptr(ws), nb, _lib.stream_ptr()))
+    return color, mask
+
+
+@torch.no_grad()
+def heads_backward_weight(x, dy8):
+    """x (N,H,W,64), dy8 (N,H,W,8) (gradient wrt the pre-activation head outputs, channels 4-7 zero) -> dw (8,64,7,7)."""
+    _chk(x, dy8)
+    n, h, wd, c = x.shape
+    if c != 64 or tuple(dy8.shape) != (n, h, wd, 8):
+        raise RuntimeError("heads_backward_weight: x (N,H,W,64) and dy8 (N,H,W,8) expected")
+    dw = torch.empty((8, 64, 7, 7), device=x.device, dtype=torch.float32)
+    ws, nb = _heads_ws(n, h, wd, x.device)
+    _lib.check(_lib.load().lwg_heads_backward_weight(_lib.ptr(x), _lib.ptr(dy8), n, h, wd, _lib.ptr(dw), _lib.ptr(ws), nb,
+                                                     _lib.stream_ptr()))
+    return dw
 
 
 @torch.no_grad()

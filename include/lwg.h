@@ -254,9 +254,14 @@ LWG_API int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float be
  * 80-133 under loss.backward(), models/impersonator_trainer.py:355-357).  fp32 MFMA; channel counts powers of two >= 8,
  * the side that becomes the GEMM's N dimension a multiple of 64 (Cout for forward, Cin for backward_data; for
  * backward_weight Cout, or Cin when transposed).  stride 1: any k <= 7 with 'same' padding for backward_data;
- * stride 2: k3 p1 on even sizes.  workspace: lwg_conv2d_workspace_bytes, scratch only (nothing persists). */
+ * stride 2: k3 p1 on even sizes.  workspace: lwg_conv2d_workspace_bytes, scratch only (nothing persists).
+ * precision 0: fp32 MFMA.  precision 1: forward and backward_data run the inference path's bf16x3 kernel (operands
+ * carried as two bf16 terms, three MFMA products, fp32 accumulation: ~2^-16 relative per operand) wherever the layer
+ * fits it -- no bias, reduction-side channels a multiple of 32, output grid per image a multiple of 128 pixels, at most
+ * 32 taps -- and the fp32 kernel elsewhere; backward_weight is fp32 either way. */
 typedef struct lwg_conv2d_desc {
     int N, H, W, Cin, Cout, k, stride, pad, transposed;
+    int precision;
 } lwg_conv2d_desc;
 LWG_API size_t lwg_conv2d_workspace_bytes(const lwg_conv2d_desc *d);
 LWG_API int lwg_conv2d_forward(const lwg_conv2d_desc *d, const float *x, const float *w, const float *bias, float *y,
@@ -265,6 +270,17 @@ LWG_API int lwg_conv2d_backward_data(const lwg_conv2d_desc *d, const float *dy, 
                                      void *workspace, size_t workspace_bytes, lwg_stream_t stream);
 LWG_API int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                                        void *workspace, size_t workspace_bytes, lwg_stream_t stream);
+
+/* The regression heads inside the training step (networks/generator.py:142-152, 163-171: img_reg = Conv2d(64,3,7,1,3) +
+ * Tanh, attetion_reg = Conv2d(64,1,7,1,3) + Sigmoid, no bias).  x (N,H,W,64) NHWC; w (w_rows >= 4, 64, 7, 7): rows 0-2 the
+ * colour head, row 3 the mask head.  forward: color (N,3,H,W) = tanh(conv), mask (N,1,H,W) = sigmoid(conv), either may
+ * be NULL.  backward_weight: dy8 (N,H,W,8) = gradient wrt the PRE-activation outputs (channels 4-7 zero) -> dw (8,64,7,7).
+ * The data gradient is lwg_conv2d_backward_data with Cout = 8.  workspace: lwg_heads_workspace_bytes, scratch only. */
+LWG_API size_t lwg_heads_workspace_bytes(int N, int H, int W);
+LWG_API int lwg_heads_forward(const float *x, int N, int H, int W, const float *w, int w_rows, float *color, float *mask,
+                              void *workspace, size_t workspace_bytes, lwg_stream_t stream);
+LWG_API int lwg_heads_backward_weight(const float *x, const float *dy8, int N, int H, int W, float *dw, void *workspace,
+                                      size_t workspace_bytes, lwg_stream_t stream);
 
 /* Generator-side adversarial term (models/impersonator_trainer.py:369-371): loss = mean((D(x) - target)^2) on
  * x (bs,input_nc,is,is) NCHW and its gradient wrt x (same shape); the discriminator's parameters get no gradient. */

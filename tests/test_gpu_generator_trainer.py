@@ -47,6 +47,34 @@ def test_forward_and_loss_terms(setup):
         assert abs(float(mine[k]) - float(v)) < 1e-4 * max(1.0, abs(float(v))), k
 
 
+def test_bf16x3_convolutions(setup):
+    """conv_precision='bf16x3': forward / data-gradient convs of the layers that fit the split-bf16 kernel (here the
+    64x64 .. 16x16 levels; the 8x8 trunk of this small case stays fp32).  Same bounds as the fp32 trainer."""
+    from impersonator_amd.models.generator_trainer import GeneratorTrainer
+    ref_tr, b = setup["tr"], setup["batch"]
+    tr = GeneratorTrainer(ref_tr.generator, ref_tr.D, conv_precision="bf16x3")
+    fake = tr.forward(b)
+    with torch.no_grad():
+        _, terms, ref_fake = torch_ref.generator_train_loss(setup["gsd"], setup["dsd"], b)
+    for name, a, c in zip(("fake_bg", "fake_src", "fake_tsf", "masks"), fake, ref_fake):
+        assert float((a.cpu() - c).abs().max()) < 2e-4, name
+    mine = tr.backward()
+    for k, v in terms.items():
+        assert abs(float(mine[k]) - float(v)) < 1e-4 * max(1.0, abs(float(v))), k
+    grads, ref = tr.gradients(), setup["grads64"]
+    num = den = 0.0
+    for k, g in ref.items():
+        e = grads[k].double() - g
+        num += float((e * e).sum())
+        den += float((g.double() ** 2).sum())
+    assert (num / den) ** 0.5 < 1.2e-2, (num / den) ** 0.5
+    # The heads' gradients: 1e-4 in fp32; here the images differ by ~1e-4 from float64's, which flips the sign of the L1
+    # terms' gradient at the handful of pixels where |fake - real| is that small (measured 7e-3 on the colour head, 6e-3
+    # on the mask head, which sees the same signs through the blend).
+    for k in ("tsf_model.img_reg.0.weight", "tsf_model.attetion_reg.0.weight", "src_model.img_reg.0.weight", "bg_model.model.27.weight"):
+        assert _rel(grads[k].double(), ref[k]) < 3e-2, k
+
+
 def test_every_parameter_gradient(setup):
     tr = setup["tr"]
     tr.forward(setup["batch"])

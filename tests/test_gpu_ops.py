@@ -21,6 +21,40 @@ def _rel(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c[1] % 32 == 0], ids=[c[0] for c in CASES if c[1] % 32 == 0])
+def test_conv_bf16x3_route(case):
+    """lwg_conv2d_desc.precision = 1: forward and data gradient on the inference path's split-bf16 kernel (operands
+    carried to 16 significand bits, fp32 accumulation)."""
+    from impersonator_amd import ops
+    _, cin, cout, k, stride, pad, transposed, H = case
+    if H * H % 128:
+        H = 32        # the bf16x3 kernel wants whole 128-pixel tiles per image (else the call takes the fp32 kernel)
+    g = torch.Generator().manual_seed(9)
+    N = 3
+    x = torch.randn(N, cin, H, H, generator=g)
+    w = torch.randn((cin, cout, k, k) if transposed else (cout, cin, k, k), generator=g) * 0.05
+    xr = x.clone().double().requires_grad_(True)
+    y = (F.conv_transpose2d(xr, w.double(), stride=2, padding=1, output_padding=1) if transposed
+         else F.conv2d(xr, w.double(), None, stride=stride, padding=pad))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    xg, dyg, wg = nhwc(x), nhwc(dy), w.cuda().contiguous()
+    y32 = ops.conv2d_forward(xg, wg, None, stride, pad, transposed)
+    y16 = ops.conv2d_forward(xg, wg, None, stride, pad, transposed, precision="bf16x3")
+    assert not torch.equal(y16, y32), "the bf16x3 route did not run"
+    assert _rel(y16.cpu().permute(0, 3, 1, 2).double(), y.detach()) < 3e-5
+    dx32 = ops.conv2d_backward_data(dyg, wg, tuple(xg.shape), stride, pad, transposed)
+    dx16 = ops.conv2d_backward_data(dyg, wg, tuple(xg.shape), stride, pad, transposed, precision="bf16x3")
+    assert not torch.equal(dx16, dx32), "the bf16x3 route did not run"
+    assert _rel(dx16.cpu().permute(0, 3, 1, 2).double(), xr.grad) < 3e-5
+    # a layer the kernel does not fit (bias) takes the fp32 kernel: same bits as precision 0
+    if not transposed:
+        b = torch.randn(cout, generator=g).cuda()
+        assert torch.equal(ops.conv2d_forward(xg, wg, b, stride, pad, transposed, precision="bf16x3"),
+                           ops.conv2d_forward(xg, wg, b, stride, pad, transposed))
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_forward_and_gradients(case):
     from impersonator_amd import ops
@@ -52,6 +86,37 @@ def test_conv_forward_and_gradients(case):
     if cin >= 64:   # the gradient wrt an 8-channel image input is never needed
         dx = ops.conv2d_backward_data(dyg, wg, tuple(xg.shape), stride, pad, transposed)
         assert _rel(dx.cpu().permute(0, 3, 1, 2), xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (24, 40), (9, 33)])
+def test_heads_ops(H, W):
+    """The regression heads' own kernels (lwg_heads_forward / lwg_heads_backward_weight, data gradient through
+    lwg_conv2d_backward_data with Cout = 8) against autograd of conv2d + tanh / sigmoid."""
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(13)
+    N = 3
+    x = torch.rand(N, 64, H, W, generator=g)                      # post-ReLU activations: non-negative
+    w = torch.zeros(8, 64, 7, 7)
+    w[:4] = torch.randn(4, 64, 7, 7, generator=g) * 0.03
+    xr, wr = x.clone().double().requires_grad_(True), w[:4].clone().double().requires_grad_(True)
+    pre = F.conv2d(xr, wr, None, stride=1, padding=3)
+    img, mask = torch.tanh(pre[:, 0:3]), torch.sigmoid(pre[:, 3:4])
+    d_img, d_mask = torch.randn(img.shape, generator=g).double(), torch.randn(mask.shape, generator=g).double()
+    (img * d_img).sum().add((mask * d_mask).sum()).backward()
+    d_pre = torch.cat([d_img * (1 - img * img), d_mask * mask * (1 - mask)], dim=1).detach()
+
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().float().cuda()
+    xg, wg = nhwc(x), w.cuda()
+    color, m = ops.heads_forward(xg, wg)
+    assert float((color.cpu().double() - img.detach()).abs().max()) < 1e-5     # fp32 sums of 3136 products
+    assert float((m.cpu().double() - mask.detach()).abs().max()) < 1e-5
+    d8 = torch.zeros(N, H, W, 8, device="cuda")
+    d8[..., :4] = nhwc(d_pre)
+    dw = ops.heads_backward_weight(xg, d8)
+    assert _rel(dw[:4].cpu().double(), wr.grad) < 2e-5
+    assert float(dw[4:].abs().max()) == 0.0
+    dx = ops.conv2d_backward_data(d8, wg, tuple(xg.shape), 1, 3)
+    assert _rel(dx.cpu().permute(0, 3, 1, 2).double(), xr.grad) < 1e-5
 
 
 def test_unsupported_shapes_fail_loudly():

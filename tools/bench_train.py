@@ -20,9 +20,11 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="forward / data-gradient convolutions of the generator update")
     a = ap.parse_args()
     opt = types.SimpleNamespace(image_size=a.image_size, batch_size=a.batch, map_name='uv_seg', norm_type='instance',
-                                repeat_num=6, is_train=True)
+                                repeat_num=6, is_train=True, conv_precision=a.precision)
     model = Impersonator(opt)
     model._G.init_weights()
     model._D.init_weights()
@@ -41,7 +43,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps({"metric": "training iteration (G update + D update)", "ms_per_iteration": round(dt * 1e3, 2),
                       "note": "BASELINE.json config 5 is --image-size 512 (--batch 1..4 per GPU)",
-                      "images_per_s": round(n / dt, 2), "batch": n, "image_size": s, "dtype": "f32", "losses": losses}))
+                      "images_per_s": round(n / dt, 2), "batch": n, "image_size": s, "dtype": "f32" if a.precision == "fp32" else "bf16x3 convs (forward, data gradient) + f32", "losses": losses}))
 
 
 if __name__ == "__main__":
