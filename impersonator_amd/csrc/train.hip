@@ -285,10 +285,198 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dy
     }
 }
 
+// ---- the same on the bf16 matrix cores (bf16x3: operands carried as hi + lo bf16, products lo*hi + hi*lo + hi*hi with
+// fp32 accumulation, conv.h).  v_mfma_f32_32x32x16_bf16 wants 8 consecutive reduction entries -- pixels -- per lane,
+// the tensors are channel-contiguous; the transposition happens in registers on the way to LDS: a loader thread
+// fetches one channel quad of PXT consecutive pixels (PXT float4 loads, coalesced across the wave's 32 quads), splits
+// the values and writes, per channel, the PXT pixels' hi terms and lo terms as one 16-byte (8-byte) LDS store.  The LDS
+// image of an operand tile is the inference kernel's: row = channel, 128 bytes = [hi: k 0-7 | 8-15 | 16-23 | 24-31 | lo ...],
+// 16-byte slots XOR-swizzled by the row so that fragment reads (32 rows x one slot) and loader writes (rows 4 apart)
+// spread over the banks.  Tile, grid, split-K slices and epilogue as wgrad_kernel.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4w_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int wg_swz(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
+
+template <int T>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const float *__restrict__ dy, int Cout, const float *__restrict__ x,
+                                                           int Cin, int N, int H, int W, int Ho, int Wo, int stride, int pad,
+                                                           long px_per_slice, float *__restrict__ out, int KWd, int ntaps, int oihw)
+{
+    constexpr int TW = T / 64, PXT = T / 16, QN = T / 4;   // tiles per wave and side; pixels per loader item; channel quads
+    constexpr int OPB = T * 128;                           // bytes of one operand tile (T rows x 32 pixels x (hi, lo))
+    extern __shared__ __attribute__((aligned(16))) char wsb[];   // [2 buffers][2 operands][T][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ci0 = blockIdx.x * T, co0 = blockIdx.y * T;
+    const int tap = blockIdx.z % ntaps, slice = blockIdx.z / ntaps;
+    const int kh = tap / KWd, kw = tap - kh * KWd;
+    const long P = (long)N * Ho * Wo;
+    const long p0 = slice * px_per_slice, p1 = p0 + px_per_slice < P ? p0 + px_per_slice : P;
+
+    // loader item: operand (waves 0-1: dY, waves 2-3: X), channel quad q, pixel block blk of the 32-pixel step.  Both
+    // operands run the same code: dY is "a conv operand with one tap, stride 1, no padding".  The item's first pixel
+    // (pl -> image ln, output position loh, low) walks ahead of the MFMAs by two steps; element offsets are 32-bit.
+    const int op = tid >> 7, idx = tid & 127, q = idx % QN, blk = idx / QN;
+    const float *lbase = op ? x : dy;
+    const unsigned lC = op ? (unsigned)Cin : (unsigned)Cout, lcoff = (op ? ci0 : co0) + 4 * q;
+    const int ls = op ? stride : 1, ldh = op ? kh - pad : 0, ldw = op ? kw - pad : 0;
+    const int lH = op ? H : Ho, lW = op ? W : Wo;
+    const bool lchan = lcoff < lC;
+    const unsigned lsC = (unsigned)ls * lC;
+    long pl = p0 + blk * PXT;
+    int ln = (int)(pl / ((long)Ho * Wo));
+    int loh, low;
+    {
+        const int rem = (int)(pl - (long)ln * Ho * Wo);
+        loh = rem / Wo;
+        low = rem - loh * Wo;
+    }
+    auto load = [&](float4 (&r)[PXT]) {
+        int tn = ln, toh = loh, tow = low;
+        int ih = toh * ls + ldh, iw = tow * ls + ldw;
+        unsigned off = ((unsigned)(tn * lH + ih) * (unsigned)lW + (unsigned)iw) * lC + lcoff;
+#pragma unroll
+        for (int i = 0; i < PXT; ++i) {
+            const bool ok = lchan && pl + i < p1 && (unsigned)ih < (unsigned)lH && (unsigned)iw < (unsigned)lW;
+            const float4 v = ld4(lbase + (ok ? off : 0u));
+            r[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            ++tow;
+            iw += ls;
+            off += lsC;
+            if (tow == Wo) {
+                tow = 0;
+                iw = ldw;
+                ++toh;
+                ih += ls;
+                if (toh == Ho) {
+                    toh = 0;
+                    ih = ldh;
+                    ++tn;
+                }
+                off = ((unsigned)(tn * lH + ih) * (unsigned)lW + (unsigned)iw) * lC + lcoff;
+            }
+        }
+        pl += WG_PX;
+        low += WG_PX;
+        while (low >= Wo) {
+            low -= Wo;
+            if (++loh == Ho) {
+                loh = 0;
+                ++ln;
+            }
+        }
+    };
+    auto store = [&](const float4 (&r)[PXT], int buf) {
+        char *base = wsb + (buf * 2 + op) * OPB;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int row = 4 * q + ch, sw = wg_swz(row);
+            __bf16 h[PXT], l[PXT];
+#pragma unroll
+            for (int i = 0; i < PXT; ++i) {
+                const float v = ch == 0 ? r[i].x : ch == 1 ? r[i].y : ch == 2 ? r[i].z : r[i].w;
+                h[i] = (__bf16)v;
+                l[i] = (__bf16)(v - (float)h[i]);
+            }
+            if constexpr (PXT == 8) {
+                bf16x8_t hv, lv;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { hv[i] = h[i]; lv[i] = l[i]; }
+                *reinterpret_cast<bf16x8_t *>(base + row * 128 + ((blk ^ sw) * 16)) = hv;
+                *reinterpret_cast<bf16x8_t *>(base + row * 128 + (((4 + blk) ^ sw) * 16)) = lv;
+            } else {
+                bf16x4w_t hv, lv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { hv[i] = h[i]; lv[i] = l[i]; }
+                *reinterpret_cast<bf16x4w_t *>(base + row * 128 + (((blk >> 1) ^ sw) * 16) + (blk & 1) * 8) = hv;
+                *reinterpret_cast<bf16x4w_t *>(base + row * 128 + (((4 + (blk >> 1)) ^ sw) * 16) + (blk & 1) * 8) = lv;
+            }
+        }
+    };
+    f32x16 acc[TW][TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) acc[i][j][r2] = 0.f;
+    // fragment rows of this lane and their swizzles
+    int arow[TW], brow[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        arow[i] = (wm * TW + i) * 32 + (lane & 31);
+        brow[i] = (wn * TW + i) * 32 + (lane & 31);
+    }
+    auto frag = [&](int buf, int opi, int row, int col) {
+        return *reinterpret_cast<const bf16x8_t *>(wsb + (buf * 2 + opi) * OPB + row * 128 + ((col ^ wg_swz(row)) * 16));
+    };
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int ch = 2 * kb + (lane >> 5);
+            bf16x8_t ah[TW], al[TW], bh[TW], bl[TW];
+#pragma unroll
+            for (int i = 0; i < TW; ++i) {
+                ah[i] = frag(buf, 0, arow[i], ch);
+                al[i] = frag(buf, 0, arow[i], 4 + ch);
+                bh[i] = frag(buf, 1, brow[i], ch);
+                bl[i] = frag(buf, 1, brow[i], 4 + ch);
+            }
+            // small terms first; tiles inside a product, so consecutive MFMAs do not share an accumulator
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // step k multiplies LDS buffer k&1 while the loads of step k+2 fly into one register set and step k+1, already
+    // in the other, is split and written to the other buffer behind the MFMAs
+    const int K = (int)((p1 - p0 + WG_PX - 1) / WG_PX);
+    float4 r0[PXT], r1[PXT];
+    if (K > 0) {
+        load(r0);
+        store(r0, 0);
+        if (K > 1) load(r1);
+    }
+    __syncthreads();
+    auto step = [&](float4 (&rload)[PXT], const float4 (&rnext)[PXT], int k) {
+        if (k + 2 < K) load(rload);
+        compute(k & 1);
+        if (k + 1 < K) store(rnext, (k + 1) & 1);
+        __syncthreads();
+    };
+    for (int k = 0; k < K; k += 2) {
+        step(r0, r1, k);
+        if (k + 1 < K) step(r1, r0, k + 1);
+    }
+    float *o = out + (size_t)slice * Cout * ntaps * Cin;
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+        const int ci = ci0 + (wn * TW + j) * 32 + (lane & 31);
+        if (ci >= Cin) continue;
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                const int co = co0 + (wm * TW + i) * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * (lane >> 5);
+                if (co < Cout) o[oihw ? ((size_t)co * Cin + ci) * ntaps + tap : ((size_t)co * ntaps + tap) * Cin + ci] = acc[i][j][r2];
+            }
+    }
+}
+
 // launcher: picks the tile, the pixel slices (split-K) and the partial buffer.  `part` must hold 32 * Cout*ntaps*Cin floats
 // (at most 32 slices); the result lands in `out`.
 int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin, int Win, int Hg, int Wg, int stride, int pad,
-                 int KWd, int ntaps, int oihw, float *out, float *part, size_t part_floats, hipStream_t st)
+                 int KWd, int ntaps, int oihw, float *out, float *part, size_t part_floats, hipStream_t st, int precision = 0)
 {
     const long P = (long)N * Hg * Wg;
     const size_t w_floats = (size_t)O * ntaps * I;
@@ -313,6 +501,26 @@ int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin,
     if (S > 1 && (size_t)S * w_floats > part_floats) LWG_FAIL(LWG_ERR_STATE, "wgrad: partial buffer too small");
     float *wout = S == 1 ? out : part;
     const dim3 grid(ceil_div(I, T), O / T, (unsigned)(ntaps * S));
+    if (precision == 1) {
+        const size_t lds16 = (size_t)4 * T * 128;
+        if (T == 128) {
+            static DeviceOnce opt_in16;
+            if (!opt_in16.done()) {
+                LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16x3_kernel<128>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+                opt_in16.mark();
+            }
+            wgrad_bf16x3_kernel<128><<<grid, 256, lds16, st>>>(go, O, in, I, N, Hin, Win, Hg, Wg, stride, pad, per, wout, KWd, ntaps, oihw);
+        } else {
+            wgrad_bf16x3_kernel<64><<<grid, 256, lds16, st>>>(go, O, in, I, N, Hin, Win, Hg, Wg, stride, pad, per, wout, KWd, ntaps, oihw);
+        }
+        LWG_LAUNCH_CHECK("wgrad_bf16x3_kernel");
+        if (S > 1) {
+            reduce_slices_kernel<<<ceil_div((long)w_floats, 256), 256, 0, st>>>(part, (int)S, (long)w_floats, out);
+            LWG_LAUNCH_CHECK("reduce_slices_kernel");
+        }
+        return LWG_OK;
+    }
     const size_t lds = (size_t)4 * WG_PX * (T + 4) * sizeof(float);
     if (T == 128) {
         static DeviceOnce opt_in;
@@ -1322,7 +1530,7 @@ int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x, const f
     const int stride = d->transposed ? 2 : d->stride, pad = d->pad, taps = d->k * d->k;
     if (O % 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_weight: needs a multiple of 64 channels on the gradient side, got %d", O);
     const long P = (long)d->N * Hg * Wg;
-    if ((rc = launch_wgrad(go, O, in, I, d->N, Hin, Win, Hg, Wg, stride, pad, d->k, taps, 1, dw, part, wgrad_part_floats(g), st)) != LWG_OK) return rc;
+    if ((rc = launch_wgrad(go, O, in, I, d->N, Hin, Win, Hg, Wg, stride, pad, d->k, taps, 1, dw, part, wgrad_part_floats(g), st, d->precision)) != LWG_OK) return rc;
     if (dbias) {
         if (d->transposed) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_weight: bias gradient of a transposed conv");
         float *cs = part + wgrad_part_floats(g);

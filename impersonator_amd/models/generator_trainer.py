@@ -47,7 +47,8 @@ class _ConvIN(object):
         draw, dg, db = ops.instance_norm_backward(self.raw, self.y if self.relu else None, dy.contiguous(), self.stats, P[self.gkey])
         G[self.gkey].add_(dg)
         G[self.bkey].add_(db)
-        G[self.wkey].add_(ops.conv2d_backward_weight(self.x, draw, tuple(P[self.wkey].shape), self.stride, self.pad, self.transposed))
+        G[self.wkey].add_(ops.conv2d_backward_weight(self.x, draw, tuple(P[self.wkey].shape), self.stride, self.pad, self.transposed,
+                                                      precision=self.tr.conv_precision))
         if not need_dx:
             return None
         return ops.conv2d_backward_data(draw, P[self.wkey], tuple(self.x.shape), self.stride, self.pad, self.transposed,
@@ -138,8 +139,8 @@ class GeneratorTrainer(object):
 
     def __init__(self, generator, discriminator, lambda_D_prob=1.0, lambda_rec=10.0, lambda_tsf=10.0, lambda_mask=0.1,
                  lambda_mask_smooth=1e-5, lr=0.0002, betas=(0.5, 0.999), eps=1e-8, conv_precision="fp32"):
-        """conv_precision 'bf16x3': the forward and data-gradient convolutions of the three streams run the inference
-        path's split-bf16 kernel (include/lwg.h, lwg_conv2d_desc.precision); weight gradients, norms, heads, Adam: fp32."""
+        """conv_precision 'bf16x3': the convolutions of the three streams (forward, data gradient, weight gradient) run on
+        split-bf16 operands (include/lwg.h, lwg_conv2d_desc.precision); norms, heads, losses, Adam: fp32."""
         if conv_precision not in ops.PRECISIONS:
             raise ValueError("conv_precision must be one of %s" % sorted(ops.PRECISIONS))
         self.conv_precision = conv_precision

@@ -67,11 +67,11 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, transposed=False, prec
 
 
 @torch.no_grad()
-def conv2d_backward_weight(x, dy, w_shape, stride=1, pad=0, transposed=False, with_bias=False):
+def conv2d_backward_weight(x, dy, w_shape, stride=1, pad=0, transposed=False, with_bias=False, precision="fp32"):
     """Gradient wrt the weight (PyTorch layout `w_shape`) and, optionally, the bias."""
     _chk(x, dy)
     cin, cout = (w_shape[0], w_shape[1]) if transposed else (w_shape[1], w_shape[0])
-    d = _desc(x.shape, cin, cout, w_shape[2], stride, pad, transposed)
+    d = _desc(x.shape, cin, cout, w_shape[2], stride, pad, transposed, precision)
     dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
     db = torch.empty(cout, device=x.device, dtype=torch.float32) if with_bias else None
     ws, nb = _ws(d, x.device)

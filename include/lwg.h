@@ -255,10 +255,10 @@ LWG_API int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float be
  * the side that becomes the GEMM's N dimension a multiple of 64 (Cout for forward, Cin for backward_data; for
  * backward_weight Cout, or Cin when transposed).  stride 1: any k <= 7 with 'same' padding for backward_data;
  * stride 2: k3 p1 on even sizes.  workspace: lwg_conv2d_workspace_bytes, scratch only (nothing persists).
- * precision 0: fp32 MFMA.  precision 1: forward and backward_data run the inference path's bf16x3 kernel (operands
- * carried as two bf16 terms, three MFMA products, fp32 accumulation: ~2^-16 relative per operand) wherever the layer
- * fits it -- no bias, reduction-side channels a multiple of 32, output grid per image a multiple of 128 pixels, at most
- * 32 taps -- and the fp32 kernel elsewhere; backward_weight is fp32 either way. */
+ * precision 0: fp32 MFMA.  precision 1 (bf16x3: operands carried as two bf16 terms, three MFMA products, fp32
+ * accumulation: ~2^-16 relative per operand): forward and backward_data run the inference path's kernel wherever the
+ * layer fits it -- no bias, reduction-side channels a multiple of 32, output grid per image a multiple of 128 pixels, at
+ * most 32 taps -- and the fp32 kernel elsewhere; backward_weight runs its own bf16x3 kernel on every layer. */
 typedef struct lwg_conv2d_desc {
     int N, H, W, Cin, Cout, k, stride, pad, transposed;
     int precision;

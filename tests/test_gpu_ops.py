@@ -55,6 +55,29 @@ def test_conv_bf16x3_route(case):
                            ops.conv2d_forward(xg, wg, b, stride, pad, transposed))
 
 
+@pytest.mark.parametrize("N", [3, 1])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_weight_gradient_bf16x3(case, N):
+    """lwg_conv2d_backward_weight with precision 1: its own bf16x3 kernel (pixels transposed in registers on the way to
+    LDS), every layer shape incl. the 8-channel stem, stride 2 and the transposed conv."""
+    from impersonator_amd import ops
+    _, cin, cout, k, stride, pad, transposed, H = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, cin, H, H, generator=g)
+    w = torch.randn((cin, cout, k, k) if transposed else (cout, cin, k, k), generator=g) * 0.05
+    wr = w.clone().double().requires_grad_(True)
+    y = (F.conv_transpose2d(x.double(), wr, stride=2, padding=1, output_padding=1) if transposed
+         else F.conv2d(x.double(), wr, None, stride=stride, padding=pad))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    xg, dyg = nhwc(x), nhwc(dy)
+    dw32 = ops.conv2d_backward_weight(xg, dyg, tuple(w.shape), stride, pad, transposed)
+    dw16 = ops.conv2d_backward_weight(xg, dyg, tuple(w.shape), stride, pad, transposed, precision="bf16x3")
+    assert not torch.equal(dw16, dw32), "the bf16x3 kernel did not run"
+    assert _rel(dw16.cpu().double(), wr.grad) < 3e-5
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_forward_and_gradients(case):
     from impersonator_amd import ops
