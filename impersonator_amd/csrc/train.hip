@@ -739,19 +739,87 @@ __global__ __launch_bounds__(256) void in_affine_bwd_partial_kernel(const float 
         o[1] = s2;
     }
 }
+// The same sums for C % 64 == 0 (every layer of the generator): a thread owns four channels (float4 loads: a pixel row of
+// the workgroup is 256 contiguous bytes, not 64) and every sixteenth pixel of slab sb, four pixels in flight.
+constexpr int RS4_CH = 64;
+__global__ __launch_bounds__(256) void in_affine_bwd_sums4_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                  const float *__restrict__ dy, const float2 *__restrict__ stats,
+                                                                  int HW, int C, int S, double *__restrict__ part)
+{
+    __shared__ double sh[2][RS_SL][RS4_CH];
+    const int cq = threadIdx.x & 15, c = blockIdx.x * RS4_CH + 4 * cq, slice = threadIdx.x >> 4, n = blockIdx.y, sb = blockIdx.z;
+    const int per = (HW + S - 1) / S, p0 = sb * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const size_t base = (size_t)n * HW * C + c;
+    const float4 sa = ld4(reinterpret_cast<const float *>(stats + (size_t)n * C + c));       // (mean, rstd) of c, c+1
+    const float4 sb4 = ld4(reinterpret_cast<const float *>(stats + (size_t)n * C + c + 2));  // c+2, c+3
+    const float mean[4] = {sa.x, sa.z, sb4.x, sb4.z}, rstd[4] = {sa.y, sa.w, sb4.y, sb4.w};
+    double s1[4] = {0., 0., 0., 0.}, s2[4] = {0., 0., 0., 0.};
+    auto add = [&](const float4 xv, const float4 yv, const float4 gv) {
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = (y && !(ys[k] > 0.f)) ? 0.f : gs[k];
+            s1[k] += g;
+            s2[k] += (double)g * ((xs[k] - mean[k]) * rstd[k]);
+        }
+    };
+    int i = p0 + slice;
+    for (; i + 3 * RS_SL < p1; i += 4 * RS_SL) {
+        float4 xv[4], yv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = base + (size_t)(i + u * RS_SL) * C;
+            xv[u] = ld4(x + o);
+            yv[u] = y ? ld4(y + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+            gv[u] = ld4(dy + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(xv[u], yv[u], gv[u]);
+    }
+    for (; i < p1; i += RS_SL) {
+        const size_t o = base + (size_t)i * C;
+        add(ld4(x + o), y ? ld4(y + o) : make_float4(1.f, 1.f, 1.f, 1.f), ld4(dy + o));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sh[0][slice][4 * cq + k] = s1[k];
+        sh[1][slice][4 * cq + k] = s2[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < RS4_CH) {
+        const int cl = threadIdx.x;
+        double a = 0., b = 0.;
+        for (int k = 0; k < RS_SL; ++k) {
+            a += sh[0][k][cl];
+            b += sh[1][k][cl];
+        }
+        double *o = part + (((size_t)n * S + sb) * C + blockIdx.x * RS4_CH + cl) * 2;
+        o[0] = a;
+        o[1] = b;
+    }
+}
+// grid ceil(N*C / 64): 64 (image, channel) pairs per workgroup, four threads per pair each summing every fourth slab
 __global__ __launch_bounds__(256) void in_sums_final_kernel(const double *__restrict__ part, int N, int C, int S,
                                                             float2 *__restrict__ sums)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i - n * C;
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;
     double s1 = 0., s2 = 0.;
-    for (int k = 0; k < S; ++k) {
-        const double *o = part + (((size_t)n * S + k) * C + c) * 2;
-        s1 += o[0];
-        s2 += o[1];
+    if (i < N * C) {
+        const int n = i / C, c = i - n * C;
+        for (int k = grp; k < S; k += 4) {
+            const double *o = part + (((size_t)n * S + k) * C + c) * 2;
+            s1 += o[0];
+            s2 += o[1];
+        }
     }
-    sums[i] = make_float2((float)s1, (float)s2);
+    sh[0][grp][cl] = s1;
+    sh[1][grp][cl] = s2;
+    __syncthreads();
+    if (grp == 0 && i < N * C)
+        sums[i] = make_float2((float)(sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl]),
+                              (float)(sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl]));
 }
 inline int in_slabs(int N, int C, int HW)
 {
@@ -759,6 +827,15 @@ inline int in_slabs(int N, int C, int HW)
     long S = 1024 / ((long)(C / RS_CH) * N);
     if (S > HW / 1024) S = HW / 1024;
     if (S > 64) S = 64;
+    return S < 1 ? 1 : (int)S;
+}
+
+// slabs of in_affine_bwd_sums4_kernel: ~4096 workgroups, at least 256 pixels each, at most 256 slabs
+inline int in_bwd_slabs4(int N, int C, int HW)
+{
+    long S = 4096 / ((long)(C / RS4_CH) * N);
+    if (S > HW / 256) S = HW / 256;
+    if (S > 256) S = 256;
     return S < 1 ? 1 : (int)S;
 }
 
@@ -824,17 +901,28 @@ __global__ __launch_bounds__(256) void grid_sample_bwd_kernel(const float *__res
 // mode 2: "transposed-conv forward" phase matrices from a tensor laid out (A, B, 3, 3): dst phase (py,px), [b][t][a]
 //         = w[a][b][ky][kx], ky = py ? (ty ? 0 : 2) : 1 (generator.hip upload_convT).  Serves ConvTranspose2d forward
 //         (A = Cin, B = Cout) and the data gradient of Conv2d(k3,s2,p1) (its OIHW tensor read as A = Cout, B = Cin).
+// split = 1: the matrix is written in the split-bf16 format of conv.h ([hi x32 | lo x32] per 32 entries, same offsets)
 __global__ __launch_bounds__(256) void weight_layout_kernel(const float *__restrict__ w, float *__restrict__ dst, int mode,
-                                                            int A, int B, int taps, long total, int pitch)
+                                                            int A, int B, int taps, long total, int pitch, int split)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    auto put = [&](size_t d, float v) {
+        if (!split) {
+            dst[d] = v;
+            return;
+        }
+        __bf16 *o = reinterpret_cast<__bf16 *>(dst) + (d >> 5) * 64 + (d & 31);
+        const __bf16 hi = (__bf16)v;
+        o[0] = hi;
+        o[32] = (__bf16)(v - (float)hi);
+    };
     if (mode == 0) {          // A = Cout, B = Cin: dst[a*pitch + t*B + b]
         const int b = (int)(i % B), t = (int)((i / B) % taps), a = (int)(i / ((long)B * taps));
-        dst[(size_t)a * pitch + (size_t)t * B + b] = w[((size_t)a * B + b) * taps + t];
+        put((size_t)a * pitch + (size_t)t * B + b, w[((size_t)a * B + b) * taps + t]);
     } else if (mode == 1) {   // A = Cout, B = Cin: dst[b*pitch + t*A + a]
         const int a = (int)(i % A), t = (int)((i / A) % taps), b = (int)(i / ((long)A * taps));
-        dst[(size_t)b * pitch + (size_t)t * A + a] = w[((size_t)a * B + b) * taps + (taps - 1 - t)];
+        put((size_t)b * pitch + (size_t)t * A + a, w[((size_t)a * B + b) * taps + (taps - 1 - t)]);
     } else {                  // four phases with 1, 2, 2, 4 taps, rows of B outputs x (t, a)
         long j = i;
         int phase = 0, nt = 1;
@@ -848,7 +936,7 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float *__restr
         const int a = (int)(j % A), t = (int)((j / A) % nt), b = (int)(j / ((long)A * nt));
         const int ty = t / KWp, tx = t - ty * KWp;
         const int ky = py == 0 ? 1 : (ty == 0 ? 2 : 0), kx = px == 0 ? 1 : (tx == 0 ? 2 : 0);
-        dst[i] = w[(((size_t)a * B + b) * 3 + ky) * 3 + kx];
+        put((size_t)i, w[(((size_t)a * B + b) * 3 + ky) * 3 + kx]);
     }
 }
 
@@ -1332,12 +1420,11 @@ bool split_route_ok(int precision, int Cin, int Hm, int Wm, int taps, const floa
 }
 
 // operand + weights -> split copies; fills in the ConvArgs fields of the bf16x3 route
-int to_split_route(ConvArgs &a, const float *x, size_t x_floats, const float *wmat, size_t w_floats, const SplitWs &sw,
-                   hipStream_t st)
+// (the weight matrices were written split, into sw.w, by relayout)
+int to_split_route(ConvArgs &a, const float *x, size_t x_floats, const SplitWs &sw, hipStream_t st)
 {
     int rc;
     if ((rc = split_pack(x, sw.x, x_floats, st)) != LWG_OK) return rc;
-    if ((rc = split_pack(wmat, sw.w, w_floats, st)) != LWG_OK) return rc;
     LWG_HIP(hipMemsetAsync(sw.zeros, 0, sw.zero_floats * sizeof(float), st));
     a.x = sw.x;
     a.w_split = sw.w;
@@ -1362,10 +1449,14 @@ int op_conv(const float *x, int N, int H, int W, int Cin, const float *wmat, con
     a.nphase = 1;
     a.ph[0] = ConvPhase{k, k, k * k, (int)align_up((size_t)k * k * Cin, kConvBK), 0, 0, 0, 0, 0};   // wmat rows have this pitch
     a.mtiles = ceil_div((long)N * a.Hm * a.Wm, kConvBM);
-    if (sw && split_route_ok(precision, Cin, a.Hm, a.Wm, k * k, bias)) {
-        const int rc = to_split_route(a, x, (size_t)N * H * W * Cin, wmat, (size_t)Cout * a.ph[0].Kpad, *sw, st);
+    if (sw) {   // the caller checked split_route_ok and had the weights written split
+        if (!split_route_ok(precision, Cin, a.Hm, a.Wm, k * k, bias) || wmat != sw->w) LWG_FAIL(LWG_ERR_STATE, "conv2d: bf16x3 route misuse");
+        const int rc = to_split_route(a, x, (size_t)N * H * W * Cin, *sw, st);
         if (rc != LWG_OK) return rc;
-        return launch_conv_igemm(a, Cout % 128 == 0 ? 128 : 64, st);
+        // 128-channel tiles once they still give every CU a workgroup, else twice as many 64-channel ones (the 32x32
+        // trunk at batch 4 is 128 tiles of 128)
+        const bool wide = Cout % 128 == 0 && (long)a.mtiles * (Cout / 128) >= device_cu_count();
+        return launch_conv_igemm(a, wide ? 128 : 64, st);
     }
     return launch_conv_igemm(a, (Cout % 128 == 0 && Cin >= kConvBK) ? 128 : 64, st);
 }
@@ -1387,8 +1478,9 @@ int op_convT(const float *x, int N, int H, int W, int Cin, const float *wph, int
         off += (long)Cout * nt * Cin;
     }
     a.mtiles = ceil_div((long)N * H * W, kConvBM);
-    if (sw && split_route_ok(precision, Cin, H, W, 4, nullptr)) {
-        const int rc = to_split_route(a, x, (size_t)N * H * W * Cin, wph, (size_t)off, *sw, st);
+    if (sw) {
+        if (!split_route_ok(precision, Cin, H, W, 4, nullptr) || wph != sw->w) LWG_FAIL(LWG_ERR_STATE, "conv2d: bf16x3 route misuse");
+        const int rc = to_split_route(a, x, (size_t)N * H * W * Cin, *sw, st);
         if (rc != LWG_OK) return rc;
         a.fuse_phases = 0;
         return launch_conv_igemm(a, Cout % 128 == 0 ? 128 : 64, st);
@@ -1398,11 +1490,13 @@ int op_convT(const float *x, int N, int H, int W, int Cin, const float *wph, int
 
 // `pitch` (floats, 0 = dense): row pitch of the matrix -- rows are output channels: A of them with taps*B entries in
 // mode 0, B of them with taps*A entries in mode 1
-int relayout(const float *w, float *dst, int mode, int A, int B, int taps, long total, hipStream_t st, int pitch = 0)
+int relayout(const float *w, float *dst, int mode, int A, int B, int taps, long total, hipStream_t st, int pitch = 0,
+             bool split = false)
 {
     const int rows = mode == 1 ? B : A, dense = taps * (mode == 1 ? A : B);
+    if (split && pitch && pitch != dense) LWG_FAIL(LWG_ERR_STATE, "relayout: split matrices have no row padding");
     if (pitch && pitch != dense) LWG_HIP(hipMemsetAsync(dst, 0, (size_t)rows * pitch * sizeof(float), st));
-    weight_layout_kernel<<<ceil_div(total, 256), 256, 0, st>>>(w, dst, mode, A, B, taps, total, pitch ? pitch : dense);
+    weight_layout_kernel<<<ceil_div(total, 256), 256, 0, st>>>(w, dst, mode, A, B, taps, total, pitch ? pitch : dense, split ? 1 : 0);
     LWG_LAUNCH_CHECK("weight_layout_kernel");
     return LWG_OK;
 }
@@ -1468,15 +1562,18 @@ int lwg_conv2d_forward(const lwg_conv2d_desc *d, const float *x, const float *w,
     if (ws_bytes < lwg_conv2d_workspace_bytes(d)) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv2d_forward: workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *wm = static_cast<float *>(ws);
+    // bf16x3 route: the weight matrices are written split straight away, into the split part of the workspace
     SplitWs sw_, *sw = nullptr;
-    if (d->precision == 1) { sw_ = carve_split(d, g, ws); sw = &sw_; }
+    const bool split = d->transposed ? split_route_ok(d->precision, d->Cin, d->H, d->W, 4, nullptr)
+                                     : split_route_ok(d->precision, d->Cin, g.Ho, g.Wo, d->k * d->k, bias);
+    if (split) { sw_ = carve_split(d, g, ws); sw = &sw_; wm = sw_.w; }
     if (d->transposed) {
         if (bias) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_forward: bias on a transposed conv");
-        if ((rc = relayout(w, wm, 2, d->Cin, d->Cout, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
+        if ((rc = relayout(w, wm, 2, d->Cin, d->Cout, 9, (long)g.w_floats, st, 0, split)) != LWG_OK) return rc;
         return op_convT(x, d->N, d->H, d->W, d->Cin, wm, d->Cout, y, st, d->precision, sw);
     }
     const int pitch = (int)align_up((size_t)d->k * d->k * d->Cin, kConvBK);   // 7x7x8 = 392 -> 416
-    if ((rc = relayout(w, wm, 0, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st, pitch)) != LWG_OK) return rc;
+    if ((rc = relayout(w, wm, 0, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st, pitch, split)) != LWG_OK) return rc;
     return op_conv(x, d->N, d->H, d->W, d->Cin, wm, bias, d->Cout, d->k, d->stride, d->pad, y, st, d->precision, sw);
 }
 
@@ -1490,24 +1587,28 @@ int lwg_conv2d_backward_data(const lwg_conv2d_desc *d, const float *dy, const fl
     if (ws_bytes < lwg_conv2d_workspace_bytes(d)) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv2d_backward_data: workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *wm = static_cast<float *>(ws);
+    // the conv that computes dx: its reduction side is Cout, its output grid the input's (the phase grid for stride 2)
     SplitWs sw_, *sw = nullptr;
-    if (d->precision == 1) { sw_ = carve_split(d, g, ws); sw = &sw_; }
+    const bool via_convT = !d->transposed && d->stride == 2;
+    const bool split = via_convT ? split_route_ok(d->precision, d->Cout, g.Ho, g.Wo, 4, nullptr)
+                                 : split_route_ok(d->precision, d->Cout, d->H, d->W, d->k * d->k, nullptr);
+    if (split) { sw_ = carve_split(d, g, ws); sw = &sw_; wm = sw_.w; }
     if (d->transposed) {
         // gradient of ConvTranspose2d(k3,s2,p1,op1) = Conv2d(k3,s2,p1) of dy whose OIHW tensor is the (Cin,Cout,3,3) one
-        if ((rc = relayout(w, wm, 0, d->Cin, d->Cout, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
+        if ((rc = relayout(w, wm, 0, d->Cin, d->Cout, 9, (long)g.w_floats, st, 0, split)) != LWG_OK) return rc;
         return op_conv(dy, d->N, g.Ho, g.Wo, d->Cout, wm, nullptr, d->Cin, 3, 2, 1, dx, st, d->precision, sw);
     }
     if (d->stride == 1) {
         if (2 * d->pad != d->k - 1) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_data: stride-1 convs need 'same' padding");
         // rows of k*k*Cout entries, padded to the reduction slice (the heads' data gradient: 49 x 8 = 392 -> 416)
         const int pitch = (int)align_up((size_t)d->k * d->k * d->Cout, kConvBK);
-        if ((rc = relayout(w, wm, 1, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st, pitch)) != LWG_OK) return rc;
+        if ((rc = relayout(w, wm, 1, d->Cout, d->Cin, d->k * d->k, (long)g.w_floats, st, pitch, split)) != LWG_OK) return rc;
         return op_conv(dy, d->N, g.Ho, g.Wo, d->Cout, wm, nullptr, d->Cin, d->k, 1, d->k - 1 - d->pad, dx, st, d->precision, sw);
     }
     if (d->k != 3 || d->pad != 1 || (d->H & 1) || (d->W & 1))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv2d_backward_data: stride-2 convs are k3 p1 on even sizes (the discriminator's k4 has its own path)");
     // gradient of Conv2d(k3,s2,p1) = ConvTranspose2d(k3,s2,p1,op1) forward of dy with the same tensor read as (Cout,Cin,3,3)
-    if ((rc = relayout(w, wm, 2, d->Cout, d->Cin, 9, (long)g.w_floats, st)) != LWG_OK) return rc;
+    if ((rc = relayout(w, wm, 2, d->Cout, d->Cin, 9, (long)g.w_floats, st, 0, split)) != LWG_OK) return rc;
     return op_convT(dy, d->N, g.Ho, g.Wo, d->Cout, wm, d->Cin, dx, st, d->precision, sw);
 }
 
@@ -1752,7 +1853,8 @@ int lwg_heads_backward_weight(const float *x, const float *dy8, int N, int H, in
 size_t lwg_instance_norm_scratch_bytes(int N, int HW, int C)
 {
     if (N < 1 || HW < 1 || C < RS_CH) return 0;
-    return (size_t)N * in_slabs(N, C, HW) * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float);
+    const int S4 = C % RS4_CH == 0 ? in_bwd_slabs4(N, C, HW) : 1, S1 = in_slabs(N, C, HW);
+    return (size_t)N * (S4 > S1 ? S4 : S1) * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float);
 }
 
 int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float *gamma, const float *beta, int relu, float *y,
@@ -1788,16 +1890,22 @@ int lwg_instance_norm_backward(const float *x, const float *y, const float *dy, 
     if (C % RS_CH) LWG_FAIL(LWG_ERR_UNSUPPORTED, "instance_norm: C=%d must be a multiple of %d", C, RS_CH);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float2 *s2 = reinterpret_cast<const float2 *>(stats);
-    const int S = in_slabs(N, C, HW);
+    const bool vec4 = C % RS4_CH == 0;
+    const int S = vec4 ? in_bwd_slabs4(N, C, HW) : in_slabs(N, C, HW);
     double *part = static_cast<double *>(scratch);
     float2 *sums = reinterpret_cast<float2 *>(part + (size_t)N * S * C * 2);
-    if (S == 1) {
+    if (vec4) {
+        in_affine_bwd_sums4_kernel<<<dim3(C / RS4_CH, N, S), 256, 0, st>>>(x, y, dy, s2, HW, C, S, part);
+        LWG_LAUNCH_CHECK("in_affine_bwd_sums4_kernel");
+        in_sums_final_kernel<<<ceil_div((long)N * C, 64), 256, 0, st>>>(part, N, C, S, sums);
+        LWG_LAUNCH_CHECK("in_sums_final_kernel");
+    } else if (S == 1) {
         in_affine_bwd_reduce_kernel<<<dim3(C / RS_CH, N), 256, 0, st>>>(x, y, dy, s2, HW, C, sums);
         LWG_LAUNCH_CHECK("in_affine_bwd_reduce_kernel");
     } else {
         in_affine_bwd_partial_kernel<<<dim3(C / RS_CH, N, S), 256, 0, st>>>(x, y, dy, s2, HW, C, S, part);
         LWG_LAUNCH_CHECK("in_affine_bwd_partial_kernel");
-        in_sums_final_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, N, C, S, sums);
+        in_sums_final_kernel<<<ceil_div((long)N * C, 64), 256, 0, st>>>(part, N, C, S, sums);
         LWG_LAUNCH_CHECK("in_sums_final_kernel");
     }
     const long total = (long)N * HW * C;
