@@ -830,6 +830,125 @@ inline int in_slabs(int N, int C, int HW)
     return S < 1 ? 1 : (int)S;
 }
 
+// ---- float4 forms of the InstanceNorm passes for C % 64 == 0 (every layer of the generator)
+// statistics partials: slab sb of image n, 64 channels per workgroup, a thread owns four channels and every sixteenth pixel
+__global__ __launch_bounds__(256) void in_stats4_kernel(const float *__restrict__ x, int HW, int C, int S, double *__restrict__ part)
+{
+    __shared__ double sh[2][RS_SL][RS4_CH];
+    const int cq = threadIdx.x & 15, c = blockIdx.x * RS4_CH + 4 * cq, slice = threadIdx.x >> 4, n = blockIdx.y, sb = blockIdx.z;
+    const int per = (HW + S - 1) / S, p0 = sb * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const float *p = x + (size_t)n * HW * C + c;
+    double s[4] = {0., 0., 0., 0.}, q[4] = {0., 0., 0., 0.};
+    auto add = [&](const float4 v) {
+        const double d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[k] += d[k];
+            q[k] += d[k] * d[k];
+        }
+    };
+    int i = p0 + slice;
+    for (; i + 3 * RS_SL < p1; i += 4 * RS_SL) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld4(p + (size_t)(i + u * RS_SL) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(v[u]);
+    }
+    for (; i < p1; i += RS_SL) add(ld4(p + (size_t)i * C));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sh[0][slice][4 * cq + k] = s[k];
+        sh[1][slice][4 * cq + k] = q[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < RS4_CH) {
+        const int cl = threadIdx.x;
+        double a = 0., b = 0.;
+        for (int k = 0; k < RS_SL; ++k) {
+            a += sh[0][k][cl];
+            b += sh[1][k][cl];
+        }
+        double *o = part + (((size_t)n * S + sb) * C + blockIdx.x * RS4_CH + cl) * 2;
+        o[0] = a;
+        o[1] = b;
+    }
+}
+// grid ceil(N*C / 64): four threads per (image, channel), each summing every fourth slab
+__global__ __launch_bounds__(256) void in_stats_final4_kernel(const double *__restrict__ part, int N, int C, int S, int HW,
+                                                              float2 *__restrict__ out)
+{
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;
+    double s = 0., q = 0.;
+    if (i < N * C) {
+        const int n = i / C, c = i - n * C;
+        for (int k = grp; k < S; k += 4) {
+            const double *o = part + (((size_t)n * S + k) * C + c) * 2;
+            s += o[0];
+            q += o[1];
+        }
+    }
+    sh[0][grp][cl] = s;
+    sh[1][grp][cl] = q;
+    __syncthreads();
+    if (grp == 0 && i < N * C) {
+        s = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+        q = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        const double mean = s / HW, var = fmax(q / HW - mean * mean, 0.);
+        out[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)kEps)));
+    }
+}
+__global__ __launch_bounds__(256) void in_apply4_kernel(const float *__restrict__ x, const float2 *__restrict__ stats,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        int relu, int HW, int C, long total4, float *__restrict__ y)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const long e = i * 4;
+    const int c = (int)(e % C), n = (int)(e / ((long)HW * C));
+    const float4 v = ld4(x + e), g = ld4(gamma + c), b = ld4(beta + c);
+    const float4 sa = ld4(reinterpret_cast<const float *>(stats + (size_t)n * C + c));
+    const float4 sb = ld4(reinterpret_cast<const float *>(stats + (size_t)n * C + c + 2));
+    float4 o;
+    o.x = g.x * ((v.x - sa.x) * sa.y) + b.x;
+    o.y = g.y * ((v.y - sa.z) * sa.w) + b.y;
+    o.z = g.z * ((v.z - sb.x) * sb.y) + b.z;
+    o.w = g.w * ((v.w - sb.z) * sb.w) + b.w;
+    if (relu) {
+        o.x = o.x < 0.f ? 0.f : o.x; o.y = o.y < 0.f ? 0.f : o.y; o.z = o.z < 0.f ? 0.f : o.z; o.w = o.w < 0.f ? 0.f : o.w;
+    }
+    *reinterpret_cast<float4 *>(y + e) = o;
+}
+__global__ __launch_bounds__(256) void in_affine_bwd_apply4_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                   const float *__restrict__ dy, const float2 *__restrict__ stats,
+                                                                   const float2 *__restrict__ sums, const float *__restrict__ gamma,
+                                                                   int HW, int C, long total4, float *__restrict__ dx)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const long e = i * 4;
+    const int c = (int)(e % C), n = (int)(e / ((long)HW * C));
+    const float4 xv = ld4(x + e), gv = ld4(dy + e), gm = ld4(gamma + c);
+    const float4 yv = y ? ld4(y + e) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sa = ld4(reinterpret_cast<const float *>(stats + (size_t)n * C + c));
+    const float4 sb = ld4(reinterpret_cast<const float *>(stats + (size_t)n * C + c + 2));
+    const float4 ma = ld4(reinterpret_cast<const float *>(sums + (size_t)n * C + c));
+    const float4 mb = ld4(reinterpret_cast<const float *>(sums + (size_t)n * C + c + 2));
+    const float inv = 1.f / (float)HW;
+    auto one = [&](float xx, float yy, float gg, float gam, float mean, float rstd, float s1, float s2) {
+        const float g = (y && !(yy > 0.f)) ? 0.f : gg;
+        return gam * rstd * (g - s1 * inv - (xx - mean) * rstd * (s2 * inv));
+    };
+    float4 o;
+    o.x = one(xv.x, yv.x, gv.x, gm.x, sa.x, sa.y, ma.x, ma.y);
+    o.y = one(xv.y, yv.y, gv.y, gm.y, sa.z, sa.w, ma.z, ma.w);
+    o.z = one(xv.z, yv.z, gv.z, gm.z, sb.x, sb.y, mb.x, mb.y);
+    o.w = one(xv.w, yv.w, gv.w, gm.w, sb.z, sb.w, mb.z, mb.w);
+    *reinterpret_cast<float4 *>(dx + e) = o;
+}
+
 // slabs of in_affine_bwd_sums4_kernel: ~4096 workgroups, at least 256 pixels each, at most 256 slabs
 inline int in_bwd_slabs4(int N, int C, int HW)
 {
@@ -1864,6 +1983,18 @@ int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float 
     if (C % RS_CH) LWG_FAIL(LWG_ERR_UNSUPPORTED, "instance_norm: C=%d must be a multiple of %d", C, RS_CH);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float2 *s2 = reinterpret_cast<float2 *>(stats);
+    const long total = (long)N * HW * C;
+    if (C % RS4_CH == 0) {
+        const int S4 = in_bwd_slabs4(N, C, HW);
+        double *part = static_cast<double *>(scratch);
+        in_stats4_kernel<<<dim3(C / RS4_CH, N, S4), 256, 0, st>>>(x, HW, C, S4, part);
+        LWG_LAUNCH_CHECK("in_stats4_kernel");
+        in_stats_final4_kernel<<<ceil_div((long)N * C, 64), 256, 0, st>>>(part, N, C, S4, HW, s2);
+        LWG_LAUNCH_CHECK("in_stats_final4_kernel");
+        in_apply4_kernel<<<ceil_div(total / 4, 256), 256, 0, st>>>(x, s2, gamma, beta, relu, HW, C, total / 4, y);
+        LWG_LAUNCH_CHECK("in_apply4_kernel");
+        return LWG_OK;
+    }
     const int S = in_slabs(N, C, HW);
     if (S == 1) {
         in_stats_kernel<<<dim3(C / RS_CH, N), 256, 0, st>>>(x, HW, C, s2);
@@ -1875,7 +2006,6 @@ int lwg_instance_norm_forward(const float *x, int N, int HW, int C, const float 
         in_stats_final_kernel<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, N, C, S, HW, s2);
         LWG_LAUNCH_CHECK("in_stats_final_kernel");
     }
-    const long total = (long)N * HW * C;
     in_apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(x, s2, gamma, beta, relu, HW, C, total, y);
     LWG_LAUNCH_CHECK("in_apply_kernel");
     return LWG_OK;
@@ -1909,8 +2039,13 @@ int lwg_instance_norm_backward(const float *x, const float *y, const float *dy, 
         LWG_LAUNCH_CHECK("in_sums_final_kernel");
     }
     const long total = (long)N * HW * C;
-    in_affine_bwd_apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(x, y, dy, s2, sums, gamma, HW, C, total, dx);
-    LWG_LAUNCH_CHECK("in_affine_bwd_apply_kernel");
+    if (vec4) {
+        in_affine_bwd_apply4_kernel<<<ceil_div(total / 4, 256), 256, 0, st>>>(x, y, dy, s2, sums, gamma, HW, C, total / 4, dx);
+        LWG_LAUNCH_CHECK("in_affine_bwd_apply4_kernel");
+    } else {
+        in_affine_bwd_apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(x, y, dy, s2, sums, gamma, HW, C, total, dx);
+        LWG_LAUNCH_CHECK("in_affine_bwd_apply_kernel");
+    }
     in_affine_bwd_params_kernel<<<ceil_div(C, 256), 256, 0, st>>>(sums, N, C, dgamma, dbeta);
     LWG_LAUNCH_CHECK("in_affine_bwd_params_kernel");
     return LWG_OK;
