@@ -138,12 +138,16 @@ class GeneratorTrainer(object):
     """One Adam optimiser over the ImpersonatorGenerator's 194 parameter tensors with a hand-written backward pass."""
 
     def __init__(self, generator, discriminator, lambda_D_prob=1.0, lambda_rec=10.0, lambda_tsf=10.0, lambda_mask=0.1,
-                 lambda_mask_smooth=1e-5, lr=0.0002, betas=(0.5, 0.999), eps=1e-8, conv_precision="fp32"):
+                 lambda_mask_smooth=1e-5, lr=0.0002, betas=(0.5, 0.999), eps=1e-8, conv_precision="fp32", mask_bce=False,
+                 bg_both=False, vgg=None):
         """conv_precision 'bf16x3': the convolutions of the three streams (forward, data gradient, weight gradient) run on
         split-bf16 operands (include/lwg.h, lwg_conv2d_desc.precision); norms, heads, losses, Adam: fp32."""
         if conv_precision not in ops.PRECISIONS:
             raise ValueError("conv_precision must be one of %s" % sorted(ops.PRECISIONS))
         self.conv_precision = conv_precision
+        # impersonator_trainer.py:251-254 (--mask_bce: BCELoss on the masks), :333-339 (--bg_both: BGNet on the source's
+        # and the target's background, 2N inputs), :256-260 + :376-377 (--use_vgg: `vgg` = networks.vgg.Vgg19Perceptual)
+        self.mask_bce, self.bg_both, self.vgg = bool(mask_bce), bool(bg_both), vgg
         self.generator, self.D = generator, discriminator
         self.lam = dict(adv=lambda_D_prob, rec=lambda_rec, tsf=lambda_tsf, mask=lambda_mask, smooth=lambda_mask_smooth)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
@@ -247,11 +251,14 @@ class GeneratorTrainer(object):
             x = self.tsf.res[i].forward(x) + ops.grid_sample_nhwc(self.src_res[i], Ts[N_DOWN], self.align)
         tsf_img, tsf_mask = self.tsf.decode_regress(x, tsf_enc)
         # --- blends (bg_both=False: one background, from the source's inputs)
-        bg = self.bg_img
-        self.fake_src = src_mask * bg + (1 - src_mask) * src_img
-        self.fake_tsf = tsf_mask * bg + (1 - tsf_mask) * tsf_img
+        n = src_img.shape[0]
+        if self.bg_img.shape[0] != (2 * n if self.bg_both else n):
+            raise ValueError("input_G_bg carries %d images for a batch of %d (bg_both=%s)" % (self.bg_img.shape[0], n, self.bg_both))
+        bg_s, bg_t = self.bg_img[:n], self.bg_img[n:] if self.bg_both else self.bg_img[:n]
+        self.fake_src = src_mask * bg_s + (1 - src_mask) * src_img
+        self.fake_tsf = tsf_mask * bg_t + (1 - tsf_mask) * tsf_img
         nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
-        return nchw(bg), nchw(self.fake_src), nchw(self.fake_tsf), torch.cat([nchw(src_mask), nchw(tsf_mask)], dim=0)
+        return nchw(self.bg_img), nchw(self.fake_src), nchw(self.fake_tsf), torch.cat([nchw(src_mask), nchw(tsf_mask)], dim=0)
 
     # ------------------------------------------------------------------ losses + backward (:368-394, :355-356)
     @torch.no_grad()
@@ -259,8 +266,9 @@ class GeneratorTrainer(object):
         b, lam = self.b, self.lam
         self.flat_g.zero_()
         to_nhwc = lambda t: t.permute(0, 2, 3, 1)
-        src_img, src_mask, tsf_img, tsf_mask, bg = self.src.img, self.src.mask, self.tsf.img, self.tsf.mask, self.bg_img
+        src_img, src_mask, tsf_img, tsf_mask = self.src.img, self.src.mask, self.tsf.img, self.tsf.mask
         n = src_img.shape[0]
+        bg, bg_t = self.bg_img[:n], self.bg_img[n:] if self.bg_both else self.bg_img[:n]
         # adversarial term through the discriminator (its parameters are not touched)
         fake_in = torch.cat([self.fake_tsf.permute(0, 3, 1, 2), b["input_G_tsf"][:, 3:]], dim=1).contiguous()
         adv, d_in = self.D.input_grad(fake_in, 0.0)
@@ -270,14 +278,25 @@ class GeneratorTrainer(object):
         diff_s = self.fake_src - to_nhwc(b["real_src"])
         diff_t = self.fake_tsf - to_nhwc(b["real_tsf"])
         terms["g_rec"] = diff_s.abs().mean() * lam["rec"]
-        terms["g_tsf"] = diff_t.abs().mean() * lam["tsf"]
         d_fs = torch.sign(diff_s) * (lam["rec"] / diff_s.numel())
-        d_ft = d_ft + torch.sign(diff_t) * (lam["tsf"] / diff_t.numel())
+        if self.vgg is not None:
+            v_loss, v_grad = self.vgg.loss_and_grad(self.fake_tsf.contiguous(), to_nhwc(b["real_tsf"]).contiguous())
+            terms["g_tsf"] = v_loss * lam["tsf"]
+            d_ft = d_ft + v_grad * lam["tsf"]
+        else:
+            terms["g_tsf"] = diff_t.abs().mean() * lam["tsf"]
+            d_ft = d_ft + torch.sign(diff_t) * (lam["tsf"] / diff_t.numel())
         # mask terms on cat([src_mask, tsf_mask])
         masks = torch.cat([src_mask, tsf_mask], dim=0)
-        dm = masks - to_nhwc(b["bg_mask"])
-        terms["g_mask"] = (dm * dm).mean() * lam["mask"]
-        d_masks = dm * (2.0 * lam["mask"] / dm.numel())
+        target = to_nhwc(b["bg_mask"])
+        if self.mask_bce:   # torch.nn.BCELoss: logs clamped at -100
+            lm, l1m = torch.log(masks).clamp_(min=-100.0), torch.log1p(-masks).clamp_(min=-100.0)
+            terms["g_mask"] = -(target * lm + (1 - target) * l1m).mean() * lam["mask"]
+            d_masks = ((1 - target) / (1 - masks).clamp_(min=1e-12) - target / masks.clamp(min=1e-12)) * (lam["mask"] / masks.numel())
+        else:
+            dm = masks - target
+            terms["g_mask"] = (dm * dm).mean() * lam["mask"]
+            d_masks = dm * (2.0 * lam["mask"] / dm.numel())
         dx = masks[:, :, :-1] - masks[:, :, 1:]
         dy = masks[:, :-1] - masks[:, 1:]
         terms["g_mask_smooth"] = (dx.abs().mean() + dy.abs().mean()) * lam["smooth"]
@@ -289,10 +308,10 @@ class GeneratorTrainer(object):
         d_masks[:, 1:] -= gy
         # blends: fake = m * bg + (1 - m) * c
         d_src_mask = d_masks[:n] + (d_fs * (bg - src_img)).sum(-1, keepdim=True)
-        d_tsf_mask = d_masks[n:] + (d_ft * (bg - tsf_img)).sum(-1, keepdim=True)
+        d_tsf_mask = d_masks[n:] + (d_ft * (bg_t - tsf_img)).sum(-1, keepdim=True)
         d_src_img = d_fs * (1 - src_mask)
         d_tsf_img = d_ft * (1 - tsf_mask)
-        d_bg = d_fs * src_mask + d_ft * tsf_mask
+        d_bg = torch.cat([d_fs * src_mask, d_ft * tsf_mask], dim=0) if self.bg_both else d_fs * src_mask + d_ft * tsf_mask
         # --- transfer stream
         d, d_skips = self.tsf.decode_regress_backward(d_tsf_img, d_tsf_mask)
         g_res = [None] * self.repeat

@@ -10,6 +10,7 @@ import torch
 
 from ..networks.discriminator import PatchDiscriminator
 from ..networks.generator import ImpersonatorGenerator
+from ..networks.vgg import Vgg19Perceptual
 from .generator_trainer import GeneratorTrainer
 from .models import BaseModel
 
@@ -104,16 +105,19 @@ class Impersonator(BaseModel):
         self._input_G_bg = self._input_G_src = self._input_G_tsf = self._T = None
         self._real_tsf = None
         self._d_loss = None
-        for flag in ('use_vgg', 'use_style', 'use_face'):
+        # --use_style / --use_face need the reference's other downloads (VGG Gram term aside, SphereFace); --use_vgg works
+        # with the VGG19 weights handed in as a file: opt.vgg_weights = torch.save()d state_dict in torchvision's naming
+        # (what models.vgg19(pretrained=True).state_dict() is; the reference downloads it, networks/networks.py:133)
+        for flag in ('use_style', 'use_face'):
             if getattr(opt, flag, False):
                 raise NotImplementedError("--%s needs a pretrained network that is a download of the reference" % flag)
-        # impersonator_trainer.py:251-254 switches the mask criterion to BCELoss under --mask_bce and :333-337 runs BGNet on
-        # both backgrounds under --bg_both; GeneratorTrainer implements the MSE mask loss and one background stream, so
-        # these flags must not be silently ignored (the reference's train_iPER.sh passes --mask_bce)
-        for flag in ('mask_bce', 'bg_both'):
-            if getattr(opt, flag, False):
-                raise NotImplementedError("--%s is not implemented in the MI355X generator update (MSE mask loss, one "
-                                          "background stream); training with it would diverge from the reference" % flag)
+        self._vgg_state = None
+        if getattr(opt, 'use_vgg', False):
+            path = getattr(opt, 'vgg_weights', None)
+            if not path:
+                raise NotImplementedError("--use_vgg: pass --vgg_weights <vgg19 state_dict .pth> (torchvision's "
+                                          "vgg19(pretrained=True).state_dict(); there is no download here)")
+            self._vgg_state = path if isinstance(path, dict) else torch.load(path, map_location='cpu')
         self._g_trainer = None
         self._real_src = self._bg_mask = None
 
@@ -125,7 +129,9 @@ class Impersonator(BaseModel):
                 lambda_tsf=getattr(o, 'lambda_tsf', 10), lambda_mask=getattr(o, 'lambda_mask', 0.1),
                 lambda_mask_smooth=getattr(o, 'lambda_mask_smooth', 1e-5), lr=getattr(o, 'lr_G', 0.0002),
                 betas=(getattr(o, 'G_adam_b1', 0.5), getattr(o, 'G_adam_b2', 0.999)),
-                conv_precision=getattr(o, 'conv_precision', 'fp32'))
+                conv_precision=getattr(o, 'conv_precision', 'fp32'), mask_bce=getattr(o, 'mask_bce', False),
+                bg_both=getattr(o, 'bg_both', False),
+                vgg=(Vgg19Perceptual(self._vgg_state, getattr(o, 'conv_precision', 'fp32')) if self._vgg_state is not None else None))
         return self._g_trainer
 
     def sync_generator(self):
@@ -163,21 +169,23 @@ class Impersonator(BaseModel):
              self._body_bbox) = self._bdr(src_img, tsf_img, src_smpl, tsf_smpl)
             real_src, real_tsf = src_img, tsf_img
             bg_mask = torch.cat((src_crop_mask, tsf_crop_mask), dim=0)
-            input_G_bg = input_G_src_bg     # bg_both is rejected in __init__
+            input_G_bg = (torch.cat([input_G_src_bg, input_G_tsf_bg], dim=0) if getattr(self._opt, 'bg_both', False)
+                          else input_G_src_bg)   # impersonator_trainer.py:306-309
         self._input_G_tsf, self._real_tsf = input_G_tsf, real_tsf
         self._input_G_bg, self._input_G_src, self._T = input_G_bg, input_G_src, T
         self._real_src, self._bg_mask = real_src, bg_mask
 
     @torch.no_grad()
     def forward(self, keep_data_for_visuals=False, return_estimates=False):
-        """impersonator_trainer.py:329-348 (bg_both=False): the generator pass and the blends onto the inpainted
-        background -> (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks).  No autograd graph."""
+        """impersonator_trainer.py:329-348: the generator pass and the blends onto the inpainted background(s)
+        -> (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks).  No autograd graph."""
         fake_bg, fake_src_color, fake_src_mask, fake_tsf_color, fake_tsf_mask = \
             self._G.forward(self._input_G_bg, self._input_G_src, self._input_G_tsf, T=self._T)
         bs = fake_src_color.shape[0]
         fake_src_bg = fake_bg[0:bs]
+        fake_tsf_bg = fake_bg[bs:] if getattr(self._opt, 'bg_both', False) else fake_src_bg
         fake_src_imgs = fake_src_mask * fake_src_bg + (1 - fake_src_mask) * fake_src_color
-        fake_tsf_imgs = fake_tsf_mask * fake_src_bg + (1 - fake_tsf_mask) * fake_tsf_color
+        fake_tsf_imgs = fake_tsf_mask * fake_tsf_bg + (1 - fake_tsf_mask) * fake_tsf_color
         return fake_bg, fake_src_imgs, fake_tsf_imgs, torch.cat([fake_src_mask, fake_tsf_mask], dim=0)
 
     def optimize_D_phase(self):

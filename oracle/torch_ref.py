@@ -470,13 +470,42 @@ G_TRAIN_DEFAULTS = dict(lambda_D_prob=1.0, lambda_rec=10.0, lambda_tsf=10.0, lam
                         lr_G=0.0002, G_adam_b1=0.5, G_adam_b2=0.999)   # options/train_options.py:33-45
 
 
+# torchvision's vgg19().features: (index, out channels) of the convs up to relu5_1, 'M' = MaxPool2d(2, 2)
+VGG19_CFG = [(0, 64), (2, 64), "M", (5, 128), (7, 128), "M", (10, 256), (12, 256), (14, 256), (16, 256), "M",
+             (19, 512), (21, 512), (23, 512), (25, 512), "M", (28, 512)]
+VGG19_TAPS = (0, 5, 10, 19, 28)   # convs whose ReLU output is a slice output (networks/networks.py:137-155: slice_ids 2,7,12,21,30)
+VGG_LOSS_WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)   # networks/networks.py:179
+
+
+def vgg19_features(vsd, x):
+    """Vgg19.forward (networks/networks.py:162-169) on a state_dict in torchvision's naming (features.N.weight / .bias):
+    the five slice outputs relu1_1, relu2_1, relu3_1, relu4_1, relu5_1."""
+    outs = []
+    for item in VGG19_CFG:
+        if item == "M":
+            x = F.max_pool2d(x, 2, 2)
+            continue
+        i = item[0]
+        x = F.relu(F.conv2d(x, vsd["features.%d.weight" % i], vsd["features.%d.bias" % i], padding=1))
+        if i in VGG19_TAPS:
+            outs.append(x)
+    return outs
+
+
+def vgg_loss(vsd, x, y):
+    """VGGLoss.forward (networks/networks.py:181-186)."""
+    fx, fy = vgg19_features(vsd, x), vgg19_features(vsd, y)
+    return sum(w * F.l1_loss(a, b.detach()) for w, a, b in zip(VGG_LOSS_WEIGHTS, fx, fy))
+
+
 def generator_train_loss(gsd, dsd, batch, opt=None, align_corners=False):
-    """models/impersonator_trainer.py: forward (:329-348, bg_both=False) + _optimize_G (:368-394) with the loss terms
-    that need no pretrained network: adversarial (LSGAN, target 0), L1 reconstruction of the source, L1 on the
-    transferred image (what the `--use_vgg` help text calls the default; the reference's own code path for it only works
-    with `self._crt_tsf` set -- VGGLoss needs a download -- so the pin test injects torch.nn.L1Loss there), mask MSE,
-    mask total variation.  No style / face terms (their flags default to off).
-    batch: input_G_bg (N,4,H,W), input_G_src, input_G_tsf (N,6,H,W), T (N,H,W,2), real_src, real_tsf (N,3,H,W),
+    """models/impersonator_trainer.py: forward (:329-348) + _optimize_G (:368-394): adversarial (LSGAN, target 0), L1
+    reconstruction of the source, the transfer term -- L1 (what the `--use_vgg` help text calls the default; the
+    reference's own code path for it only works with `self._crt_tsf` set, so the pin test injects torch.nn.L1Loss there)
+    or, with opt['vgg'] = a VGG19 state_dict, VGGLoss (--use_vgg) --, the mask term (MSE, or BCE with opt['mask_bce']),
+    mask total variation.  opt['bg_both']: BGNet ran on 2N inputs and the transferred image blends with the second half
+    (:336-339).  No style / face terms.
+    batch: input_G_bg (N or 2N,4,H,W), input_G_src, input_G_tsf (N,6,H,W), T (N,H,W,2), real_src, real_tsf (N,3,H,W),
     bg_mask (2N,1,H,W).  Returns (total, dict of terms, (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks))."""
     o = dict(G_TRAIN_DEFAULTS)
     o.update(opt or {})
@@ -484,15 +513,18 @@ def generator_train_loss(gsd, dsd, batch, opt=None, align_corners=False):
                                                                       batch["input_G_tsf"], batch["T"], align_corners)
     bs = src_img.shape[0]
     fake_src_bg = fake_bg[0:bs]
+    fake_tsf_bg = fake_bg[bs:] if o.get("bg_both") else fake_src_bg
     fake_src_imgs = src_mask * fake_src_bg + (1 - src_mask) * src_img
-    fake_tsf_imgs = tsf_mask * fake_src_bg + (1 - tsf_mask) * tsf_img
+    fake_tsf_imgs = tsf_mask * fake_tsf_bg + (1 - tsf_mask) * tsf_img
     fake_masks = torch.cat([src_mask, tsf_mask], dim=0)
     d_fake = discriminator_forward(dsd, torch.cat([fake_tsf_imgs, batch["input_G_tsf"][:, 3:]], dim=1))
+    tsf_term = vgg_loss(o["vgg"], fake_tsf_imgs, batch["real_tsf"]) if o.get("vgg") else F.l1_loss(fake_tsf_imgs, batch["real_tsf"])
+    mask_term = (F.binary_cross_entropy if o.get("mask_bce") else F.mse_loss)(fake_masks, batch["bg_mask"])
     terms = dict(
         g_adv=torch.mean(d_fake ** 2) * o["lambda_D_prob"],
         g_rec=F.l1_loss(fake_src_imgs, batch["real_src"]) * o["lambda_rec"],
-        g_tsf=F.l1_loss(fake_tsf_imgs, batch["real_tsf"]) * o["lambda_tsf"],
-        g_mask=F.mse_loss(fake_masks, batch["bg_mask"]) * o["lambda_mask"],
+        g_tsf=tsf_term * o["lambda_tsf"],
+        g_mask=mask_term * o["lambda_mask"],
         g_mask_smooth=(torch.mean(torch.abs(fake_masks[:, :, :, :-1] - fake_masks[:, :, :, 1:])) +
                        torch.mean(torch.abs(fake_masks[:, :, :-1, :] - fake_masks[:, :, 1:, :]))) * o["lambda_mask_smooth"])
     return sum(terms.values()), terms, (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)

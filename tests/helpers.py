@@ -65,13 +65,32 @@ def discriminator_state_dict(seed=0, input_nc=6, ndf=64, n_layers=4):
     return sd
 
 
-def train_batch(seed=0, n=2, size=64):
-    """Seeded stand-in for what the reference's BodyRecoveryFlow hands the trainer (impersonator_trainer.py:300-319)."""
+def vgg19_state_dict(seed=0):
+    """Random VGG19 conv stack in torchvision's naming (features.N.weight / .bias) up to relu5_1 -- the real weights are a
+    download; He-scaled so that activations keep their magnitude through the 13 layers."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd, cin = {}, 3
+    for idx, cout in [(0, 64), (2, 64), (5, 128), (7, 128), (10, 256), (12, 256), (14, 256), (16, 256), (19, 512), (21, 512),
+                      (23, 512), (25, 512), (28, 512)]:
+        sd["features.%d.weight" % idx] = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        sd["features.%d.bias" % idx] = torch.randn(cout, generator=g) * 0.05
+        cin = cout
+    return sd
+
+
+def train_batch(seed=0, n=2, size=64, bg_both=False):
+    """Seeded stand-in for what the reference's BodyRecoveryFlow hands the trainer (impersonator_trainer.py:300-319);
+    bg_both: the background input carries the source's and the target's (2n images, :333-337)."""
     import torch
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.rand(*s, generator=g) * 2 - 1
     T = torch.rand(n, size, size, 2, generator=g) * 2.4 - 1.2
     T[0, size // 4:size // 2, size // 8:size // 3] = -2
+    if bg_both:
+        return dict(input_G_src=r(n, 6, size, size), input_G_tsf=r(n, 6, size, size), T=T, real_src=r(n, 3, size, size),
+                    real_tsf=r(n, 3, size, size), bg_mask=(torch.rand(2 * n, 1, size, size, generator=g) > 0.5).float(),
+                    input_G_bg=r(2 * n, 4, size, size))
     return dict(input_G_bg=r(n, 4, size, size), input_G_src=r(n, 6, size, size), input_G_tsf=r(n, 6, size, size), T=T,
                 real_src=r(n, 3, size, size), real_tsf=r(n, 3, size, size),
                 bg_mask=(torch.rand(2 * n, 1, size, size, generator=g) > 0.5).float())

@@ -75,6 +75,59 @@ def test_bf16x3_convolutions(setup):
         assert _rel(grads[k].double(), ref[k]) < 3e-2, k
 
 
+@pytest.mark.parametrize("conv_precision", ["fp32", "bf16x3"])
+def test_training_script_flags(setup, conv_precision):
+    """--mask_bce --use_vgg (scripts/train_iPER.sh) and --bg_both: BCE mask loss, the VGG19 perceptual transfer term
+    (networks/vgg.py, seeded weights in torchvision's naming -- the real ones are a download) and two backgrounds, against
+    the oracle with the same options (pinned to the reference's own classes in tests/test_oracle_vs_reference.py)."""
+    from impersonator_amd.models.generator_trainer import GeneratorTrainer
+    from impersonator_amd.networks.vgg import Vgg19Perceptual
+    ref_tr = setup["tr"]
+    vsd = helpers.vgg19_state_dict(seed=4)
+    b = helpers.train_batch(seed=5, n=2, size=64, bg_both=True)
+    o = dict(bg_both=True, mask_bce=True, vgg=vsd, lambda_mask=1.0, lambda_mask_smooth=1.0)
+    tr = GeneratorTrainer(ref_tr.generator, ref_tr.D, lambda_mask=1.0, lambda_mask_smooth=1.0, conv_precision=conv_precision,
+                          mask_bce=True, bg_both=True, vgg=Vgg19Perceptual(vsd, conv_precision))
+    fake = tr.forward(b)
+    with torch.no_grad():
+        _, terms, ref_fake = torch_ref.generator_train_loss(setup["gsd"], setup["dsd"], b, o)
+    tol = 1e-4 if conv_precision == "fp32" else 2e-4
+    for name, a, c in zip(("fake_bg", "fake_src", "fake_tsf", "masks"), fake, ref_fake):
+        assert a.shape == c.shape and float((a.cpu() - c).abs().max()) < tol, name
+    mine = tr.backward()
+    for k, v in terms.items():
+        assert abs(float(mine[k]) - float(v)) < 2e-4 * max(1.0, abs(float(v))), (k, float(mine[k]), float(v))
+    dbl = lambda d: {k: v.double() for k, v in d.items()}
+    o64 = dict(o, vgg=dbl(vsd))
+    _, grads64, _ = torch_ref.generator_train_steps(dbl(setup["gsd"]), dbl(setup["dsd"]), [dbl(b)], o64)
+    grads = tr.gradients()
+    num = den = 0.0
+    for k, g in grads64.items():
+        e = grads[k].double() - g
+        num += float((e * e).sum())
+        den += float((g.double() ** 2).sum())
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
+def test_vgg_perceptual_loss_and_gradient():
+    """Vgg19Perceptual.loss_and_grad against autograd through the oracle's VGG19 (float64), both conv precisions."""
+    from impersonator_amd.networks.vgg import Vgg19Perceptual
+    vsd = helpers.vgg19_state_dict(seed=8)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1)
+    y = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1)
+    xr = x.double().requires_grad_(True)
+    loss = torch_ref.vgg_loss({k: v.double() for k, v in vsd.items()}, xr, y.double())
+    loss.backward()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    for precision, ltol, tol in (("fp32", 1e-5, 5e-3), ("bf16x3", 1e-4, 5e-2)):   # measured 1.5e-3 in fp32
+        v, d = Vgg19Perceptual(vsd, precision).loss_and_grad(nhwc(x), nhwc(y))
+        assert abs(float(v) - float(loss.detach())) < ltol * max(1.0, float(loss.detach())), (precision, float(v), float(loss.detach()))
+        got = d.cpu().permute(0, 3, 1, 2).double()
+        # the L1 terms' sign() and the ReLU masks make single entries jump when a feature difference is ~1e-6: norm-wise bound
+        assert float((got - xr.grad).norm() / xr.grad.norm()) < tol, (precision, float((got - xr.grad).norm() / xr.grad.norm()))
+
+
 def test_every_parameter_gradient(setup):
     tr = setup["tr"]
     tr.forward(setup["batch"])

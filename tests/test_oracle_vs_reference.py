@@ -186,6 +186,63 @@ def test_generator_train_loss_matches_reference_trainer(ref):
         assert torch.allclose(p.grad, grads[k], atol=1e-6 + 1e-4 * float(p.grad.abs().max()), rtol=0), k
 
 
+def _torchvision_vgg19(vsd):
+    """What torchvision.models.vgg19().features is, with the given weights (the reference slices it by index)."""
+    layers, cin = [], 3
+    for v in [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]:
+        if v == "M":
+            layers.append(torch.nn.MaxPool2d(2, 2))
+        else:
+            conv = torch.nn.Conv2d(cin, v, 3, padding=1)
+            k = "features.%d" % len(layers)
+            if k + ".weight" in vsd:
+                conv.weight.data.copy_(vsd[k + ".weight"])
+                conv.bias.data.copy_(vsd[k + ".bias"])
+            layers += [conv, torch.nn.ReLU(inplace=True)]
+            cin = v
+    return types.SimpleNamespace(features=torch.nn.Sequential(*layers))
+
+
+def test_generator_train_loss_with_the_training_scripts_flags(ref):
+    """scripts/train_iPER.sh trains with --mask_bce --use_vgg (and --bg_both in train_iPER_Place2.sh): the reference's
+    forward + _optimize_G with BCELoss, its own VGGLoss / Vgg19 classes (torchvision.models.vgg19 replaced by the same
+    layer stack with seeded weights: the real ones are a download) and two backgrounds == the oracle with those options."""
+    T = ref.trainer.Impersonator
+    G = ref.generator.ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6)
+    D = ref.discriminator.PatchDiscriminator(input_nc=6, ndf=64, n_layers=4, norm_type='instance', use_sigmoid=False)
+    gsd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=2, affine="random"))
+    dsd = helpers.discriminator_state_dict(seed=3)
+    vsd = helpers.vgg19_state_dict(seed=4)
+    G.load_state_dict(gsd)
+    D.load_state_dict(dsd)
+    b = helpers.train_batch(seed=5, n=2, size=64, bg_both=True)
+    ref.networks.models.vgg19 = lambda pretrained=True: _torchvision_vgg19(vsd)
+    crt_tsf = ref.networks.VGGLoss(vgg=ref.networks.Vgg19())
+    opt = types.SimpleNamespace(bg_both=True, use_vgg=True, use_style=False, use_face=False, lambda_D_prob=1, lambda_rec=10,
+                                lambda_tsf=10, lambda_mask=1.0, lambda_mask_smooth=1.0)
+    me = types.SimpleNamespace(_G=G, _D=D, _opt=opt, _input_G_bg=b["input_G_bg"], _input_G_src=b["input_G_src"],
+                               _input_G_tsf=b["input_G_tsf"], _T=b["T"], _real_src=b["real_src"], _real_tsf=b["real_tsf"],
+                               _bg_mask=b["bg_mask"], _crt_l1=torch.nn.L1Loss(), _crt_tsf=crt_tsf,
+                               _crt_mask=torch.nn.BCELoss(), _loss_g_style=torch.zeros(1), _loss_g_face=torch.zeros(1),
+                               _loss_g_mask_smooth=torch.zeros(1))
+    me._compute_loss_D = types.MethodType(T._compute_loss_D, me)
+    me._compute_loss_smooth = types.MethodType(T._compute_loss_smooth, me)
+    fake = T.forward(me)
+    loss = T._optimize_G(me, *fake)
+    G.zero_grad()
+    loss.backward()
+    o = dict(bg_both=True, mask_bce=True, vgg=vsd, lambda_mask=1.0, lambda_mask_smooth=1.0)
+    total, terms, mine_fake = torch_ref.generator_train_loss({k: v.clone().requires_grad_(True) for k, v in gsd.items()}, dsd, b, o)
+    assert abs(float(loss) - float(total)) < 1e-5 * max(1.0, float(total))
+    assert abs(float(me._loss_g_tsf) - float(terms["g_tsf"])) < 1e-5 * max(1.0, float(terms["g_tsf"]))
+    assert abs(float(me._loss_g_mask) - float(terms["g_mask"])) < 1e-5 * max(1.0, float(terms["g_mask"]))
+    for a, c in zip(fake, mine_fake):
+        assert torch.allclose(a, c, atol=1e-5, rtol=1e-5)
+    _, grads, _ = torch_ref.generator_train_steps(gsd, dsd, [b], o)
+    for k, p in G.named_parameters():
+        assert torch.allclose(p.grad, grads[k], atol=1e-6 + 1e-4 * float(p.grad.abs().max()), rtol=0), k
+
+
 def test_body_recovery_flow_restatement_matches_reference(ref):
     """BodyRecoveryFlow.forward (models/impersonator_trainer.py:44-87), the trainer's input preparation, run unbound on a
     stub that carries the reference's own SMPLRenderer methods and the CPU SMPL (batch of 2 source / target pairs)."""
