@@ -139,7 +139,7 @@ class GeneratorTrainer(object):
 
     def __init__(self, generator, discriminator, lambda_D_prob=1.0, lambda_rec=10.0, lambda_tsf=10.0, lambda_mask=0.1,
                  lambda_mask_smooth=1e-5, lr=0.0002, betas=(0.5, 0.999), eps=1e-8, conv_precision="fp32", mask_bce=False,
-                 bg_both=False, vgg=None):
+                 bg_both=False, vgg=None, face=None, lambda_face=1.0):
         """conv_precision 'bf16x3': the convolutions of the three streams (forward, data gradient, weight gradient) run on
         split-bf16 operands (include/lwg.h, lwg_conv2d_desc.precision); norms, heads, losses, Adam: fp32."""
         if conv_precision not in ops.PRECISIONS:
@@ -147,7 +147,9 @@ class GeneratorTrainer(object):
         self.conv_precision = conv_precision
         # impersonator_trainer.py:251-254 (--mask_bce: BCELoss on the masks), :333-339 (--bg_both: BGNet on the source's
         # and the target's background, 2N inputs), :256-260 + :376-377 (--use_vgg: `vgg` = networks.vgg.Vgg19Perceptual)
-        self.mask_bce, self.bg_both, self.vgg = bool(mask_bce), bool(bg_both), vgg
+        # :268-273 + :383-385 (--use_face: `face` = networks.facenet.SphereFaceLoss; the batch then carries 'head_bbox')
+        self.mask_bce, self.bg_both, self.vgg, self.face = bool(mask_bce), bool(bg_both), vgg, face
+        self.lambda_face = lambda_face
         self.generator, self.D = generator, discriminator
         self.lam = dict(adv=lambda_D_prob, rec=lambda_rec, tsf=lambda_tsf, mask=lambda_mask, smooth=lambda_mask_smooth)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
@@ -221,7 +223,7 @@ class GeneratorTrainer(object):
 
     @torch.no_grad()
     def forward(self, batch):
-        b = {k: v.cuda().float() for k, v in batch.items()}
+        b = {k: (v.cuda().float() if k != "head_bbox" else v) for k, v in batch.items()}
         self.b = b
         # --- BGNet
         x = _nhwc(b["input_G_bg"], 8)
@@ -286,6 +288,10 @@ class GeneratorTrainer(object):
         else:
             terms["g_tsf"] = diff_t.abs().mean() * lam["tsf"]
             d_ft = d_ft + torch.sign(diff_t) * (lam["tsf"] / diff_t.numel())
+        if self.face is not None:
+            f_loss, f_grad = self.face.loss_and_grad(self.fake_tsf.contiguous(), to_nhwc(b["real_tsf"]).contiguous(), b["head_bbox"])
+            terms["g_face"] = f_loss * self.lambda_face
+            d_ft = d_ft + f_grad * self.lambda_face
         # mask terms on cat([src_mask, tsf_mask])
         masks = torch.cat([src_mask, tsf_mask], dim=0)
         target = to_nhwc(b["bg_mask"])

@@ -10,6 +10,7 @@ import torch
 
 from ..networks.discriminator import PatchDiscriminator
 from ..networks.generator import ImpersonatorGenerator
+from ..networks.facenet import SphereFaceLoss
 from ..networks.vgg import Vgg19Perceptual
 from .generator_trainer import GeneratorTrainer
 from .models import BaseModel
@@ -105,12 +106,24 @@ class Impersonator(BaseModel):
         self._input_G_bg = self._input_G_src = self._input_G_tsf = self._T = None
         self._real_tsf = None
         self._d_loss = None
-        # --use_style / --use_face need the reference's other downloads (VGG Gram term aside, SphereFace); --use_vgg works
-        # with the VGG19 weights handed in as a file: opt.vgg_weights = torch.save()d state_dict in torchvision's naming
-        # (what models.vgg19(pretrained=True).state_dict() is; the reference downloads it, networks/networks.py:133)
-        for flag in ('use_style', 'use_face'):
-            if getattr(opt, flag, False):
-                raise NotImplementedError("--%s needs a pretrained network that is a download of the reference" % flag)
+        # The loss networks are downloads of the reference; here their weights are handed in as files.
+        #   --use_vgg : opt.vgg_weights = torch.save()d state_dict in torchvision's naming (what
+        #               models.vgg19(pretrained=True).state_dict() is; the reference downloads it, networks/networks.py:133)
+        #   --use_face: opt.face_model = the reference's own option (base_options.py:31, sphere20a_20171020.pth)
+        #   --use_style (lambda_style is 0 in the reference's training scripts): not implemented
+        if getattr(opt, 'use_style', False):
+            raise NotImplementedError("--use_style (Gram-matrix term) is not implemented")
+        self._face_state = None
+        if getattr(opt, 'use_face', False):
+            path = getattr(opt, 'face_model', None)
+            if isinstance(path, dict):
+                self._face_state = path
+            else:
+                import os
+                if not path or not os.path.exists(path):
+                    raise NotImplementedError("--use_face: --face_model %r does not exist (the Sphere20a checkpoint is a "
+                                              "download of the reference)" % (path,))
+                self._face_state = torch.load(path, map_location='cpu')
         self._vgg_state = None
         if getattr(opt, 'use_vgg', False):
             path = getattr(opt, 'vgg_weights', None)
@@ -131,7 +144,9 @@ class Impersonator(BaseModel):
                 betas=(getattr(o, 'G_adam_b1', 0.5), getattr(o, 'G_adam_b2', 0.999)),
                 conv_precision=getattr(o, 'conv_precision', 'fp32'), mask_bce=getattr(o, 'mask_bce', False),
                 bg_both=getattr(o, 'bg_both', False),
-                vgg=(Vgg19Perceptual(self._vgg_state, getattr(o, 'conv_precision', 'fp32')) if self._vgg_state is not None else None))
+                vgg=(Vgg19Perceptual(self._vgg_state, getattr(o, 'conv_precision', 'fp32')) if self._vgg_state is not None else None),
+                face=(SphereFaceLoss(self._face_state) if self._face_state is not None else None),
+                lambda_face=getattr(o, 'lambda_face', 1))
         return self._g_trainer
 
     def sync_generator(self):
@@ -209,6 +224,10 @@ class Impersonator(BaseModel):
         the images the generator produced before its update.  Returns the loss terms."""
         batch = dict(input_G_bg=self._input_G_bg, input_G_src=self._input_G_src, input_G_tsf=self._input_G_tsf, T=self._T,
                      real_src=self._real_src, real_tsf=self._real_tsf, bg_mask=self._bg_mask)
+        if self._face_state is not None:
+            if self._head_bbox is None:
+                raise RuntimeError("--use_face needs the head boxes: call set_input(sample) (BodyRecoveryFlow) or set _head_bbox")
+            batch['head_bbox'] = self._head_bbox
         terms, (_, _, fake_tsf_imgs, _) = self._generator_trainer().optimize_G(batch)
         losses = {k: float(v) for k, v in terms.items()}
         if trainable:

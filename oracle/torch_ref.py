@@ -498,13 +498,51 @@ def vgg_loss(vsd, x, y):
     return sum(w * F.l1_loss(a, b.detach()) for w, a, b in zip(VGG_LOSS_WEIGHTS, fx, fy))
 
 
+# Sphere20a (networks/facenet.py:200-262): stage name, channels, residual units; every stage opens with a stride-2 conv
+SPHERE20A_STAGES = (("1", 64, 1), ("2", 128, 2), ("3", 256, 4), ("4", 512, 1))
+FACE_HW = (112, 96)   # networks/networks.py:221
+
+
+def sphere20a_features(fsd, x):
+    """Sphere20a.forward (networks/facenet.py:264-290): the four stage outputs and the fc5 embedding."""
+    def unit(x, name):
+        return F.prelu(F.conv2d(x, fsd["conv%s.weight" % name], fsd["conv%s.bias" % name], stride=1, padding=1),
+                       fsd["relu%s.weight" % name])
+    feats = []
+    for st, _, units in SPHERE20A_STAGES:
+        x = F.prelu(F.conv2d(x, fsd["conv%s_1.weight" % st], fsd["conv%s_1.bias" % st], stride=2, padding=1),
+                    fsd["relu%s_1.weight" % st])
+        for u in range(units):
+            x = x + unit(unit(x, "%s_%d" % (st, 2 + 2 * u)), "%s_%d" % (st, 3 + 2 * u))
+        feats.append(x)
+    feats.append(F.linear(x.reshape(x.shape[0], -1), fsd["fc5.weight"], fsd["fc5.bias"]))
+    return feats
+
+
+def crop_head_bbox(imgs, bboxs):
+    """FaceLoss.crop_head_bbox (networks/networks.py:290-312): bbox rows are (min_x, max_x, min_y, max_y) pixel indices."""
+    heads = []
+    for i in range(imgs.shape[0]):
+        min_x, max_x, min_y, max_y = [int(v) for v in bboxs[i]]
+        heads.append(F.interpolate(imgs[i:i + 1, :, min_y:max_y, min_x:max_x], size=FACE_HW, mode="bilinear", align_corners=True))
+    return torch.cat(heads, dim=0)
+
+
+def face_loss(fsd, x, y, bbox):
+    """FaceLoss.forward with bbox1 = bbox2 (impersonator_trainer.py:383-385) + compute_loss (networks.py:272-285): the
+    unweighted sum of the five L1 feature distances."""
+    f1, f2 = sphere20a_features(fsd, crop_head_bbox(x, bbox)), sphere20a_features(fsd, crop_head_bbox(y, bbox))
+    return sum(F.l1_loss(a, b.detach()) for a, b in zip(f1, f2))
+
+
 def generator_train_loss(gsd, dsd, batch, opt=None, align_corners=False):
     """models/impersonator_trainer.py: forward (:329-348) + _optimize_G (:368-394): adversarial (LSGAN, target 0), L1
     reconstruction of the source, the transfer term -- L1 (what the `--use_vgg` help text calls the default; the
     reference's own code path for it only works with `self._crt_tsf` set, so the pin test injects torch.nn.L1Loss there)
     or, with opt['vgg'] = a VGG19 state_dict, VGGLoss (--use_vgg) --, the mask term (MSE, or BCE with opt['mask_bce']),
     mask total variation.  opt['bg_both']: BGNet ran on 2N inputs and the transferred image blends with the second half
-    (:336-339).  No style / face terms.
+    (:336-339).  opt['face'] = a Sphere20a state_dict: the face term on the head crops batch['head_bbox'] (--use_face,
+    :383-385).  No style term.
     batch: input_G_bg (N or 2N,4,H,W), input_G_src, input_G_tsf (N,6,H,W), T (N,H,W,2), real_src, real_tsf (N,3,H,W),
     bg_mask (2N,1,H,W).  Returns (total, dict of terms, (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks))."""
     o = dict(G_TRAIN_DEFAULTS)
@@ -525,6 +563,8 @@ def generator_train_loss(gsd, dsd, batch, opt=None, align_corners=False):
         g_rec=F.l1_loss(fake_src_imgs, batch["real_src"]) * o["lambda_rec"],
         g_tsf=tsf_term * o["lambda_tsf"],
         g_mask=mask_term * o["lambda_mask"],
+        **({"g_face": face_loss(o["face"], fake_tsf_imgs, batch["real_tsf"], batch["head_bbox"]) * o.get("lambda_face", 1.0)}
+           if o.get("face") else {}),
         g_mask_smooth=(torch.mean(torch.abs(fake_masks[:, :, :, :-1] - fake_masks[:, :, :, 1:])) +
                        torch.mean(torch.abs(fake_masks[:, :, :-1, :] - fake_masks[:, :, 1:, :]))) * o["lambda_mask_smooth"])
     return sum(terms.values()), terms, (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)

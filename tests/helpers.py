@@ -79,6 +79,25 @@ def vgg19_state_dict(seed=0):
     return sd
 
 
+def sphere20a_state_dict(seed=0):
+    """Random Sphere20a (networks/facenet.py:200-262) in its own state_dict naming -- the real file
+    (sphere20a_20171020.pth) is a download; He-scaled convs, PReLU slopes around 0.25."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd, cin = {}, 3
+    for st, c, units in (("1", 64, 1), ("2", 128, 2), ("3", 256, 4), ("4", 512, 1)):
+        for j in range(1, 2 + 2 * units):
+            name = "%s_%d" % (st, j)
+            ci = cin if j == 1 else c
+            sd["conv%s.weight" % name] = torch.randn(c, ci, 3, 3, generator=g) * (1.0 / (9 * ci)) ** 0.5
+            sd["conv%s.bias" % name] = torch.randn(c, generator=g) * 0.05
+            sd["relu%s.weight" % name] = 0.25 + 0.1 * torch.rand(c, generator=g)
+        cin = c
+    sd["fc5.weight"] = torch.randn(512, 512 * 7 * 6, generator=g) * (1.0 / (512 * 42)) ** 0.5
+    sd["fc5.bias"] = torch.randn(512, generator=g) * 0.05
+    return sd
+
+
 def train_batch(seed=0, n=2, size=64, bg_both=False):
     """Seeded stand-in for what the reference's BodyRecoveryFlow hands the trainer (impersonator_trainer.py:300-319);
     bg_both: the background input carries the source's and the target's (2n images, :333-337)."""

@@ -109,6 +109,57 @@ def test_training_script_flags(setup, conv_precision):
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
 
 
+def test_face_loss_and_gradient():
+    """SphereFaceLoss.loss_and_grad (head crops, Sphere20a on the op-level kernels, fc5) against autograd through the
+    oracle's restatement in float64 (pinned to the reference's FaceLoss / Sphere20a in tests/test_oracle_vs_reference.py)."""
+    from impersonator_amd.networks.facenet import SphereFaceLoss
+    fsd = helpers.sphere20a_state_dict(seed=6)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    y = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    bbox = torch.tensor([[30, 90, 10, 70], [44, 101, 3, 58]])
+    xr = x.double().requires_grad_(True)
+    loss = torch_ref.face_loss({k: v.double() for k, v in fsd.items()}, xr, y.double(), bbox)
+    loss.backward()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    v, d = SphereFaceLoss(fsd).loss_and_grad(nhwc(x), nhwc(y), bbox)
+    assert abs(float(v) - float(loss.detach())) < 1e-5 * max(1.0, float(loss.detach())), (float(v), float(loss.detach()))
+    got = d.cpu().permute(0, 3, 1, 2).double()
+    assert float(got[0, :, :10].abs().max()) == 0.0                      # outside the head box: no gradient
+    rel = float((got - xr.grad).norm() / xr.grad.norm())
+    assert rel < 5e-3, rel                                                # sign() / PReLU kinks: norm-wise, as for VGG
+
+
+def test_training_with_the_face_term(setup):
+    """--use_face on top of --mask_bce --use_vgg: scripts/train_iPER.sh's loss, against the oracle."""
+    from impersonator_amd.models.generator_trainer import GeneratorTrainer
+    from impersonator_amd.networks.facenet import SphereFaceLoss
+    from impersonator_amd.networks.vgg import Vgg19Perceptual
+    ref_tr = setup["tr"]
+    vsd, fsd = helpers.vgg19_state_dict(seed=4), helpers.sphere20a_state_dict(seed=6)
+    b = helpers.train_batch(seed=5, n=2, size=64)
+    b["head_bbox"] = torch.tensor([[8, 40, 2, 30], [20, 58, 5, 41]])
+    o = dict(mask_bce=True, vgg=vsd, face=fsd, lambda_face=5.0, lambda_mask=1.0, lambda_mask_smooth=1.0)
+    tr = GeneratorTrainer(ref_tr.generator, ref_tr.D, lambda_mask=1.0, lambda_mask_smooth=1.0, mask_bce=True,
+                          vgg=Vgg19Perceptual(vsd), face=SphereFaceLoss(fsd), lambda_face=5.0)
+    tr.forward(b)
+    mine = tr.backward()
+    with torch.no_grad():
+        _, terms, _ = torch_ref.generator_train_loss(setup["gsd"], setup["dsd"], b, o)
+    assert set(mine) == set(terms)
+    for k, v in terms.items():
+        assert abs(float(mine[k]) - float(v)) < 2e-4 * max(1.0, abs(float(v))), (k, float(mine[k]), float(v))
+    dbl = lambda d: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+    _, grads64, _ = torch_ref.generator_train_steps(dbl(setup["gsd"]), dbl(setup["dsd"]), [dbl(b)], dict(o, vgg=dbl(vsd), face=dbl(fsd)))
+    grads = tr.gradients()
+    num = den = 0.0
+    for k, g in grads64.items():
+        e = grads[k].double() - g
+        num += float((e * e).sum())
+        den += float((g.double() ** 2).sum())
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
 def test_vgg_perceptual_loss_and_gradient():
     """Vgg19Perceptual.loss_and_grad against autograd through the oracle's VGG19 (float64), both conv precisions."""
     from impersonator_amd.networks.vgg import Vgg19Perceptual

@@ -243,6 +243,26 @@ def test_generator_train_loss_with_the_training_scripts_flags(ref):
         assert torch.allclose(p.grad, grads[k], atol=1e-6 + 1e-4 * float(p.grad.abs().max()), rtol=0), k
 
 
+def test_face_loss_matches_reference(ref, tmp_path):
+    """oracle face_loss == the reference's FaceLoss (networks/networks.py:211-312) + Sphere20a (networks/facenet.py), loaded
+    the reference's way from a .pth with seeded weights (the real file is a download), value and gradient."""
+    fsd = helpers.sphere20a_state_dict(seed=6)
+    path = str(tmp_path / "sphere20a_seeded.pth")
+    torch.save(dict(fsd, **{"fc6.weight": torch.zeros(4, 512)}), path)     # load_sphere_model drops fc6.*
+    crit = ref.networks.FaceLoss(pretrained_path=path)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(2, 3, 128, 128, generator=g) * 2 - 1).requires_grad_(True)
+    y = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    bbox = torch.tensor([[30, 90, 10, 70], [44, 101, 3, 58]])
+    theirs = crit(x, y, bbox1=bbox, bbox2=bbox)
+    theirs.backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    mine = torch_ref.face_loss(fsd, x2, y, bbox)
+    mine.backward()
+    assert abs(float(theirs) - float(mine)) < 1e-6 * max(1.0, float(mine))
+    assert torch.allclose(x.grad, x2.grad, atol=1e-9 + 1e-5 * float(x.grad.abs().max()), rtol=0)
+
+
 def test_body_recovery_flow_restatement_matches_reference(ref):
     """BodyRecoveryFlow.forward (models/impersonator_trainer.py:44-87), the trainer's input preparation, run unbound on a
     stub that carries the reference's own SMPLRenderer methods and the CPU SMPL (batch of 2 source / target pairs)."""
