@@ -1108,6 +1108,13 @@ ConvArgs base_args(const float *x, int ldx, int N, int H, int Cin, const float *
     return a;
 }
 
+// 128-channel tiles once they give every CU a workgroup, else twice as many 64-channel ones (the 15x15 and 14x14 maps of the
+// last layers are 15 row tiles: 60 workgroups of 128 channels on 256 CUs)
+int d_tile_width(int mtiles, int cout)
+{
+    return (cout % 128 == 0 && (long)mtiles * (cout / 128) >= device_cu_count()) ? 128 : 64;
+}
+
 // forward conv of layer l on `x` (2N images): raw = conv(x) + bias
 int d_conv_forward(lwg_discriminator *d, int l, const float *x, int B, hipStream_t st)
 {
@@ -1119,7 +1126,7 @@ int d_conv_forward(lwg_discriminator *d, int l, const float *x, int B, hipStream
     a.nphase = 1;
     a.ph[0] = ConvPhase{4, 4, 16, 16 * L.cin_pad, 0, 0, 0, 0, 0};
     a.mtiles = ceil_div((long)B * L.Ho * L.Ho, kConvBM);
-    return launch_conv_igemm(a, L.cout_pad % 128 == 0 ? 128 : 64, st);
+    return launch_conv_igemm(a, d_tile_width(a.mtiles, L.cout_pad), st);
 }
 
 // data gradient of layer l: dact[l-1] = conv^T(draw[l])
@@ -1143,7 +1150,7 @@ int d_conv_dgrad(lwg_discriminator *d, int l, int B, hipStream_t st)
         }
     }
     a.mtiles = ceil_div((long)B * a.Hm * a.Wm, kConvBM);
-    return launch_conv_igemm(a, L.cin_pad % 128 == 0 ? 128 : 64, st);
+    return launch_conv_igemm(a, d_tile_width(a.mtiles, L.cin_pad), st);
 }
 
 int d_refresh_dgrad_weights(lwg_discriminator *d, hipStream_t st)
