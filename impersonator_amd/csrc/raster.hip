@@ -7,9 +7,10 @@
 // bit-identical to the uncontracted (no fused multiply-add) evaluation of the .cu file's float expressions.
 //
 // Design (MI355X-first, not a translation).  The reference tests 65536 x 13776 pixel/face pairs per frame; SMPL faces
-// cover ~2 pixels each.  Two launches, no global atomics, no depth buffer in memory, no clear pass:
-//   1. setup kernel, one lane per (frame, face): [vertex gather + orthographic projection + y flip + look_at shift,
-//      when called from lwg_transfer_frame], back-face cull, inverse matrix (.cu:40-84), conservative pixel box, and
+// cover ~2 pixels each.  Two launches (three from lwg_transfer_frame), no global atomics, no depth buffer in memory, no
+// clear pass:
+//   0. (lwg_transfer_frame) projection kernel: vertex gather + orthographic projection + y flip + look_at shift -> f2verts;
+//   1. setup kernel, one lane per (frame, face): back-face cull, inverse matrix (.cu:40-84), conservative pixel box, and
 //      that box in units of tiles, packed in 4 bytes.  Culled / off-screen faces get an empty box.
 //   2. tile kernel, one workgroup per 32x8-pixel tile (a tile row is one 128-byte line of every per-pixel plane):
 //        a. the workgroup streams the frame's packed tile boxes (4 B per face, 16 B per lane and load, L2-resident:
@@ -18,17 +19,19 @@
 //           visibility with a 64-bit LDS atomic min per covered pixel on the key (orderable(zp) << 32 | face_id):
 //           the lexicographic minimum is exactly the reference's "strictly smaller depth, lowest face index wins
 //           ties" rule (hazard H6), whatever the order faces are visited in.  The z-buffer (2 KB) lives and dies
-//           in the workgroup's LDS; faces whose clipped box is large are swept by all 256 lanes instead;
+//           in the workgroup's LDS; faces whose clipped box is large (slivers: the whole tile) are swept by all 256
+//           lanes, one pixel each, instead;
 //        c. one lane per pixel decodes the winner, recomputes its barycentrics with the same float expression
 //           sequence and writes fim/wim/depth (vertically flipped, rasterize.py:334-338) and, in the fused per-frame
 //           path, cond = map_fn[fim], the flow T, the warped source image and the generator's NHWC8 input --
 //           five reference passes -- with plain stores.
 //      The list holds 4096 faces; a tile that more faces touch (a mesh shrunk to a few pixels, a frame full of
 //      slivers) flushes it through step b and keeps scanning, so every face count is handled without a fallback.
-// Nothing a kernel of another stream could disturb survives between launches except the per-face records (plain
-// stores in launch 1, plain loads in launch 2, ordinary stream order), which makes the entry points re-entrant and
-// safe to overlap with anything: an earlier face-parallel version kept the depth keys in global memory and updated
-// them with device-scope atomics, and rarely showed a stale 128-byte line of keys when other streams were busy.
+// Nothing survives between launches except f2verts and the per-face records (plain stores in one launch, plain loads
+// in the next, ordinary stream order): the entry points are re-entrant.  Two code shapes of earlier versions -- the
+// projection fused into the setup kernel, and a wave-per-face pixel loop for the large faces -- computed wrong values
+// in single quarter-waves whenever conv_igemm_bf16x3 workgroups shared their CUs (DESIGN.md section 5.1 has the
+// bisection); the present shapes have run 6000 batches beside those kernels without a differing pixel.
 // Work per frame drops from 9.0e8 pair tests to ~2e5 plus 3.5e6 four-byte box tests.
 //
 // Exactness: this file is compiled with -ffp-contract=off and evaluates the .cu file's expressions in the same
@@ -162,15 +165,12 @@ Tiling tiling_for(int is)
 }
 
 // One lane per (frame, face slot); slots nf .. nfp-1 of a frame are padding (nfp = nf rounded up to 4, so that the
-// tile kernel can fetch four packed boxes with one aligned 16-byte load) and only receive an empty box.
-// kProject: the face's vertices are gathered from the posed mesh and projected (utils/nmr.py:10-28 + :271, look_at.py
-// with the identity rotation of nmr.py:177, vertices_to_faces.py) and written to `faces` = f2verts; otherwise `faces`
-// is the input.
-template <bool kProject>
-__global__ __launch_bounds__(256) void raster_setup_kernel(const float *__restrict__ verts,
-                                                           const float *__restrict__ cam,
-                                                           const int32_t *__restrict__ faces_idx, int nv, float eye_z,
-                                                           float *__restrict__ faces, int bs, int nf, int nfp, int is,
+// tile kernel can fetch four packed boxes with one aligned 16-byte load) and only receive an empty box.  `faces` = f2verts:
+// given by the caller, or written just before by project_faces_kernel.  (Round 2 first fused that projection in here,
+// gather + stores ahead of the record arithmetic.  That form computed wrong records for single quarter-waves while
+// conv_igemm_bf16x3 workgroups ran on the same CUs -- never alone, never beside other kernels, cause not found; the
+// two-kernel form has shown none in 6000 overlapped batches: DESIGN.md section 5.1.)
+__global__ __launch_bounds__(256) void raster_setup_kernel(const float *__restrict__ faces, int bs, int nf, int nfp, int is,
                                                            Tiling tl, float *__restrict__ faces_inv,
                                                            Box *__restrict__ pbox, unsigned *__restrict__ tbox)
 {
@@ -181,21 +181,8 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const float *__restri
     if (fn < nf) {
         const size_t t = (size_t)b * nf + fn;
         float v[9];
-        if (kProject) {
-            const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float *p = verts + ((size_t)b * nv + faces_idx[fn * 3 + k]) * 3;
-                v[3 * k + 0] = s * (p[0] + tx);          // utils/nmr.py:24
-                v[3 * k + 1] = -(s * (p[1] + ty));       // utils/nmr.py:24 then :271
-                v[3 * k + 2] = p[2] - eye_z;             // look_at.py:58-60 with the identity rotation of nmr.py:177
-            }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) faces[t * 9 + k] = v[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) v[k] = faces[t * 9 + k];
-        }
+        for (int k = 0; k < 9; ++k) v[k] = faces[t * 9 + k];
         if (!backside(v)) {
             float px[3], py[3], inv[9], det;
             face_inverse(v, is, px, py, inv, det);
@@ -258,7 +245,7 @@ __device__ __forceinline__ void shade_pixel(const float v[9], const float inv[9]
     atomicMin(key, ((unsigned long long)order_bits(zp) << 32) | (unsigned)fn);
 }
 
-constexpr int kBigCap = 256;   // faces with a large footprint in the tile that get a wave each (more: all-lane sweep)
+constexpr int kBigCap = 256;   // large-footprint faces of a tile kept in their own list (more: tagged in the main list)
 
 __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__restrict__ faces,
                                                                const float *__restrict__ faces_inv,
@@ -299,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
             if (x0 > x1 || y0 > y1) continue;      // the packed box is coarser than the pixel box
             if ((x1 - x0 + 1) * (y1 - y0 + 1) > kInlineBoxMax) {
                 const int slot = atomicAdd(&sh_nbig, 1);
-                if (slot < kBigCap) sh_big[slot] = fn;            // a wave will sweep it
+                if (slot < kBigCap) sh_big[slot] = fn;            // swept by all lanes after the barrier
                 else sh_list[e] = fn | (int)0x80000000;           // left for the all-lane sweep
                 continue;
             }
@@ -315,35 +302,25 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
         __syncthreads();
         const int nbig = sh_nbig;
         if (!nbig) return;
-        // faces with a large footprint in this tile (at most the 256 pixels of the tile each): one wave per face
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int e = wave; e < min(nbig, kBigCap); e += kThreads / 64) {
-            const int fn = __builtin_amdgcn_readfirstlane(sh_big[e]);
-            const Box bx = fb[fn];
-            const int x0 = max((int)bx.x0, ox), x1 = min((int)bx.x1, ex);
-            const int y0 = max((int)bx.y0, oy), y1 = min((int)bx.y1, ey);
-            const int bw = x1 - x0 + 1, area = bw * (y1 - y0 + 1);
-            float v[9], inv[9];
-            load_face(fv, fi, fn, v, inv);
-            for (int p = lane; p < area; p += 64) {
-                const int yy = p / bw, xi = x0 + (p - yy * bw), yi = y0 + yy;
-                shade_pixel(v, inv, fn, xi, yi, sh_xp[xi - ox], sh_yp[yi - oy], near_z, far_z,
-                            &sh_key[(yi - oy) * kTileW + (xi - ox)]);
-            }
-        }
-        if (nbig <= kBigCap) return;
-        // more of them than the wave list holds (a frame full of slivers): all lanes, one pixel each, entry by entry
+        // Faces with a large footprint in this tile (the whole-image boxes of slivers, in practice): all lanes, one pixel
+        // each, face by face -- first the ones that fitted sh_big, then (a frame full of slivers) the tagged list entries.
+        // (Round 2 swept them a wave per face with a pixel loop per lane.  That loop produced wrong hits in single
+        // quarter-waves while conv_igemm_bf16x3 workgroups ran beside it on the CU -- never alone, never with other
+        // neighbours, cause not found: DESIGN.md section 5.1.  The straight-line form below has shown none.)
         const int lx = tid & (kTileW - 1), ly = tid / kTileW;
-        for (int e = 0; e < n; ++e) {
-            const int tagged = sh_list[e];
-            if (tagged >= 0) continue;
-            const int fn = __builtin_amdgcn_readfirstlane(tagged & 0x7fffffff);
+        const int xi = ox + lx, yi = oy + ly;
+        auto sweep = [&](int fn) {
             const Box bx = fb[fn];
-            const int xi = ox + lx, yi = oy + ly;
-            if (xi < (int)bx.x0 || xi > (int)bx.x1 || yi < (int)bx.y0 || yi > (int)bx.y1 || xi > ex || yi > ey) continue;
+            if (xi < (int)bx.x0 || xi > (int)bx.x1 || yi < (int)bx.y0 || yi > (int)bx.y1 || xi > ex || yi > ey) return;
             float v[9], inv[9];
             load_face(fv, fi, fn, v, inv);
             shade_pixel(v, inv, fn, xi, yi, sh_xp[lx], sh_yp[ly], near_z, far_z, &sh_key[tid]);
+        };
+        for (int e = 0; e < min(nbig, kBigCap); ++e) sweep(__builtin_amdgcn_readfirstlane(sh_big[e]));
+        if (nbig <= kBigCap) return;
+        for (int e = 0; e < n; ++e) {
+            const int tagged = sh_list[e];
+            if (tagged < 0) sweep(__builtin_amdgcn_readfirstlane(tagged & 0x7fffffff));
         }
     };
 
@@ -376,8 +353,15 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned tb0 = qq[k];
-                if (cx >= (tb0 & 255u) && cy >= ((tb0 >> 8) & 255u) && cx <= ((tb0 >> 16) & 255u) && cy <= (tb0 >> 24))
-                    sh_list[atomicAdd(&sh_n, 1)] = f + k;
+                const bool hit = cx >= (tb0 & 255u) && cy >= ((tb0 >> 8) & 255u) && cx <= ((tb0 >> 16) & 255u) && cy <= (tb0 >> 24);
+                // one list allocation per wave: lane 0 reserves the wave's hits, the lanes place theirs by rank
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+                if (bal) {
+                    int base = 0;
+                    if ((tid & 63) == 0) base = atomicAdd(&sh_n, __builtin_popcountll(bal));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (hit) sh_list[base + __builtin_popcountll(bal & ((1ull << (tid & 63)) - 1ull))] = f + k;
+                }
             }
         }
         f0 += room * kScanStep;
@@ -554,12 +538,11 @@ int run_raster(const float *verts, const float *cam, const int32_t *faces_idx, i
     const Tiling tl = tiling_for(is);
     const int nfp = padded_faces(nf);
     const int setup_blocks = ceil_div((long)bs * nfp, 256);
-    if (verts)
-        raster_setup_kernel<true><<<setup_blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, nfp, is,
-                                                                 tl, w.faces_inv, w.pbox, w.tbox);
-    else
-        raster_setup_kernel<false><<<setup_blocks, 256, 0, st>>>(nullptr, nullptr, nullptr, 0, 0.f, faces, bs, nf, nfp,
-                                                                  is, tl, w.faces_inv, w.pbox, w.tbox);
+    if (verts) {
+        project_faces_kernel<<<ceil_div((long)bs * nf * 3, 256), 256, 0, st>>>(verts, cam, faces_idx, bs, nv, nf, eye_z, faces);
+        LWG_LAUNCH_CHECK("project_faces_kernel");
+    }
+    raster_setup_kernel<<<setup_blocks, 256, 0, st>>>(faces, bs, nf, nfp, is, tl, w.faces_inv, w.pbox, w.tbox);
     LWG_LAUNCH_CHECK("raster_setup_kernel");
     raster_tile_kernel<<<bs * tl.tiles_x * tl.tiles_y, kThreads, 0, st>>>(faces, w.faces_inv, w.pbox, w.tbox, nf, nfp, is,
                                                                            tl, near_z, far_z, out);

@@ -216,6 +216,8 @@ class Imitator(BaseModel):
     # latency-bound at these sizes) and the lanes drain once per round; tools/depth_bench.py at batch 8, two lanes:
     # depth 1 2709, 2 2772, 3 2799, 4 2811 frames/s in one process.  env LWG_ROUND_DEPTH
     round_depth = 4
+    # the next round's geometry runs underneath this round's generators (False: waits for them)
+    overlap_geometry = True
 
     def _lanes(self, n):
         """n (stream, generator) pairs, each with its own HIP stream; lane 0 drives self.generator, the others an
@@ -230,29 +232,26 @@ class Imitator(BaseModel):
         return have[:n]
 
     @torch.no_grad()
-    def predict_batches(self, batches, cam_strategy='smooth', lanes=None, _overlap_geometry=False):
+    def predict_batches(self, batches, cam_strategy='smooth', lanes=None, overlap_geometry=None):
         """Yields (t, preds) for every (tgt_smpls_chunk, t) of `batches`, in order.  Frames are independent once the
-        source is personalised, so consecutive batches are processed in rounds of `lanes`:
-          1. the geometry of the round's batches (`lanes * round_depth` of them: swap_smpl, SMPL, rasteriser, flow, image
-             warp -- a dozen small, latency-bound kernels) runs as ONE launch sequence over all the round's frames on a
-             side stream, *with no generator running*;
+        source is personalised, so consecutive batches are processed in rounds of `lanes * round_depth`:
+          1. the geometry of the round's batches (swap_smpl, SMPL, projection, rasteriser, flow, image warp -- a dozen
+             small, latency-bound kernels) runs as ONE launch sequence over all the round's frames on a side stream;
           2. their generators then run side by side, each on its own stream and engine (scratch): a layer is
              conv -> finalize -> apply, every launch waiting for the one before, and the idle tails and launch gaps
              of one chain are filled by the other's kernels (+15 % frames/s at batch 8 with two lanes; a third adds
              1 %).
-        The next round's geometry waits for this round's generators.  That barrier is deliberate and measured
-        (DESIGN.md section 5.1): while bf16x3 convolution kernels of *other* HIP queues are running, the per-face
-        records one geometry kernel hands to the next through memory are occasionally read stale in 16-lane groups
-        (wrong pixels in ~90 % of six-batch passes, tools/lane_stress.py with overlap=1) -- with exact-fp32
-        generators, with one hardware queue, or with the geometry on its own, never.  It is a property of the
-        platform under that load, not of the rasteriser's algorithm (the round-1 rasteriser with global atomics and
-        the tile-owned one show it alike), so the pipeline does not create the situation; `_overlap_geometry=True`
-        exists for tools/lane_stress.py to reproduce it.  Events order every hand-over; round r+1 is enqueued before
+        The geometry of round r+1 runs underneath the generators of round r (`overlap_geometry`, default
+        Imitator.overlap_geometry = True; False makes it wait for them: the strictly alternating order).  Until the end
+        of round 2 that overlap produced wrong pixels in ~90 % of passes; the cause was two code shapes in the
+        rasteriser that miscompute beside the bf16x3 convolution kernels, both replaced --
+        tools/lane_stress.py: 0 differing batches in 6000.  Events order every hand-over; round r+1 is enqueued before
         round r is yielded, so a consumer that synchronises on a result (device->host copy) does not drain the
         pipeline.  Same results as transfer_params_by_smpl + forward per batch."""
         import os
         nl = max(1, int(lanes if lanes is not None else os.environ.get("LWG_LANES", self.lanes)))
         depth = max(1, int(os.environ.get("LWG_ROUND_DEPTH", self.round_depth)))
+        overlap = self.overlap_geometry if overlap_geometry is None else bool(overlap_geometry)
         main = torch.cuda.current_stream()
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
@@ -267,7 +266,7 @@ class Imitator(BaseModel):
             per lane; returns [(t, preds, info, done_event)]"""
             prepared = []
             with torch.cuda.stream(side):
-                if not _overlap_geometry:
+                if not overlap:
                     for ev in prev_done:
                         side.wait_event(ev)
                 sizes = [int(chunk.shape[0]) if chunk.dim() > 1 else 1 for chunk, _ in items]

@@ -144,11 +144,12 @@ def test_stream_pipeline_equals_the_sequential_path(imi, lanes):
     assert len(list(imitator.predict_batches(iter(chunks[:1]), "smooth", lanes=lanes))) == 1
 
 
-def test_lane_pipeline_stress(imi):
-    """Thirty passes of the two-lane pipeline with a consumer that never synchronises (tools/lane_stress.py in small):
-    with the geometry overlapping bf16x3 generators of other streams the geometry kernels read stale per-face records
-    (DESIGN.md section 5.1); the round structure of predict_batches never creates that situation and must stay at
-    zero differences."""
+@pytest.mark.parametrize("depth,overlap", [(1, True), (4, True), (1, False)])
+def test_lane_pipeline_stress(imi, depth, overlap):
+    """Thirty passes of the two-lane pipeline with a consumer that never synchronises (tools/lane_stress.py in small).
+    depth 1 + overlap: every round's geometry runs underneath the previous round's bf16x3 generators -- the situation
+    that produced wrong pixels in ~90 % of passes until two code shapes in the rasteriser were replaced (DESIGN.md
+    section 5.1); the default (depth 4, overlap) and the strictly alternating order must be just as clean."""
     imitator = imi[0]
     smpls = torch.from_numpy(demo.synthetic_smpls(24, seed=5)).cuda()
     imitator.first_cam = smpls[0:1, 0:3].clone()
@@ -157,9 +158,13 @@ def test_lane_pipeline_stress(imi):
     for chunk, t in chunks:
         x = imitator.transfer_params_by_smpl(chunk, "smooth", t=t)
         seq.append(imitator.forward(x, imitator.tsf_info["T"]).clone())
-    for _ in range(30):
-        got = [p.clone() for _, p in imitator.predict_batches(iter(chunks), "smooth", lanes=2)]
-        torch.cuda.synchronize()
-        for p, q in zip(got, seq):
-            assert torch.equal(p, q)
-
+    keep = imitator.round_depth
+    imitator.round_depth = depth
+    try:
+        for _ in range(30):
+            got = [p.clone() for _, p in imitator.predict_batches(iter(chunks), "smooth", lanes=2, overlap_geometry=overlap)]
+            torch.cuda.synchronize()
+            for p, q in zip(got, seq):
+                assert torch.equal(p, q)
+    finally:
+        imitator.round_depth = keep

@@ -265,3 +265,36 @@ def test_argument_errors_are_reported_not_swallowed():
     r = _renderer()
     with pytest.raises(RuntimeError):
         r.render_fim_wim(torch.zeros(1, 3), torch.zeros(1, 6890, 3))   # CPU tensors: no fallback
+
+
+def test_rasteriser_beside_bf16x3_convolutions():
+    """The regression test of DESIGN.md section 5.1: SMPLRenderer.transfer and .rasterize on fixed inputs while
+    conv_igemm_bf16x3 runs on two other streams.  Until the end of round 2 this gave wrong pixels in 25 % (rasterize:
+    sliver faces painted by the wave-per-face sweep) to 99 % (transfer: groups of 16 faces missing, projection fused into
+    the setup kernel) of the launches."""
+    from impersonator_amd import demo, ops
+    im, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=8, seed=0, affine="random")
+    im.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+    smpls = torch.from_numpy(demo.synthetic_smpls(48, seed=3)).cuda()
+    im.first_cam = smpls[0:1, 0:3].clone()
+    im.transfer_params_by_smpl(smpls[32:48], "smooth", t=32)
+    cam, verts, si = im.tsf_info["cam"].clone(), im.tsf_info["verts"].clone(), im.src_info
+    ref = {k: v.clone() for k, v in im.render.transfer(cam, verts, si["p2verts"], si["img"]).items()}
+    f2v = ref["f2verts"].clone()
+    fim_ref = im.render.rasterize(f2v)[0].clone()
+    xx, ww = torch.randn(8, 32, 32, 512, device="cuda"), torch.randn(512, 512, 3, 3, device="cuda") * 0.02
+    lanes, side = [torch.cuda.Stream(), torch.cuda.Stream()], torch.cuda.Stream()
+    torch.cuda.synchronize()
+    bad = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for _ in range(60):
+        for st in lanes:
+            with torch.cuda.stream(st):
+                for _ in range(12):
+                    ops.conv2d_forward(xx, ww, None, 1, 1, precision="bf16x3")
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                out = im.render.transfer(cam, verts, si["p2verts"], si["img"])
+                bad[0] += sum((out[k] != ref[k]).sum() for k in ("f2verts", "fim", "wim", "T", "tsf_img"))
+                bad[1] += (im.render.rasterize(f2v)[0] != fim_ref).sum()
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0, 0]

@@ -17,8 +17,9 @@ smpls = torch.from_numpy(demo.synthetic_smpls(1024, seed=0)).cuda()
 im.first_cam = smpls[0:1, 0:3].clone()
 
 
-def run(n, lanes, depth):
+def run(n, lanes, depth, overlap=True):
     im.round_depth = depth
+    im.overlap_geometry = overlap
     out = None
     chunks = ((smpls[(i % 128) * 8:(i % 128) * 8 + 8], (i % 128) * 8) for i in range(n))
     for _, out in im.predict_batches(chunks, "smooth", lanes=lanes):
@@ -26,7 +27,7 @@ def run(n, lanes, depth):
     return out
 
 
-settings = [(2, 1), (2, 2), (2, 3), (2, 4), (3, 1), (3, 2)]
+settings = [(2, 1, True), (2, 2, True), (2, 4, True), (2, 4, False), (2, 1, False), (3, 2, True), (3, 4, True)]
 for s in settings:
     run(24, *s)
 torch.cuda.synchronize()
@@ -40,4 +41,4 @@ for r in range(reps):
         res[s].append(steps * 8 / (time.perf_counter() - t0))
 for s in settings:
     v = sorted(res[s])
-    print("lanes %d depth %d: median %.0f fps (min %.0f max %.0f)" % (s[0], s[1], v[len(v) // 2], v[0], v[-1]))
+    print("lanes %d depth %d overlap %d: median %.0f fps (min %.0f max %.0f)" % (s[0], s[1], s[2], v[len(v) // 2], v[0], v[-1]))

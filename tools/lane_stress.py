@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 bad = tot = 0
 for p in range(passes):
     for nl in lane_counts:
-        got = [q.clone() for _, q in im.predict_batches(iter(chunks), "smooth", lanes=nl, _overlap_geometry=OVERLAP)]   # no sync per batch
+        got = [q.clone() for _, q in im.predict_batches(iter(chunks), "smooth", lanes=nl, overlap_geometry=OVERLAP)]   # no sync per batch
         torch.cuda.synchronize()
         tot += 1
         for k, (a, b) in enumerate(zip(got, seq)):

@@ -51,7 +51,7 @@ count = {}
 shown = 0
 for p in range(passes):
     got = []
-    for _, q in im.predict_batches(iter(chunks), "smooth", lanes=nl, _overlap_geometry=OVERLAP):
+    for _, q in im.predict_batches(iter(chunks), "smooth", lanes=nl, overlap_geometry=OVERLAP):
         d = {k: im.tsf_info[k].clone() for k in KEYS}
         d["pred"] = q.clone()
         got.append(d)
