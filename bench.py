@@ -283,7 +283,8 @@ def main():
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             stamp = tj.get("_stamp", {})
-            t = tj.get(name)
+            # rocprofv3 prints every template argument (the tile height too), the variant table of the library does not
+            t = tj.get(name) or next((v for k, v in tj.items() if k.startswith(name.rstrip('>') + ',')), None)
             if stamp.get("csrc_sha256") != csrc_digest():
                 block["traffic_note"] = ("profiles/%s was measured on other kernel sources (stamp %s..., now %s...): "
                                          "not attached" % (TRAFFIC_FILE, str(stamp.get("csrc_sha256"))[:10], csrc_digest()[:10]))
