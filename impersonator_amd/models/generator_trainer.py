@@ -139,7 +139,8 @@ class GeneratorTrainer(object):
 
     def __init__(self, generator, discriminator, lambda_D_prob=1.0, lambda_rec=10.0, lambda_tsf=10.0, lambda_mask=0.1,
                  lambda_mask_smooth=1e-5, lr=0.0002, betas=(0.5, 0.999), eps=1e-8, conv_precision="fp32", mask_bce=False,
-                 bg_both=False, vgg=None, face=None, lambda_face=1.0):
+                 bg_both=False, vgg=None, face=None, lambda_face=1.0, use_vgg=None, use_style=False,
+                 lambda_style=5.0):
         """conv_precision 'bf16x3': the convolutions of the three streams (forward, data gradient, weight gradient) run on
         split-bf16 operands (include/lwg.h, lwg_conv2d_desc.precision); norms, heads, losses, Adam: fp32."""
         if conv_precision not in ops.PRECISIONS:
@@ -148,8 +149,13 @@ class GeneratorTrainer(object):
         # impersonator_trainer.py:251-254 (--mask_bce: BCELoss on the masks), :333-339 (--bg_both: BGNet on the source's
         # and the target's background, 2N inputs), :256-260 + :376-377 (--use_vgg: `vgg` = networks.vgg.Vgg19Perceptual)
         # :268-273 + :383-385 (--use_face: `face` = networks.facenet.SphereFaceLoss; the batch then carries 'head_bbox')
+        # `vgg` also serves :262-267 + :379-381 (--use_style: Gram-matrix term, use_style=True); use_vgg=False keeps the L1
+        # transfer term while the network is only there for the style term
         self.mask_bce, self.bg_both, self.vgg, self.face = bool(mask_bce), bool(bg_both), vgg, face
-        self.lambda_face = lambda_face
+        self.use_vgg = (vgg is not None) if use_vgg is None else bool(use_vgg)
+        self.use_style, self.lambda_style, self.lambda_face = bool(use_style), lambda_style, lambda_face
+        if (self.use_vgg or self.use_style) and vgg is None:
+            raise ValueError("use_vgg / use_style need `vgg` (networks.vgg.Vgg19Perceptual)")
         self.generator, self.D = generator, discriminator
         self.lam = dict(adv=lambda_D_prob, rec=lambda_rec, tsf=lambda_tsf, mask=lambda_mask, smooth=lambda_mask_smooth)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
@@ -281,13 +287,17 @@ class GeneratorTrainer(object):
         diff_t = self.fake_tsf - to_nhwc(b["real_tsf"])
         terms["g_rec"] = diff_s.abs().mean() * lam["rec"]
         d_fs = torch.sign(diff_s) * (lam["rec"] / diff_s.numel())
-        if self.vgg is not None:
+        if self.use_vgg:
             v_loss, v_grad = self.vgg.loss_and_grad(self.fake_tsf.contiguous(), to_nhwc(b["real_tsf"]).contiguous())
             terms["g_tsf"] = v_loss * lam["tsf"]
             d_ft = d_ft + v_grad * lam["tsf"]
         else:
             terms["g_tsf"] = diff_t.abs().mean() * lam["tsf"]
             d_ft = d_ft + torch.sign(diff_t) * (lam["tsf"] / diff_t.numel())
+        if self.use_style:
+            s_loss, s_grad = self.vgg.style_loss_and_grad(self.fake_tsf.contiguous(), to_nhwc(b["real_tsf"]).contiguous())
+            terms["g_style"] = s_loss * self.lambda_style
+            d_ft = d_ft + s_grad * self.lambda_style
         if self.face is not None:
             f_loss, f_grad = self.face.loss_and_grad(self.fake_tsf.contiguous(), to_nhwc(b["real_tsf"]).contiguous(), b["head_bbox"])
             terms["g_face"] = f_loss * self.lambda_face

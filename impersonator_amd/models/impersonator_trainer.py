@@ -110,9 +110,7 @@ class Impersonator(BaseModel):
         #   --use_vgg : opt.vgg_weights = torch.save()d state_dict in torchvision's naming (what
         #               models.vgg19(pretrained=True).state_dict() is; the reference downloads it, networks/networks.py:133)
         #   --use_face: opt.face_model = the reference's own option (base_options.py:31, sphere20a_20171020.pth)
-        #   --use_style (lambda_style is 0 in the reference's training scripts): not implemented
-        if getattr(opt, 'use_style', False):
-            raise NotImplementedError("--use_style (Gram-matrix term) is not implemented")
+        #   --use_style: the Gram-matrix term over the same VGG19 (needs --vgg_weights too)
         self._face_state = None
         if getattr(opt, 'use_face', False):
             path = getattr(opt, 'face_model', None)
@@ -125,10 +123,10 @@ class Impersonator(BaseModel):
                                               "download of the reference)" % (path,))
                 self._face_state = torch.load(path, map_location='cpu')
         self._vgg_state = None
-        if getattr(opt, 'use_vgg', False):
+        if getattr(opt, 'use_vgg', False) or getattr(opt, 'use_style', False):
             path = getattr(opt, 'vgg_weights', None)
             if not path:
-                raise NotImplementedError("--use_vgg: pass --vgg_weights <vgg19 state_dict .pth> (torchvision's "
+                raise NotImplementedError("--use_vgg / --use_style: pass --vgg_weights <vgg19 state_dict .pth> (torchvision's "
                                           "vgg19(pretrained=True).state_dict(); there is no download here)")
             self._vgg_state = path if isinstance(path, dict) else torch.load(path, map_location='cpu')
         self._g_trainer = None
@@ -146,7 +144,8 @@ class Impersonator(BaseModel):
                 bg_both=getattr(o, 'bg_both', False),
                 vgg=(Vgg19Perceptual(self._vgg_state, getattr(o, 'conv_precision', 'fp32')) if self._vgg_state is not None else None),
                 face=(SphereFaceLoss(self._face_state) if self._face_state is not None else None),
-                lambda_face=getattr(o, 'lambda_face', 1))
+                lambda_face=getattr(o, 'lambda_face', 1), use_vgg=bool(getattr(o, 'use_vgg', False)),
+                use_style=bool(getattr(o, 'use_style', False)), lambda_style=getattr(o, 'lambda_style', 5))
         return self._g_trainer
 
     def sync_generator(self):

@@ -61,12 +61,8 @@ class Vgg19Perceptual(object):
             return y.add_(self.b[i]).clamp_(min=0)
         return ops.conv2d_forward(x, self.w[i], self.b[i], 1, 1).clamp_(min=0)
 
-    @torch.no_grad()
-    def loss_and_grad(self, x, y):
-        """x (generated), y (target): (N,H,W,3) NHWC on the device, H and W multiples of 16.
-        -> (sum_i w_i * mean|f_i(x) - f_i(y)|, its gradient wrt x (N,H,W,3))."""
-        n = x.shape[0]
-        z = torch.nn.functional.pad(torch.cat([x, y], dim=0), (0, 5)).contiguous()
+    def _features(self, z):
+        """the conv stack on an 8-channel NHWC batch; returns the trace the backward pass walks"""
         trace = []          # ('conv', index, output) / ('pool', input, output)
         for item in CFG:
             if item == "M":
@@ -76,17 +72,18 @@ class Vgg19Perceptual(object):
             else:
                 z = self._conv(z, item[0])
                 trace.append(("conv", item[0], z))
-        loss = torch.zeros((), device=x.device)
+        return trace
+
+    def _backward(self, trace, n, tap_grad):
+        """gradient wrt the first n images of the batch, given tap_grad(tap position, slice output) -> gradient wrt that
+        slice output's first n images"""
         d = None
         for kind, a, out in reversed(trace):
             if kind == "pool":
                 d = _pool_backward(a[:n], out[:n], d)
                 continue
             if a in TAPS:
-                diff = out[:n] - out[n:]
-                wgt = WEIGHTS[TAPS.index(a)]
-                loss += wgt * diff.abs().mean()
-                g = torch.sign(diff) * (wgt / diff.numel())
+                g = tap_grad(TAPS.index(a), out)
                 d = g if d is None else d + g
             d = (d * (out[:n] > 0)).contiguous()
             if a == 0:
@@ -94,4 +91,45 @@ class Vgg19Perceptual(object):
             else:
                 cin = self.w[a].shape[1]
                 d = ops.conv2d_backward_data(d, self.w[a], (n, d.shape[1], d.shape[2], cin), 1, 1, precision=self.precision)
-        return loss, d.contiguous()
+        return d.contiguous()
+
+    @torch.no_grad()
+    def loss_and_grad(self, x, y):
+        """VGGLoss.  x (generated), y (target): (N,H,W,3) NHWC on the device, H and W multiples of 16.
+        -> (sum_i w_i * mean|f_i(x) - f_i(y)|, its gradient wrt x (N,H,W,3))."""
+        n = x.shape[0]
+        trace = self._features(torch.nn.functional.pad(torch.cat([x, y], dim=0), (0, 5)).contiguous())
+        loss = torch.zeros((), device=x.device)
+
+        def tap_grad(i, out):
+            nonlocal loss
+            diff = out[:n] - out[n:]
+            loss += WEIGHTS[i] * diff.abs().mean()
+            return torch.sign(diff) * (WEIGHTS[i] / diff.numel())
+        return loss, self._backward(trace, n, tap_grad)
+
+    @torch.no_grad()
+    def style_loss_and_grad(self, x, y, size=224):
+        """StyleLoss.forward (networks/networks.py:414-423, weight 1): both images resized to 224x224 (nearest), then
+        sum_i mean|gram(f_i(x)) - gram(f_i(y))| / (H_i W_i) with gram(f) = f f^T per image.  -> (loss, gradient wrt x)."""
+        n, h, w, _ = x.shape
+        iy = (torch.arange(size, device=x.device) * h) // size        # F.interpolate(mode='nearest'): floor(i * in / out)
+        ix = (torch.arange(size, device=x.device) * w) // size
+        z = torch.cat([x, y], dim=0)[:, iy][:, :, ix]
+        trace = self._features(torch.nn.functional.pad(z, (0, 5)).contiguous())
+        loss = torch.zeros((), device=x.device)
+
+        def tap_grad(i, out):
+            nonlocal loss
+            b, hh, ww, c = out.shape
+            f = out.reshape(b, hh * ww, c)
+            gram = torch.bmm(f.transpose(1, 2), f)                       # (2n, c, c): a small library GEMM per level
+            diff = gram[:n] - gram[n:]
+            loss += diff.abs().mean() / (hh * ww)
+            s = torch.sign(diff) / (diff.numel() * hh * ww)
+            return torch.bmm(f[:n], s + s.transpose(1, 2)).reshape(n, hh, ww, c)
+        d224 = self._backward(trace, n, tap_grad)
+        dx = torch.zeros_like(x)
+        flat = (iy[:, None] * w + ix[None, :]).reshape(-1)               # nearest resize backward: scatter-add
+        dx.view(n, h * w, 3).index_add_(1, flat, d224.reshape(n, size * size, 3))
+        return loss, dx

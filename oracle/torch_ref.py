@@ -535,6 +535,17 @@ def face_loss(fsd, x, y, bbox):
     return sum(F.l1_loss(a, b.detach()) for a, b in zip(f1, f2))
 
 
+def style_loss(vsd, imgs, recon_imgs):
+    """StyleLoss.forward (networks/networks.py:414-423) with weight 1 and Vgg19 as the feature extractor
+    (impersonator_trainer.py:262-264)."""
+    def gram(x):
+        g = x.view(x.size(0), x.size(1), x.size(2) * x.size(3))
+        return torch.bmm(g, torch.transpose(g, 1, 2))
+    feats = vgg19_features(vsd, F.interpolate(imgs, (224, 224)))
+    recon = vgg19_features(vsd, F.interpolate(recon_imgs, (224, 224)))
+    return sum(torch.mean(torch.abs(gram(a) - gram(b))) / (a.size(2) * a.size(3)) for a, b in zip(feats, recon))
+
+
 def generator_train_loss(gsd, dsd, batch, opt=None, align_corners=False):
     """models/impersonator_trainer.py: forward (:329-348) + _optimize_G (:368-394): adversarial (LSGAN, target 0), L1
     reconstruction of the source, the transfer term -- L1 (what the `--use_vgg` help text calls the default; the
@@ -542,7 +553,7 @@ def generator_train_loss(gsd, dsd, batch, opt=None, align_corners=False):
     or, with opt['vgg'] = a VGG19 state_dict, VGGLoss (--use_vgg) --, the mask term (MSE, or BCE with opt['mask_bce']),
     mask total variation.  opt['bg_both']: BGNet ran on 2N inputs and the transferred image blends with the second half
     (:336-339).  opt['face'] = a Sphere20a state_dict: the face term on the head crops batch['head_bbox'] (--use_face,
-    :383-385).  No style term.
+    :383-385).  opt['style'] (needs opt['vgg']): the Gram-matrix style term (--use_style, :379-381).
     batch: input_G_bg (N or 2N,4,H,W), input_G_src, input_G_tsf (N,6,H,W), T (N,H,W,2), real_src, real_tsf (N,3,H,W),
     bg_mask (2N,1,H,W).  Returns (total, dict of terms, (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks))."""
     o = dict(G_TRAIN_DEFAULTS)
@@ -565,6 +576,8 @@ def generator_train_loss(gsd, dsd, batch, opt=None, align_corners=False):
         g_mask=mask_term * o["lambda_mask"],
         **({"g_face": face_loss(o["face"], fake_tsf_imgs, batch["real_tsf"], batch["head_bbox"]) * o.get("lambda_face", 1.0)}
            if o.get("face") else {}),
+        **({"g_style": style_loss(o["vgg"], fake_tsf_imgs, batch["real_tsf"]) * o.get("lambda_style", 5.0)}
+           if o.get("style") else {}),
         g_mask_smooth=(torch.mean(torch.abs(fake_masks[:, :, :, :-1] - fake_masks[:, :, :, 1:])) +
                        torch.mean(torch.abs(fake_masks[:, :, :-1, :] - fake_masks[:, :, 1:, :]))) * o["lambda_mask_smooth"])
     return sum(terms.values()), terms, (fake_bg, fake_src_imgs, fake_tsf_imgs, fake_masks)

@@ -131,7 +131,8 @@ def test_face_loss_and_gradient():
 
 
 def test_training_with_the_face_term(setup):
-    """--use_face on top of --mask_bce --use_vgg: scripts/train_iPER.sh's loss, against the oracle."""
+    """--use_face and --use_style on top of --mask_bce --use_vgg: scripts/train_iPER.sh's loss plus the style term (every
+    loss flag of the trainer), against the oracle."""
     from impersonator_amd.models.generator_trainer import GeneratorTrainer
     from impersonator_amd.networks.facenet import SphereFaceLoss
     from impersonator_amd.networks.vgg import Vgg19Perceptual
@@ -139,9 +140,9 @@ def test_training_with_the_face_term(setup):
     vsd, fsd = helpers.vgg19_state_dict(seed=4), helpers.sphere20a_state_dict(seed=6)
     b = helpers.train_batch(seed=5, n=2, size=64)
     b["head_bbox"] = torch.tensor([[8, 40, 2, 30], [20, 58, 5, 41]])
-    o = dict(mask_bce=True, vgg=vsd, face=fsd, lambda_face=5.0, lambda_mask=1.0, lambda_mask_smooth=1.0)
+    o = dict(mask_bce=True, vgg=vsd, face=fsd, lambda_face=5.0, lambda_mask=1.0, lambda_mask_smooth=1.0, style=True, lambda_style=5.0)
     tr = GeneratorTrainer(ref_tr.generator, ref_tr.D, lambda_mask=1.0, lambda_mask_smooth=1.0, mask_bce=True,
-                          vgg=Vgg19Perceptual(vsd), face=SphereFaceLoss(fsd), lambda_face=5.0)
+                          vgg=Vgg19Perceptual(vsd), face=SphereFaceLoss(fsd), lambda_face=5.0, use_style=True, lambda_style=5.0)
     tr.forward(b)
     mine = tr.backward()
     with torch.no_grad():
@@ -158,6 +159,25 @@ def test_training_with_the_face_term(setup):
         num += float((e * e).sum())
         den += float((g.double() ** 2).sum())
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
+def test_style_loss_and_gradient():
+    """Vgg19Perceptual.style_loss_and_grad (nearest resize to 224, Gram matrices per level) against autograd through the
+    oracle's restatement in float64 (pinned to the reference's StyleLoss in tests/test_oracle_vs_reference.py)."""
+    from impersonator_amd.networks.vgg import Vgg19Perceptual
+    vsd = helpers.vgg19_state_dict(seed=8)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 96, 96, generator=g) * 2 - 1
+    y = torch.rand(2, 3, 96, 96, generator=g) * 2 - 1
+    xr = x.double().requires_grad_(True)
+    loss = torch_ref.style_loss({k: v.double() for k, v in vsd.items()}, xr, y.double())
+    loss.backward()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    v, d = Vgg19Perceptual(vsd).style_loss_and_grad(nhwc(x), nhwc(y))
+    assert abs(float(v) - float(loss.detach())) < 1e-4 * max(1.0, float(loss.detach())), (float(v), float(loss.detach()))
+    got = d.cpu().permute(0, 3, 1, 2).double()
+    rel = float((got - xr.grad).norm() / xr.grad.norm())
+    assert rel < 1e-2, rel
 
 
 def test_vgg_perceptual_loss_and_gradient():

@@ -243,6 +243,23 @@ def test_generator_train_loss_with_the_training_scripts_flags(ref):
         assert torch.allclose(p.grad, grads[k], atol=1e-6 + 1e-4 * float(p.grad.abs().max()), rtol=0), k
 
 
+def test_style_loss_matches_reference(ref):
+    """oracle style_loss == the reference's StyleLoss over its own Vgg19 class (seeded weights), value and gradient."""
+    vsd = helpers.vgg19_state_dict(seed=4)
+    ref.networks.models.vgg19 = lambda pretrained=True: _torchvision_vgg19(vsd)
+    crit = ref.networks.StyleLoss(feat_extractors=ref.networks.Vgg19())
+    g = torch.Generator().manual_seed(12)
+    x = (torch.rand(2, 3, 96, 96, generator=g) * 2 - 1).requires_grad_(True)
+    y = torch.rand(2, 3, 96, 96, generator=g) * 2 - 1
+    theirs = crit(x, y)
+    theirs.backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    mine = torch_ref.style_loss(vsd, x2, y)
+    mine.backward()
+    assert abs(float(theirs) - float(mine)) < 1e-6 * max(1.0, float(mine))
+    assert torch.allclose(x.grad, x2.grad, atol=1e-9 + 1e-5 * float(x.grad.abs().max()), rtol=0)
+
+
 def test_face_loss_matches_reference(ref, tmp_path):
     """oracle face_loss == the reference's FaceLoss (networks/networks.py:211-312) + Sphere20a (networks/facenet.py), loaded
     the reference's way from a .pth with seeded weights (the real file is a download), value and gradient."""
