@@ -52,7 +52,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps({"metric": "training iteration (G update + D update)", "ms_per_iteration": round(dt * 1e3, 2),
                       "note": "BASELINE.json config 5 is --image-size 512 (--batch 1..4 per GPU)",
-                      "images_per_s": round(n / dt, 2), "batch": n, "image_size": s, "loss": "train_iPER.sh (mask_bce, vgg, face)" if a.script_loss else "adv + L1 + mask", "dtype": "f32" if a.precision == "fp32" else "bf16x3 convs (forward, data gradient) + f32", "losses": losses}))
+                      "images_per_s": round(n / dt, 2), "batch": n, "image_size": s, "loss": "train_iPER.sh (mask_bce, vgg, face)" if a.script_loss else "adv + L1 + mask", "dtype": "f32" if a.precision == "fp32" else "bf16x3 generator convs (forward, data and weight gradient) + f32", "losses": losses}))
 
 
 if __name__ == "__main__":
