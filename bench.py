@@ -47,12 +47,18 @@ IMAGE_SIZE = 256
 TRAFFIC_FILE = "r02_traffic.json"
 
 
+# sources of the kernels the timed step launches (the training and inpainting kernels are not among them)
+STEP_SOURCES = ("common.h", "conv.h", "conv.hip", "direct.hip", "generator.hip", "heads.hip", "raster.hip", "sample.h", "smpl.hip",
+                "warp.hip")
+
+
 def csrc_digest():
-    """sha256 over the kernel sources (what profiles/*_traffic.json is stamped with by tools/summarize_profile.py)."""
+    """sha256 over the sources of the timed step's kernels: what profiles/*_traffic.json is stamped with by
+    tools/summarize_profile.py (which calls this function)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "impersonator_amd", "csrc")
-    for f in sorted(os.listdir(d)):
+    for f in STEP_SOURCES:
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()

@@ -77,19 +77,18 @@ def traffic(fetch_csv, write_csv, out_json, out_md):
             res.setdefault(k, {})["launches"] = n
             res[k][key] = v / n
     # stamp: bench.py attaches these bytes only while the kernel sources are the ones they were measured on
-    import hashlib, os, subprocess
+    import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h, d = hashlib.sha256(), os.path.join(root, "impersonator_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
+    sys.path.insert(0, root)
+    import bench   # one definition of the digest: bench.py's
+    digest = bench.csrc_digest()
     commit = os.environ.get("LWG_COMMIT", "")
     if not commit:
         try:
             commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
         except Exception:
             commit = "unknown (no .git on the GPU box; see the commit that added this file)"
-    res["_stamp"] = {"csrc_sha256": h.hexdigest(), "commit": commit}
+    res["_stamp"] = {"csrc_sha256": digest, "commit": commit}
     json.dump(res, open(out_json, "w"), indent=1, sort_keys=True)
     with open(out_md, "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two own passes) -- bench.py --steps 2\n\n"
