@@ -16,7 +16,12 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant implicit-GEMM conv kernel, algorithmic FLOP / HIP-event time of its launches, as a
                  fraction of the MFMA peak both ways (algorithmic and executed products); exact_fp32_mode has its own
   cpu_baseline : the CPU oracle (port of the reference's PyTorch path + C rasteriser) timed on this box's host cores
-  parity       : the timed pipeline re-run on 16 frames after the timed region and compared with the oracle.
+  parity       : the timed pipeline re-run on 16 frames after the timed region and compared with the oracle; a failed
+                 check marks the line `"invalid"` and the process exits 1
+  secondary    : after the timed region -- `swap`: Swapper.swap (BASELINE config 4, appearance transfer with the
+                 two-stream Liquid Warping Block) at 256x256, one pair and eight pairs per launch sequence, with the
+                 same HIP-event roofline pass; `train`: one G + D training iteration (config 5) at 512x512 batch 1
+                 and 256x256 batch 4.
 """
 import argparse
 import json
@@ -78,6 +83,8 @@ def parse():
     p.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
                    help="conv arithmetic of the per-frame stream (default: the library default, bf16x3)")
     p.add_argument("--no-fp32-mode", action="store_true", help="skip the extra timed pass in exact-fp32 mode")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="skip the `secondary` block (appearance transfer = BASELINE config 4, training iteration = config 5)")
     p.add_argument("--lanes", type=int, default=None,
                    help="generator engines/streams consecutive batches are dealt to (default: Imitator.lanes = 2)")
     return p.parse_args()
@@ -174,8 +181,10 @@ def parity_block(imitator, src_img, bg_img, smpls, lanes, theta_chain):
     agree = (fim == theta_chain["fim"])
     d_chain = (pred - theta_chain["pred"]).abs()
     frames_agree = agree.flatten(1).all(1)
-    return {"frames": int(pred.shape[0]), "linf": round(float((pred - ref).abs().max()), 7),
-            "fim_mismatch": int((fim != fr["fim"]).sum()) + int((si["fim"].cpu() != src["fim"]).sum()),
+    linf = float((pred - ref).abs().max())
+    fim_mismatch = int((fim != fr["fim"]).sum()) + int((si["fim"].cpu() != src["fim"]).sum())
+    return {"ok": bool(linf <= 1e-3 and fim_mismatch == 0),
+            "frames": int(pred.shape[0]), "linf": round(linf, 7), "fim_mismatch": fim_mismatch,
             "T_linf": round(float((torch.cat(Ts) - fr["T"]).abs().max()), 9),
             "bound": 1e-3, "oracle": "same_vertices: oracle/torch_ref.py + raster_ref.c restarted from the device's posed "
                                      "vertices; pipeline = the timed one (%d lanes)" % lanes,
@@ -185,6 +194,88 @@ def parity_block(imitator, src_img, bg_img, smpls, lanes, theta_chain):
                                                      if bool(frames_agree.any()) else None),
                             "linf_all": round(float(d_chain.max()), 7),
                             "note": "oracle's own CPU SMPL from the same theta (vertices differ by ~1e-6)"}}
+
+
+def conv_roofline(generator, run, steps=1):
+    """HIP-event pass over the conv kernels of `run()` (liblwg records events around every conv launch on the launch
+    stream): the dominant kernel and the all-conv figure, both ways (see main()'s roofline_pass for the definitions)."""
+    generator.profile(True)
+    run()
+    n, ms, flops = generator.profile_read()
+    table = generator.profile_table()
+    generator.profile(False)
+    name, (kn, kms, kfl) = max(table.items(), key=lambda kv: kv[1][1])
+    achieved = kfl / (kms * 1e-3) / 1e12
+    x3 = "bf16x3" in name
+    peak = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
+    ideal_ms = sum(v[2] / (kernel_peak(k) * 1e12) * 1e3 for k, v in table.items())
+    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "frac_pipe": round(achieved * (3.0 if x3 else 1.0) / peak, 4),
+            "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
+            "all_conv_kernels": {"achieved": round(flops / (ms * 1e-3) / 1e12, 3), "frac_pipe": round(ideal_ms / ms, 4),
+                                 "launches": n, "ms": round(ms / steps, 4)}}
+
+
+def secondary_swap(dev, steps=30):
+    """BASELINE config 4: appearance transfer, models/swapper.py:198-271 (Swapper.swap: part masks, calculate_trans, two
+    image warps, generator.swap = tsf ResUnet with TWO warped source-feature sets per Liquid-Warping-Block level,
+    networks/generator.py:245-275, blend) on two synthetic subjects at 256x256.  `one_pair`: Swapper.swap as the
+    reference calls it (batch 1), back to back on one stream.  `eight_pairs`: the generator part of eight swaps as one
+    launch sequence (batch 8 through lwg_generator_swap, the two subjects' cached features shared) -- the throughput
+    form, with the HIP-event roofline of its conv kernels."""
+    from impersonator_amd.utils import synthetic
+    sw, smpl_a, img_a, bg_a = demo.build_synthetic_imitator(batch_size=BATCH, seed=0, image_size=IMAGE_SIZE, model="swapper")
+    smpl_b = demo.synthetic_smpls(8, seed=3)[5]
+    img_b = synthetic.smooth_image(77, (1, 3, IMAGE_SIZE, IMAGE_SIZE))[0]
+    bg_b = synthetic.smooth_image(78, (1, 3, IMAGE_SIZE, IMAGE_SIZE))[0]
+    sw.swap_setup(img_a, img_b, src_smpl=smpl_a, tgt_smpl=smpl_b, src_bg=bg_a, tgt_bg=bg_b)
+    src, tgt = sw.src_info, sw.tsf_info
+
+    def timed(fn, n):
+        for _ in range(3):
+            out = fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize(dev)
+        assert bool(torch.isfinite(out).all())
+        return (time.perf_counter() - t0) / n * 1e3
+
+    one_ms = timed(lambda: sw.swap(src, tgt, target_part="body"), steps)
+    T11, T21 = sw.T12, sw.T21          # what swap() left behind: (1,is,is,2) each
+    sel = sw.PART_IDS["body"]
+    part_mask = (src['part'][:, sel].sum(1, keepdim=True) != 0).float()
+    left_mask = src['part'][:, [0]].sum(1, keepdim=True).bool().float()
+    tsf_img = sw.generator.transform(tgt['img'], T21) * part_mask + sw.generator.transform(src['img'], T11) * left_mask
+    x8 = torch.cat([tsf_img, src['cond']], 1).expand(BATCH, -1, -1, -1).contiguous()
+    T11_8, T21_8 = T11.expand(BATCH, -1, -1, -1).contiguous(), T21.expand(BATCH, -1, -1, -1).contiguous()
+    eight = lambda: sw.forward(x8, tgt['feats'], T21_8, src['feats'], T11_8, src['bg'])[0]
+    eight_ms = timed(eight, steps)
+    roof = conv_roofline(sw.generator, lambda: [eight() for _ in range(4)], steps=4)
+    sw.generator.release()
+    return {"workload": "Swapper.swap, two synthetic subjects, 256x256, swap_part='body' (BASELINE config 4)",
+            "one_pair": {"ms": round(one_ms, 4), "swaps_per_s": round(1e3 / one_ms, 2),
+                         "what": "the whole Swapper.swap call at batch 1 (masks, T11/T21, 2 image warps, generator.swap, blend)"},
+            "eight_pairs": {"ms": round(eight_ms, 4), "swaps_per_s": round(BATCH * 1e3 / eight_ms, 2),
+                            "what": "Swapper.forward on 8 prepared inputs: one launch sequence of the two-stream generator",
+                            "roofline": roof},
+            "dtype": "bf16x3" if sw.generator.precision != "fp32" else "f32"}
+
+
+def secondary_train(steps=3):
+    """BASELINE config 5 per GPU: one training iteration (generator fwd/bwd + PatchGAN discriminator update,
+    impersonator_trainer.py:350-366) -- tools/bench_train.py's measurement."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_train
+    out = {}
+    for name, (n, s) in (("512x512_batch1", (1, 512)), ("256x256_batch4", (4, 256))):
+        r = bench_train.measure(n, s, steps=steps, warmup=2, precision="bf16x3")
+        out[name] = {"ms_per_iteration": r["ms_per_iteration"], "images_per_s": r["images_per_s"]}
+        torch.cuda.empty_cache()
+    out["what"] = ("G update (three streams forward, losses adv + L1 + mask, hand-written backward, Adam) + D update; "
+                   "bf16x3 generator convolutions, fp32 elsewhere; 1 GPU, no all-reduce")
+    return out
 
 
 def main():
@@ -347,7 +438,14 @@ def main():
             line["cpu_baseline"], kept = cpu_baseline()
             # self-check of the timed pipeline against the oracle, after and outside the timed region
             line["parity"] = parity_block(imitator, src_img, bg_img, smpls, lanes, kept)
+            if not line["parity"]["ok"]:
+                line["invalid"] = "the timed pipeline's output failed the parity check against the oracle (see `parity`)"
+        if world == 1 and not args.no_secondary:
+            # other workloads of BASELINE.json, measured after (and outside) the timed region
+            line["secondary"] = {"swap": secondary_swap(dev), "train": secondary_train()}
         print(json.dumps(line))
+        if line.get("invalid"):
+            sys.exit(1)
     if world > 1:
         torch.distributed.destroy_process_group()
 

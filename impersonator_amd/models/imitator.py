@@ -216,8 +216,13 @@ class Imitator(BaseModel):
     # latency-bound at these sizes) and the lanes drain once per round; tools/depth_bench.py at batch 8, two lanes:
     # depth 1 2709, 2 2772, 3 2799, 4 2811 frames/s in one process.  env LWG_ROUND_DEPTH
     round_depth = 4
-    # the next round's geometry runs underneath this round's generators (False: waits for them)
-    overlap_geometry = True
+    # True: the next round's geometry runs underneath this round's generators; False (default): it waits for them.
+    # At round_depth 4 the overlap is worth nothing (2896 vs 2895 frames/s), and it is the
+    # configuration in which two rasteriser code shapes used to miscompute beside conv_igemm_bf16x3 -- an effect
+    # that was removed by replacing those shapes, not explained.  Opt in with LWG_OVERLAP_GEOMETRY=1 / the keyword.
+    overlap_geometry = False
+    # entries of tsf_info with one row per frame (hmr.get_details + SMPLRenderer.transfer, imitator.py:236-268)
+    PER_FRAME_KEYS = ('theta', 'cam', 'pose', 'shape', 'verts', 'j2d', 'j3d', 'fim', 'wim', 'cond', 'tsf_img', 'T')
 
     def _lanes(self, n):
         """n (stream, generator) pairs, each with its own HIP stream; lane 0 drives self.generator, the others an
@@ -241,17 +246,22 @@ class Imitator(BaseModel):
              conv -> finalize -> apply, every launch waiting for the one before, and the idle tails and launch gaps
              of one chain are filled by the other's kernels (+15 % frames/s at batch 8 with two lanes; a third adds
              1 %).
-        The geometry of round r+1 runs underneath the generators of round r (`overlap_geometry`, default
-        Imitator.overlap_geometry = True; False makes it wait for them: the strictly alternating order).  Until the end
-        of round 2 that overlap produced wrong pixels in ~90 % of passes; the cause was two code shapes in the
-        rasteriser that miscompute beside the bf16x3 convolution kernels, both replaced --
-        tools/lane_stress.py: 0 differing batches in 6000.  Events order every hand-over; round r+1 is enqueued before
+        By default the geometry of round r+1 waits for the generators of round r (the strictly alternating order);
+        `overlap_geometry=True` / LWG_OVERLAP_GEOMETRY=1 lets it run underneath them (worth +2.5 % at round_depth 1,
+        nothing at the default depth 4).  Until the end of round 2 that overlap produced wrong pixels in ~90 % of
+        passes; the cause was two code shapes in the rasteriser that miscompute beside the bf16x3 convolution
+        kernels, both replaced, and the stress runs since are clean (profiles/) -- but the
+        mechanism is not understood, so the overlap is opt-in.  Events order every hand-over; round r+1 is enqueued before
         round r is yielded, so a consumer that synchronises on a result (device->host copy) does not drain the
         pipeline.  Same results as transfer_params_by_smpl + forward per batch."""
         import os
         nl = max(1, int(lanes if lanes is not None else os.environ.get("LWG_LANES", self.lanes)))
         depth = max(1, int(os.environ.get("LWG_ROUND_DEPTH", self.round_depth)))
-        overlap = self.overlap_geometry if overlap_geometry is None else bool(overlap_geometry)
+        if overlap_geometry is None:
+            env = os.environ.get("LWG_OVERLAP_GEOMETRY")
+            overlap = self.overlap_geometry if env is None else env not in ("0", "", "false", "False")
+        else:
+            overlap = bool(overlap_geometry)
         main = torch.cuda.current_stream()
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
@@ -278,8 +288,8 @@ class Imitator(BaseModel):
                     tsf_inputs = self.transfer_params_by_smpl(whole, cam_strategy, t=items[0][1])
                     info, k0 = self.tsf_info, 0
                     for (_, t), n in zip(items, sizes):
-                        part = {k: (v[k0:k0 + n] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == whole.shape[0]
-                                    else v) for k, v in info.items()}
+                        # the per-frame entries are named, not inferred from a leading dimension
+                        part = {k: (v[k0:k0 + n] if k in self.PER_FRAME_KEYS else v) for k, v in info.items()}
                         prepared.append((t, tsf_inputs[k0:k0 + n], part))
                         k0 += n
                 else:

@@ -166,12 +166,14 @@ class Impersonator(BaseModel):
                                   max_batch=getattr(self._opt, 'batch_size', 4)).cuda()
 
     @torch.no_grad()
-    def set_input(self, input_G_tsf, real_tsf=None, input_G_bg=None, input_G_src=None, T=None, real_src=None, bg_mask=None):
+    def set_input(self, input_G_tsf, real_tsf=None, input_G_bg=None, input_G_src=None, T=None, real_src=None, bg_mask=None,
+                  head_bbox=None, body_bbox=None):
         """impersonator_trainer.py:289-319.  Called as the reference calls it -- `set_input(sample)` with
         sample['images'] (N,2,3,H,W) and sample['smpls'] (N,2,85): source / target pairs of a dataset batch -- the inputs
         are derived on the device by BodyRecoveryFlow.  Called with explicit tensors (extension) it takes what
-        BodyRecoveryFlow would have produced: the generator inputs of the three streams, the flow T and the real images
-        (`_optimize_D` alone needs input_G_tsf and real_tsf)."""
+        BodyRecoveryFlow would have produced: the generator inputs of the three streams, the flow T, the real images
+        (`_optimize_D` alone needs input_G_tsf and real_tsf) and, for --use_face, `head_bbox` (N,4); the boxes of an
+        earlier batch are never kept."""
         if isinstance(input_G_tsf, dict):
             sample = input_G_tsf
             images, smpls = sample['images'], sample['smpls']
@@ -185,6 +187,8 @@ class Impersonator(BaseModel):
             bg_mask = torch.cat((src_crop_mask, tsf_crop_mask), dim=0)
             input_G_bg = (torch.cat([input_G_src_bg, input_G_tsf_bg], dim=0) if getattr(self._opt, 'bg_both', False)
                           else input_G_src_bg)   # impersonator_trainer.py:306-309
+        else:
+            self._head_bbox, self._body_bbox = head_bbox, body_bbox
         self._input_G_tsf, self._real_tsf = input_G_tsf, real_tsf
         self._input_G_bg, self._input_G_src, self._T = input_G_bg, input_G_src, T
         self._real_src, self._bg_mask = real_src, bg_mask

@@ -87,7 +87,9 @@ def _heads_ws(n, h, w, dev):
 
 @torch.no_grad()
 def heads_forward(x, w):
-    """Regression heads: x (N,H,W,64), w (>=4,64,7,7) -> (tanh(conv rows 0-2) (N,3,H,W), sigmoid(conv row 3) (N,1,H,W))."""
+    """Regression heads: x (N,H,W,64), w (>=4,64,7,7) -> (tanh(conv rows 0-2) (N,3,H,W), sigmoid(conv row 3) (N,1,H,W)).
+    PRECONDITION x >= 0 (post-ReLU activations, what the generator feeds its heads): the kernel is the inference path's,
+    which folds the preceding ReLU into its operand load -- negative entries are read as 0 (include/lwg.h)."""
     _chk(x, w)
     n, h, wd, c = x.shape
     if c != 64 or tuple(w.shape[1:]) != (64, 7, 7) or w.shape[0] < 4:

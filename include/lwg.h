@@ -275,7 +275,10 @@ LWG_API int lwg_conv2d_backward_weight(const lwg_conv2d_desc *d, const float *x,
  * Tanh, attetion_reg = Conv2d(64,1,7,1,3) + Sigmoid, no bias).  x (N,H,W,64) NHWC; w (w_rows >= 4, 64, 7, 7): rows 0-2 the
  * colour head, row 3 the mask head.  forward: color (N,3,H,W) = tanh(conv), mask (N,1,H,W) = sigmoid(conv), either may
  * be NULL.  backward_weight: dy8 (N,H,W,8) = gradient wrt the PRE-activation outputs (channels 4-7 zero) -> dw (8,64,7,7).
- * The data gradient is lwg_conv2d_backward_data with Cout = 8.  workspace: lwg_heads_workspace_bytes, scratch only. */
+ * The data gradient is lwg_conv2d_backward_data with Cout = 8.  workspace: lwg_heads_workspace_bytes, scratch only.
+ * PRECONDITION: x >= 0 (it is the output of the last IN + ReLU block, generator.py:129-133,178-181).  The forward is the
+ * inference path's heads kernel, whose operand load folds that ReLU in: a negative entry of x is read as 0, i.e. the
+ * entry point computes tanh/sigmoid(conv(max(x, 0))) and neither gradient accounts for the clamp. */
 LWG_API size_t lwg_heads_workspace_bytes(int N, int H, int W);
 LWG_API int lwg_heads_forward(const float *x, int N, int H, int W, const float *w, int w_rows, float *color, float *mask,
                               void *workspace, size_t workspace_bytes, lwg_stream_t stream);

@@ -422,6 +422,52 @@ def discriminator_train_steps(sd, batches, n_layers=4, lr=0.0002, betas=(0.5, 0.
     return losses, first, {k: v.detach().clone() for k, v in params.items()}
 
 
+def create_meshgrid(image_size):
+    """utils/nmr.py:490-504: the identity sampling grid (is, is, 2), x along the last image axis."""
+    factor = (torch.arange(0, image_size, dtype=torch.float32) / (image_size - 1) - 0.5) * 2
+    xv, yv = torch.meshgrid([factor, factor], indexing="ij")
+    return torch.stack([yv, xv], dim=-1)
+
+
+def swapper_personalize(sd, img, cam, verts, faces_idx, map_fn, part_fn, bg_ks=13, ft_ks=3, image_size=256):
+    """Swapper.personalize (models/swapper.py:99-165) given the posed vertices, --bg_model ORIGINAL (the generator's own
+    BGNet inpaints the background)."""
+    f2v, fim, wim = render_fim_wim(cam, verts, faces_idx, image_size)
+    cond = encode_fim(fim, map_fn)
+    part = encode_fim(fim, part_fn)
+    bg_mask = morph(cond[:, -1:], bg_ks, "erode")
+    bg = bgnet_forward(sd, torch.cat([img * bg_mask, bg_mask], dim=1))
+    ft = 1 - morph(cond[:, -1:], ft_ks, "erode")
+    enc, res = encode_src(sd, torch.cat([img * ft, cond], 1))
+    return dict(fim=fim, wim=wim, cond=cond, part=part, p2verts=source_p2verts(f2v), img=img, bg=bg, enc=enc, res=res)
+
+
+def swapper_swap(sd, src, tgt, part_faces, selected_ids=(1, 2, 3, 4, 5, 6, 7, 8, 9), all_ids=tuple(range(10))):
+    """Swapper.swap + calculate_trans + forward (models/swapper.py:198-271), front_warp off; src / tgt as
+    swapper_personalize returns them.  -> dict(T11, T21, tsf_inputs, preds, mask)."""
+    left_ids = [i for i in all_ids if i not in selected_ids]
+    part_mask = (torch.sum(src["part"][:, list(selected_ids)], dim=1) != 0)
+    left_mask = torch.sum(src["part"][:, left_ids], dim=1).bool()
+    left_faces = sorted(set(f for i in left_ids for f in part_faces[i]))
+    T11 = create_meshgrid(src["img"].shape[-1]).clone()
+    T11[~left_mask[0]] = -2
+    T11 = T11[None]
+    f2p = tgt["p2verts"].clone()
+    f2p[0, left_faces] = -2
+    T21 = cal_bc_transform(f2p, src["fim"], src["wim"]).clamp(-2, 2)
+    tsf_img = grid_sample(tgt["img"], T21) * part_mask[:, None].float() + grid_sample(src["img"], T11) * left_mask[:, None].float()
+    x = torch.cat([tsf_img, src["cond"]], 1)
+    color, mask = generator_swap(sd, x, tgt["enc"], src["enc"], tgt["res"], src["res"], T21, T11)
+    return dict(T11=T11, T21=T21, left_mask=left_mask, tsf_inputs=x, preds=mask * src["bg"] + (1 - mask) * color, mask=mask)
+
+
+def viewer_view(sd, src, tsf_mesh, cam, faces_idx, map_fn, bg_replace=False, image_size=256):
+    """Viewer.view + forward (models/viewer.py:273-311) after rotate_trans, front_warp off."""
+    fr = transfer_frame(src["img"], src["p2verts"], cam, tsf_mesh, faces_idx, map_fn, image_size)
+    bg = src["bg"] if bg_replace else torch.zeros_like(src["bg"])
+    return fr, imitator_forward(sd, src["enc"], src["res"], bg, fr["tsf_inputs"], fr["T"])[0]
+
+
 def bgnet_forward(sd, x, repeat=6, n_down=3):
     """ResNetGenerator.forward (networks/generator.py:23-65) as ImpersonatorGenerator builds it (k_size=3, n_down=3):
     conv7-IN-ReLU, 3 x [conv3 s2-IN-ReLU], `repeat` residual blocks, 3 x [convT3 s2-IN-ReLU], conv7, tanh.

@@ -16,6 +16,11 @@ What comes from where
                         inputs of impersonator_amd/utils/synthetic.py.  The only non-reference piece
                         in that pass is the C restatement of the CUDA rasteriser (oracle/raster_ref.c),
                         which teapot_kat.npz pins.
+  * tasks_golden.npz -- BASELINE config 4 and the Viewer, executed by the reference's own METHODS run unbound on a
+                        stand-in `self`: `Swapper.personalize` (models/swapper.py:99-165) for two subjects,
+                        `Swapper.swap` + `calculate_trans` + `forward` (:198-271) and `Viewer.view` + `rotate_trans` +
+                        `forward` (models/viewer.py:262-311) for two views.  Stand-ins: a fixed-vertices `hmr`, the
+                        image reader (no cv2), `.cuda()` as the identity, the C rasteriser.
 """
 import os
 import sys
@@ -171,6 +176,90 @@ def make_frame(ref):
     print("frame_golden: covered px", int(cov.sum()), "preds range", float(preds.min()), float(preds.max()))
 
 
+def make_tasks(ref):
+    import importlib
+    ref_swapper = importlib.import_module("models.swapper")
+    ref_viewer = importlib.import_module("models.viewer")
+    S, V, R = ref_swapper.Swapper, ref_viewer.Viewer, ref.nmr.SMPLRenderer
+    torch.set_num_threads(os.cpu_count())
+    from tests import helpers
+    sc = helpers.task_scene()
+    FixedHMR = helpers.FixedHMR
+    image_size = 256
+    rs = types.SimpleNamespace(faces=torch.from_numpy(sc["faces"]), image_size=image_size, map_fn=torch.from_numpy(sc["map_fn"]),
+                               proj_func=ref.nmr.orthographic_proj_withz_idrot, eye=[0, 0, -(1. / np.tan(np.radians(30)) + 1)])
+    for name in ("render_fim_wim", "encode_fim", "cal_bc_transform"):
+        setattr(rs, name, types.MethodType(getattr(R, name), rs))
+    G = ref.generator.ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in G.state_dict().items()]
+    sd = synthetic.random_state_dict(shapes, seed=0, affine="random")
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+
+    images = {"A": sc["img_a"][0], "B": sc["img_b"][0]}
+    # the reference reads a file and maps [0,255] -> [-1,1]; the stand-ins hand the float image through exactly
+    # (float64 in between: (x + 1) / 2 * 2 - 1 == x there)
+    for mod in (ref_swapper.cv_utils,):
+        mod.read_cv2_img = lambda path: images[path]
+        mod.transform_img = lambda img, size, transpose=True: (img.astype(np.float64) + 1.0) / 2.0
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        t = torch.from_numpy
+        stub = types.SimpleNamespace(
+            _opt=types.SimpleNamespace(image_size=image_size, only_vis=False, bg_model='ORIGINAL', bg_ks=13, ft_ks=3, front_warp=False),
+            hmr=FixedHMR([(t(sc["cam_a"]), t(sc["verts_a"])), (t(sc["cam_b"]), t(sc["verts_b"]))]), render=rs, detector=None,
+            bgnet=G.bg_model, generator=G, part_fn=t(sc["part_fn"]), part_faces=sc["part_faces"], PART_IDS=S.PART_IDS,
+            grid=R.create_meshgrid(image_size), src_info=None, tsf_info=None)
+        captured = {}
+
+        def calculate_trans(self, mask, faces):
+            captured["left_mask"], captured["left_faces"] = mask.clone(), list(faces)
+            captured["T11"], captured["T21"] = S.calculate_trans(self, mask, faces)
+            return captured["T11"], captured["T21"]
+
+        def forward(self, tsf_inputs, *args):
+            captured["tsf_inputs"] = tsf_inputs.clone()
+            return S.forward(self, tsf_inputs, *args)
+
+        stub.calculate_trans = types.MethodType(calculate_trans, stub)
+        stub.forward = types.MethodType(forward, stub)
+        smpl = np.zeros(85, np.float32)
+        with torch.no_grad():
+            stub.src_info = S.personalize(stub, "A", smpl)
+            stub.tsf_info = S.personalize(stub, "B", smpl)
+            preds = S.swap(stub, stub.src_info, stub.tsf_info, target_part='body')
+        A, B = stub.src_info, stub.tsf_info
+        out = dict(
+            fim_a=A["fim"].numpy().astype(np.int16), fim_b=B["fim"].numpy().astype(np.int16),
+            part_a=A["part"].argmax(1).numpy().astype(np.uint8),
+            bg_a_sub=A["bg"].numpy()[:, :, ::4, ::4], bg_b_sub=B["bg"].numpy()[:, :, ::4, ::4],
+            left_mask=np.packbits(captured["left_mask"].numpy()), left_faces_n=np.array([len(captured["left_faces"])]),
+            T11=captured["T11"].numpy(), T21=captured["T21"].numpy(), tsf_inputs_sub=captured["tsf_inputs"].numpy()[:, :, ::2, ::2],
+            swap_preds=preds.numpy())
+
+        # --- Viewer.view on subject A (the reference's view / rotate_trans / forward)
+        vstub = types.SimpleNamespace(src_info=A, render=rs, generator=G, _opt=types.SimpleNamespace(bg_replace=False, front_warp=False))
+        meshes = []
+
+        def rotate_trans(self, rt, tr, X):
+            meshes.append(V.rotate_trans(self, rt, tr, X))
+            return meshes[-1]
+
+        vstub.rotate_trans = types.MethodType(rotate_trans, vstub)
+        vstub.forward = types.MethodType(V.forward, vstub)
+        for i, (rt, tr, replace) in enumerate(sc["views"]):
+            vstub._opt.bg_replace = replace
+            with torch.no_grad():
+                vp = V.view(vstub, rt, tr)
+            out["view%d_mesh" % i] = meshes[-1].numpy()
+            out["view%d_preds" % i] = vp.numpy()
+    finally:
+        torch.Tensor.cuda = cuda
+    np.savez_compressed(os.path.join(HERE, "tasks_golden.npz"), **out)
+    print("tasks_golden: swap preds range", float(preds.min()), float(preds.max()), "kept px", int(captured["left_mask"].sum()),
+          "left faces", len(captured["left_faces"]))
+
+
 def make_discriminator(ref):
     """One discriminator update of the REAL reference code: PatchDiscriminator (networks/discriminator.py) as the
     trainer builds it (impersonator_trainer.py:219-222), the LSGAN loss of _optimize_D/_compute_loss_D (:396-414),
@@ -205,10 +294,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "discriminator":   # add this fixture without regenerating the others
         make_discriminator(ref)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tasks":
+        make_tasks(ref)
+        sys.exit(0)
     make_teapot(ref)
     make_look_at()
     make_frame(ref)
     make_discriminator(ref)
+    make_tasks(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -113,3 +113,30 @@ def train_batch(seed=0, n=2, size=64, bg_both=False):
     return dict(input_G_bg=r(n, 4, size, size), input_G_src=r(n, 6, size, size), input_G_tsf=r(n, 6, size, size), T=T,
                 real_src=r(n, 3, size, size), real_tsf=r(n, 3, size, size),
                 bg_mask=(torch.rand(2 * n, 1, size, size, generator=g) > 0.5).float())
+
+
+class FixedHMR(object):
+    """`hmr` stand-in: get_details() hands out prepared (cam, verts) in call order (the SMPL regressor / LBS are not
+    what these fixtures pin)."""
+
+    def __init__(self, infos):
+        self.infos = list(infos)
+
+    def get_details(self, smpl):
+        cam, verts = self.infos.pop(0)
+        return dict(theta=smpl, cam=cam, pose=smpl[:, 3:75], shape=smpl[:, 75:], verts=verts)
+
+    def cuda(self):
+        return self
+
+
+def task_scene():
+    """Inputs of tests/golden/tasks_golden.npz (numpy): two subjects (rest pose / frame 200 of the synthetic motion, own
+    cameras and images), the synthetic 10-part partition, two views."""
+    rest, faces = synthetic.body_mesh()
+    part_fn, part_faces = synthetic.part_map_fn(rest, faces)
+    return dict(rest=rest, faces=faces, map_fn=synthetic.uv_seg_map_fn(rest, faces), part_fn=part_fn, part_faces=part_faces,
+                cam_a=synthetic.cams(1, seed=100), verts_a=rest[None].copy(), img_a=synthetic.smooth_image(11),
+                cam_b=synthetic.cams(1, seed=101), verts_b=synthetic.motion_verts(rest, 200)[None].copy(),
+                img_b=synthetic.smooth_image(77),
+                views=[((0.0, 0.6, 0.0), (0.0, 0.0, 0.0), False), ((0.2, -1.1, 0.1), (0.02, 0.0, 0.0), True)])

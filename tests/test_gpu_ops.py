@@ -142,6 +142,21 @@ def test_heads_ops(H, W):
     assert _rel(dx.cpu().permute(0, 3, 1, 2).double(), xr.grad) < 1e-5
 
 
+def test_heads_forward_clamps_negative_inputs():
+    """The documented precondition of lwg_heads_forward (include/lwg.h): x is post-ReLU; a signed x is read through
+    max(x, 0) -- stated, and pinned here so that a caller relying on anything else finds out."""
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 40, 48, 64, generator=g).cuda()
+    w = torch.zeros(8, 64, 7, 7)
+    w[:4] = torch.randn(4, 64, 7, 7, generator=g) * 0.03
+    c0, m0 = ops.heads_forward(x, w.cuda())
+    c1, m1 = ops.heads_forward(x.clamp(min=0), w.cuda())
+    assert torch.equal(c0, c1) and torch.equal(m0, m1)
+    pre = F.conv2d(x.clamp(min=0).permute(0, 3, 1, 2).cpu().double(), w[:4].double(), None, stride=1, padding=3)
+    assert float((c0.cpu().double() - torch.tanh(pre[:, 0:3])).abs().max()) < 1e-5
+
+
 def test_unsupported_shapes_fail_loudly():
     from impersonator_amd import _lib, ops
     x = torch.zeros(1, 8, 8, 48, device="cuda")

@@ -1,7 +1,14 @@
 """Secondary measurement (NOT the bench.py contract): one full training iteration (generator update + discriminator
 update, impersonator_trainer.py:350-366) on an MI355X, synthetic inputs.
 
-    python tools/bench_train.py [--batch 4] [--image-size 256] [--steps 5]"""
+    python tools/bench_train.py [--batch 4] [--image-size 256] [--steps 5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py ...
+
+Under torchrun every rank trains on its own `--batch` images (data parallel, BASELINE.json config 5) and the two flat
+gradient buffers (G 390 MB, D 27.8 MB) are averaged over the ranks between backward and the Adam step
+(sharding.average_gradients: RCCL over xGMI; LWG_DIST_BACKEND=gloo lets several ranks share one GPU for a functional
+run).  The line then also carries the time of those two all-reduces alone, measured on the same buffers.
+`measure()` is what bench.py's `secondary.train` block calls."""
 import argparse
 import json
 import os
@@ -12,12 +19,79 @@ import types
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from impersonator_amd import sharding  # noqa: E402
 from impersonator_amd.models.impersonator_trainer import Impersonator  # noqa: E402
+
+
+def build(batch, image_size, precision="bf16x3", script_loss=False, seed=0):
+    opt = types.SimpleNamespace(image_size=image_size, batch_size=batch, map_name='uv_seg', norm_type='instance',
+                                repeat_num=6, is_train=True, conv_precision=precision)
+    if script_loss:
+        from tests import helpers
+        opt.mask_bce, opt.use_vgg, opt.use_face = True, True, True
+        opt.vgg_weights, opt.face_model = helpers.vgg19_state_dict(0), helpers.sphere20a_state_dict(0)
+        opt.lambda_face, opt.lambda_mask, opt.lambda_mask_smooth = 5.0, 1.0, 1.0
+    torch.manual_seed(seed)          # every rank starts from the same parameters
+    model = Impersonator(opt)
+    model._G.init_weights()
+    model._D.init_weights()
+    g = torch.Generator().manual_seed(seed + 1 + sharding.env_world()[0])   # ... and trains on its own images
+    n, s = batch, image_size
+    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).cuda()
+    # head boxes as BodyRecoveryFlow.cal_head_bbox would give them (a 1/5-size box near the top)
+    boxes = torch.tensor([[s * 2 // 5, s * 3 // 5, s // 10, s * 3 // 10]] * n) if script_loss else None
+    model.set_input(r(n, 6, s, s), r(n, 3, s, s), input_G_bg=r(n, 4, s, s), input_G_src=r(n, 6, s, s),
+                    T=(torch.rand(n, s, s, 2, generator=g) * 2.4 - 1.2).cuda(), real_src=r(n, 3, s, s),
+                    bg_mask=(torch.rand(2 * n, 1, s, s, generator=g) > 0.5).float().cuda(), head_bbox=boxes)
+    return model
+
+
+def measure(batch, image_size, steps=5, warmup=1, precision="bf16x3", script_loss=False):
+    """-> dict(ms_per_iteration, images_per_s, ...) of `steps` optimize_parameters() calls after `warmup`; under an
+    initialised multi-rank group: max over ranks, images of all ranks."""
+    rank, _, world = sharding.env_world()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model = build(batch, image_size, precision, script_loss)
+    for _ in range(max(1, warmup)):
+        losses = model.optimize_parameters()
+    sharding.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = model.optimize_parameters()
+    sharding.barrier(dev)
+    dt = sharding.max_over_ranks((time.perf_counter() - t0) / steps, "cpu")
+    out = {"ms_per_iteration": round(dt * 1e3, 2), "images_per_s": round(world * batch / dt, 2), "batch_per_rank": batch,
+           "world": world, "image_size": image_size,
+           "dtype": "f32" if precision == "fp32" else "bf16x3 generator convs (forward, data and weight gradient) + f32",
+           "loss": "train_iPER.sh (mask_bce, vgg, face)" if script_loss else "adv + L1 + mask",
+           "losses": {k: round(v, 6) for k, v in losses.items()}}
+    if world > 1:
+        # the two collectives of an iteration on their own: the same buffers, the same call
+        fg, dg = model._generator_trainer().flat_g, model._D.flat_buffers()[1]
+        keep_g, keep_d = fg.clone(), dg.clone()
+        ms = {}
+        for name, buf in (("G", fg), ("D", dg)):
+            sharding.average_gradients(buf)
+            sharding.barrier(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                sharding.average_gradients(buf)
+            torch.cuda.synchronize(dev)
+            ms[name] = sharding.max_over_ranks((time.perf_counter() - t0) / 3, "cpu") * 1e3
+        fg.copy_(keep_g)
+        dg.copy_(keep_d)
+        import torch.distributed as dist
+        out["all_reduce"] = {"backend": dist.get_backend(), "G_bytes": fg.numel() * 4, "D_bytes": dg.numel() * 4,
+                             "G_ms": round(ms["G"], 3), "D_ms": round(ms["D"], 3),
+                             "note": "ring all-reduce over xGMI moves 2(N-1)/N x bytes per GPU at <= ~153 GB/s per link"}
+    model._D.release()
+    model._G.release()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=4, help="images per rank")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--script-loss", action="store_true",
@@ -25,34 +99,17 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="forward / data-gradient convolutions of the generator update")
     a = ap.parse_args()
-    opt = types.SimpleNamespace(image_size=a.image_size, batch_size=a.batch, map_name='uv_seg', norm_type='instance',
-                                repeat_num=6, is_train=True, conv_precision=a.precision)
-    if a.script_loss:
-        from tests import helpers
-        opt.mask_bce, opt.use_vgg, opt.use_face = True, True, True
-        opt.vgg_weights, opt.face_model = helpers.vgg19_state_dict(0), helpers.sphere20a_state_dict(0)
-        opt.lambda_face, opt.lambda_mask, opt.lambda_mask_smooth = 5.0, 1.0, 1.0
-    model = Impersonator(opt)
-    model._G.init_weights()
-    model._D.init_weights()
-    g = torch.Generator().manual_seed(0)
-    n, s = a.batch, a.image_size
-    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).cuda()
-    model.set_input(r(n, 6, s, s), r(n, 3, s, s), input_G_bg=r(n, 4, s, s), input_G_src=r(n, 6, s, s),
-                    T=(torch.rand(n, s, s, 2, generator=g) * 2.4 - 1.2).cuda(), real_src=r(n, 3, s, s),
-                    bg_mask=(torch.rand(2 * n, 1, s, s, generator=g) > 0.5).float().cuda())
-    if a.script_loss:   # head boxes as BodyRecoveryFlow.cal_head_bbox would give them (a 1/5-size box near the top)
-        model._head_bbox = torch.tensor([[s * 2 // 5, s * 3 // 5, s // 10, s * 3 // 10]] * n)
-    losses = model.optimize_parameters()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = model.optimize_parameters()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"metric": "training iteration (G update + D update)", "ms_per_iteration": round(dt * 1e3, 2),
-                      "note": "BASELINE.json config 5 is --image-size 512 (--batch 1..4 per GPU)",
-                      "images_per_s": round(n / dt, 2), "batch": n, "image_size": s, "loss": "train_iPER.sh (mask_bce, vgg, face)" if a.script_loss else "adv + L1 + mask", "dtype": "f32" if a.precision == "fp32" else "bf16x3 generator convs (forward, data and weight gradient) + f32", "losses": losses}))
+    rank, local_rank, world = sharding.init_process_group()
+    if local_rank >= torch.cuda.device_count() and os.environ.get("LWG_DIST_BACKEND") == "gloo":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    line = measure(a.batch, a.image_size, a.steps, 1, a.precision, a.script_loss)
+    if rank == 0:
+        line = dict({"metric": "training iteration (G update + D update)",
+                     "note": "BASELINE.json config 5 is --image-size 512 (--batch 1..4 per GPU)", "batch": a.batch}, **line)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
