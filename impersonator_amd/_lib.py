@@ -23,6 +23,8 @@ class LwgError(RuntimeError):
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
 _PROTOS = {
+    "lwg_conv_trace": (_i, [_vp, _sz]),
+    "lwg_conv_trace_launch": (_i, [_i, _c.POINTER(_c.c_longlong)]),
     "lwg_version": (_i, []),
     "lwg_last_error": (_c.c_char_p, []),
     "lwg_device_info": (_i, [_c.POINTER(_i), _c.POINTER(_sz), _c.c_char_p, _sz]),

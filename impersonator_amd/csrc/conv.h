@@ -62,10 +62,16 @@ struct ConvArgs {
     // `accumulate` adds into y instead of storing.  Register-staged fp32 kernel only; no fused statistics
     // (partials must be null), mtiles = ceil(M / 128).
     int natural_order;              // 1: keep the natural tile order (default 0: XCD bands, see conv_igemm_bf16x3)
+    int tap_inner;                  // bf16x3 kernel: 1 = walk the reduction (32-channel slice, tap) with the taps innermost
+    unsigned long long *trace;      // measurement builds only (LWG_CONV_TRACE): per-wave cycle accounting, see conv_igemm_bf16x3
     int general;
     const float *bias;
     ConvPhase ph[4];
 };
+
+// measurement hook behind lwg_conv_trace / lwg_conv_trace_launch (include/lwg.h)
+int conv_trace_set(void *device_buffer, size_t bytes);
+int conv_trace_launch(int idx, long long *v10);
 
 // bn = 64 or 128 output channels per workgroup tile.  *variant (optional) receives which kernel instantiation ran:
 enum { kIgemmReg64 = 0, kIgemmReg128 = 1, kIgemmSmallCin = 2, kIgemmDma64 = 3, kIgemmDma128 = 4, kIgemmBf16x3_64 = 5,

@@ -660,6 +660,12 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
+    // DBG & 512 (tools/conv_trace.py): per-wave cycle accounting with s_memtime around the stage's two blocking sites.
+    // The three reads of a stage are consumed at the NEXT stage's site, behind the lgkmcnt(0) that is there anyway, so
+    // the instrumented kernel has no wait the production kernel does not have.
+    unsigned long long tr_a = 0, tr_b = 0, tr_c = 0, tr_wait = 0, tr_bar = 0, tr_t0 = 0, tr_loop0 = 0, tr_loop1 = 0;
+    unsigned tr_stages = 0;
+    if (DBG & 512) tr_t0 = __builtin_amdgcn_s_memtime();
 
     // unfused phases: blockIdx.z counts the phase index down (most taps first, see conv_igemm_dma_f32)
     const int pz0 = a.fuse_phases ? 0 : a.nphase - 1 - (int)blockIdx.z;
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         wvoff[j] = (unsigned)(((n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4) * 4);
     }
     int s_tap = 0, s_kh = 0, s_kw = 0;
-    unsigned s_ci_b = 0;
+    unsigned s_ci_b = 0, s_w_b = 0;   // channel-slice byte offset of the activations, K byte offset of the weight rows
     auto retap = [&]() {
         const int tapoff = (s_kh * a.W + s_kw) * a.dil * a.ldx;
 #pragma unroll
@@ -713,16 +719,30 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         if (p < A_CH) {
             dma16(cur[p], x_base + s_ci_b, wave_a + slot_byte + (unsigned)(p * 8 * BK * 4));
         } else {
-            dma16(wvoff[p - A_CH], w_base + (size_t)kt * (BK * 4), wave_b + slot_byte + (unsigned)((p - A_CH) * 8 * BK * 4));
+            dma16(wvoff[p - A_CH], w_base + __builtin_amdgcn_readfirstlane(s_w_b), wave_b + slot_byte + (unsigned)((p - A_CH) * 8 * BK * 4));
         }
         if (p == LPS - 1) {
-            s_ci_b += BK * 4;
-            if (s_ci_b == (unsigned)a.Cin * 4) {
-                asm volatile("; next tap" ::: "memory");   // keeps this rare path a real (wave-uniform) branch
-                s_ci_b = 0;
+            // next stage's slice of the reduction.  The weight rows are [tap][ci]; the walk order is free:
+            if (a.tap_inner) {
+                // taps innermost: the nine taps of one 32-channel slice are consecutive stages, so a tile re-reads
+                // the 128-byte lines of its own pixel neighbourhood (9 x 16 KiB loaded, ~26 KiB distinct) while they
+                // are still in L1/L2.  Channel-innermost, a pixel's line comes back Cin/32 stages later, after the
+                // XCD's 32 workgroups have pushed 16 MB through its 4 MiB L2: every tap was a fabric fetch.
                 ++s_tap;
                 if (++s_kw == ph.KW) { s_kw = 0; ++s_kh; }
+                if (s_tap == ph.ntaps) { s_tap = 0; s_kh = 0; s_kw = 0; s_ci_b += BK * 4; }
+                s_w_b = (unsigned)(s_tap * a.Cin) * 4u + s_ci_b;
                 retap();
+            } else {
+                s_w_b += BK * 4;
+                s_ci_b += BK * 4;
+                if (s_ci_b == (unsigned)a.Cin * 4) {
+                    asm volatile("; next tap" ::: "memory");   // keeps this rare path a real (wave-uniform) branch
+                    s_ci_b = 0;
+                    ++s_tap;
+                    if (++s_kw == ph.KW) { s_kw = 0; ++s_kh; }
+                    retap();
+                }
             }
         }
     };
@@ -783,6 +803,11 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
             const int t = r / TILES, i = (r / WN) % WM, j = r % WN;   // cross terms first, hi*hi last
             if (q == QB) {
                 __builtin_amdgcn_sched_barrier(0);
+                if (DBG & 512) {
+                    if (tr_stages) { tr_wait += tr_b - tr_a; tr_bar += tr_c - tr_b; }   // the previous stage's reads have landed
+                    ++tr_stages;
+                    tr_a = __builtin_amdgcn_s_memtime();
+                }
                 // stage kt+1 must have landed for every wave (only younger pieces may be in flight) and every wave
                 // must be done reading this slot's predecessor before the pieces issued below overwrite it
                 if (decltype(do_dma)::value) {
@@ -790,7 +815,9 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
                 } else {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 }
+                if (DBG & 512) tr_b = __builtin_amdgcn_s_memtime();
                 if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+                if (DBG & 512) tr_c = __builtin_amdgcn_s_memtime();
                 asm volatile("" ::: "memory");
                 if (DBG & 256) {
                     load_frags(slot1, 0, nx);
@@ -848,19 +875,22 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     asm volatile("" ::: "memory");
     load_frags(0, 0, fr);
 
+    if (DBG & 512) tr_loop0 = __builtin_amdgcn_s_memtime();
     // whole turns of the ring with compile-time slots, the remaining stages through a slot dispatch
     int kt = 0, slot = 0;
-    static_assert(NS == 3 || NS == 4, "ring depth");
+    static_assert(NS >= 3 && NS <= 5, "ring depth");
     for (; kt + 2 * (NS - 1) < nk; kt += NS) {
         stage_body(kt, std::integral_constant<int, 0>{}, yes{});
         stage_body(kt + 1, std::integral_constant<int, 1>{}, yes{});
         stage_body(kt + 2, std::integral_constant<int, 2>{}, yes{});
-        if constexpr (NS == 4) stage_body(kt + 3, std::integral_constant<int, 3>{}, yes{});
+        if constexpr (NS >= 4) stage_body(kt + 3, std::integral_constant<int, 3>{}, yes{});
+        if constexpr (NS >= 5) stage_body(kt + 4, std::integral_constant<int, 4>{}, yes{});
     }
     auto run_stage = [&](int k, int sl, auto do_dma) {
         if (sl == 0) stage_body(k, std::integral_constant<int, 0>{}, do_dma);
         else if (sl == 1) stage_body(k, std::integral_constant<int, 1>{}, do_dma);
         else if (NS == 3 || sl == 2) stage_body(k, std::integral_constant<int, 2>{}, do_dma);
+        else if (NS == 4 || sl == 3) stage_body(k, std::integral_constant<int, (NS > 3 ? 3 : 2)>{}, do_dma);
         else stage_body(k, std::integral_constant<int, NS - 1>{}, do_dma);
     };
     for (; kt + (NS - 1) < nk; ++kt) {
@@ -872,7 +902,24 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         if (++slot == NS) slot = 0;
     }
 
+    if (DBG & 512) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tr_wait += tr_b - tr_a;
+        tr_bar += tr_c - tr_b;
+        tr_loop1 = __builtin_amdgcn_s_memtime();
+    }
     if (!(DBG & 32)) igemm_epilogue<BN, WM, WN, !(DBG & 128), NW, BMT>(a, ph, pz, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
+    if ((DBG & 512) && a.trace && lane == 0) {
+        // [workgroup][wave][8]: start, prologue end, loop end, kernel end (absolute), cycles in the data wait, in the
+        // barrier, stages, (xcc_id << 8 | cu_id-ish hw id)
+        const unsigned long long tr_end = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = a.trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
+        o[0] = tr_t0; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = tr_end; o[4] = tr_wait; o[5] = tr_bar; o[6] = tr_stages;
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[7] = ((unsigned long long)xcc << 32) | hwid;
+    }
     if (DBG & 32) {   // bench only: keep every MFMA alive without an epilogue
         float keep = 0.f;
 #pragma unroll
@@ -1139,7 +1186,30 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 const char *const kIgemmVariantNames[kIgemmVariants] = {
     "conv_igemm_f32<64, 1, 2, false, 0>", "conv_igemm_f32<128, 2, 2, false, 0>", "conv_igemm_f32<64, 1, 2, true, 0>",
     "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>",
-    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2, 3, 0>", "stem_bf16x3_kernel"};
+    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2, 4, 0>", "stem_bf16x3_kernel"};
+
+// ---- measurement hook: per-wave cycle accounting of the 128-wide bf16x3 kernel (lwg_conv_trace, tools/conv_trace.py)
+constexpr int kTraceMaxLaunches = 4096;
+struct TraceLaunch { size_t offset; int gx, gy, gz, waves, stages, cin, cout, hm, n; };
+struct TraceState {
+    void *buf = nullptr; size_t bytes = 0, used = 0; int n = 0;
+    TraceLaunch launch[kTraceMaxLaunches];
+};
+static TraceState g_trace;
+
+int conv_trace_set(void *device_buffer, size_t bytes)
+{
+    g_trace.buf = device_buffer; g_trace.bytes = device_buffer ? bytes : 0; g_trace.used = 0; g_trace.n = 0;
+    return LWG_OK;
+}
+int conv_trace_launch(int idx, long long *v)
+{
+    if (idx < 0 || idx >= g_trace.n) return LWG_ERR_INVALID_ARG;
+    const TraceLaunch &L = g_trace.launch[idx];
+    v[0] = (long long)L.offset; v[1] = L.gx; v[2] = L.gy; v[3] = L.gz; v[4] = L.waves; v[5] = L.stages; v[6] = L.cin; v[7] = L.cout;
+    v[8] = L.hm; v[9] = L.n;
+    return LWG_OK;
+}
 
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
 {
@@ -1222,8 +1292,48 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         }
         for (int p = 0; p < a.nphase; ++p)
             if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the bf16x3 path");
+        static const char *ring = getenv("LWG_RING");   // "3": the round-2 3-slot ring on the 128-wide tile (A/B switch)
+        const bool ring4 = !(ring && ring[0] == '3');
+        if (g_trace.buf && bn == 128 && ring4) {
+            // measurement hook (lwg_conv_trace): the same kernel with s_memtime accounting, one record block per launch
+            const size_t need = (size_t)grid.x * grid.y * grid.z * 4 * 8 * sizeof(unsigned long long);
+            if (g_trace.used + need <= g_trace.bytes && g_trace.n < kTraceMaxLaunches) {
+                ConvArgs t = a;
+                t.trace = reinterpret_cast<unsigned long long *>(static_cast<char *>(g_trace.buf) + g_trace.used);
+                TraceLaunch &L = g_trace.launch[g_trace.n++];
+                L.offset = g_trace.used; L.gx = grid.x; L.gy = grid.y; L.gz = grid.z; L.waves = 4;
+                L.stages = a.ph[a.fuse_phases ? 0 : 0].Kpad / BK; L.cin = a.Cin; L.cout = a.Cout; L.hm = a.Hm; L.n = a.N;
+                g_trace.used += need;
+                static DeviceOnce optt;
+                if (!optt.done()) {
+                    LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<128, 2, 2, 4, 512>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (BM + 128) * BK * (int)sizeof(float)));
+                    optt.mark();
+                }
+                conv_igemm_bf16x3<128, 2, 2, 4, 512><<<grid, 256, (size_t)4 * (BM + 128) * BK * sizeof(float), st>>>(t);
+                if (variant) *variant = kIgemmBf16x3_128;
+                LWG_LAUNCH_CHECK("conv_igemm_bf16x3 (traced)");
+                return LWG_OK;
+            }
+        }
         if (bn == 64) {
             conv_igemm_bf16x3<64, 1, 2><<<grid, 256, lds3, st>>>(a);
+        } else if (ring && ring[0] == '5') {   // measurement switch: 5 slots = all 160 KiB of a CU's LDS
+            static DeviceOnce opt5;
+            if (!opt5.done()) {
+                LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<128, 2, 2, 5>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (BM + 128) * BK * (int)sizeof(float)));
+                opt5.mark();
+            }
+            conv_igemm_bf16x3<128, 2, 2, 5><<<grid, 256, (size_t)5 * (BM + 128) * BK * sizeof(float), st>>>(a);
+        } else if (ring4) {
+            static DeviceOnce opt4;
+            if (!opt4.done()) {
+                LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<128, 2, 2, 4>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (BM + 128) * BK * (int)sizeof(float)));
+                opt4.mark();
+            }
+            conv_igemm_bf16x3<128, 2, 2, 4><<<grid, 256, (size_t)4 * (BM + 128) * BK * sizeof(float), st>>>(a);
         } else {
             conv_igemm_bf16x3<128, 2, 2><<<grid, 256, lds3, st>>>(a);
         }

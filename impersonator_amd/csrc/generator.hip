@@ -371,6 +371,8 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     a.precision = (g->split && L.w_split) ? 1 : 0;   // the 7x7 stem (Cin 6, fp32 NHWC8 input) stays on the fp32 kernel
     static const bool natural = getenv("LWG_NATURAL_TILE_ORDER") != nullptr;   // A/B switch for measurements
     a.natural_order = natural ? 1 : 0;
+    static const char *k_order = getenv("LWG_K_ORDER");                          // "channel": the round-2 walk (A/B switch)
+    a.tap_inner = (k_order && k_order[0] == 'c') ? 0 : 1;
     a.zeros = g->zeros;
     if (a.precision == 1) {
         a.zeros = zero_tail_of(g, x);
@@ -1041,6 +1043,14 @@ int lwg_generator_profile(lwg_generator *g, int enable)
 }
 
 int lwg_generator_profile_variants(void) { return kIgemmVariants; }
+
+int lwg_conv_trace(void *device_buffer, size_t bytes) { return conv_trace_set(device_buffer, bytes); }
+
+int lwg_conv_trace_launch(int index, long long *info10)
+{
+    LWG_REQUIRE(info10, "conv_trace_launch: NULL argument");
+    return conv_trace_launch(index, info10);
+}
 
 const char *lwg_generator_profile_variant_name(int variant)
 {

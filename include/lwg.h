@@ -330,6 +330,15 @@ LWG_API const char *lwg_generator_profile_variant_name(int variant);
 LWG_API int lwg_generator_profile_read(lwg_generator *g, int variant, int *launches, double *total_ms,
                                        double *total_flops);
 
+/* Measurement hook (tools/conv_trace.py; no reference counterpart -- rocprofv3's thread trace has no decoder in this
+ * image): with a device buffer set, every launch of the dominant 128-channel bf16x3 conv kernel runs its instrumented
+ * twin (same code + s_memtime reads around the stage's data wait and barrier) and appends one block of
+ * [workgroup][wave][8] uint64 {start, loop start, loop end, end, cycles in the data wait, cycles in the barrier,
+ * stages, hw id}.  trace_launch(i): {byte offset, grid x, y, z, waves, stages, Cin, Cout, Hm, N} of traced launch i, or
+ * LWG_ERR_INVALID_ARG past the last one.  conv_trace(NULL, 0) switches it off.  Process-wide, not thread-safe. */
+LWG_API int lwg_conv_trace(void *device_buffer, size_t bytes);
+LWG_API int lwg_conv_trace_launch(int index, long long *info10);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,4 +153,4 @@ def test_bench_train_under_torchrun():
     line = json.loads(lines[0])
     assert line["world"] == 2 and line["batch_per_rank"] == 2 and line["images_per_s"] > 0
     ar = line["all_reduce"]
-    assert ar["G_bytes"] > 3.8e8 and 2.7e7 < ar["D_bytes"] < 2.9e7 and ar["G_ms"] > 0 and ar["D_ms"] > 0
+    assert ar["G_bytes"] > 3.8e8 and 2.7e7 < ar["D_bytes"] < 3.1e7   # 27.8 MB of parameters + the layout's padding rows and ar["G_ms"] > 0 and ar["D_ms"] > 0

@@ -1,0 +1,362 @@
+// tools/coresidency_repro.hip -- torch-free reproducer of the co-residency miscompute of DESIGN.md section 5.1.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/coresidency_repro.hip -o tools/_build/coresidency_repro
+//   hipcc ... -DREAL_NEIGHBOUR -DLWG_IGEMM_BENCH tools/coresidency_repro.hip impersonator_amd/csrc/capi.hip -o tools/_build/coresidency_repro_real
+//   coresidency_repro [launches=300] [victim=1] [neighbour=2] [cumask=0]
+//
+// What round 2 saw inside the pipeline: a kernel of the rasteriser computes wrong values in single quarter-waves
+// (16 lanes) ONLY while workgroups of conv_igemm_bf16x3 run on the same device from other streams -- never alone, never
+// beside library GEMMs, never beside the exact-fp32 conv kernel.  Bisecting the neighbour left its ds_read_b128 stream
+// (MFMAs alone: clean).  Bisecting the victim left two code shapes; the more reliable one (297 of 300 launches wrong)
+// is reproduced here: ONE kernel that gathers a face's vertices, projects them, STORES the nine floats (three
+// global_store_dwordx3 per lane) and then runs ~150 VALU instructions of record arithmetic on the same registers
+// (back-face test, 3x3 inverse with nine divisions, bounding box) before storing the record.
+//
+//   victim   1 = fused gather -> stores -> arithmetic (the failing shape)
+//            2 = projection as its own kernel, arithmetic kernel reads what it wrote (the shape the product uses now)
+//            3 = fused, the nine stores moved BEHIND the arithmetic
+//            4 = fused as 1 + s_waitcnt vmcnt(0) right after the stores
+//            5 = fused as 1 with the nine stores issued as single dwords (probe DESIGN.md section 9 lists)
+//   neighbour 0 = none (control), 1 = MFMA stream only, 2 = ds_read_b128 + MFMA stream (stripped conv main loop:
+//            96 KiB of LDS per workgroup = one workgroup per CU, one wave per SIMD, one 16-byte LDS read behind every MFMA),
+//            3 = the product's conv_igemm_bf16x3<128> itself (only when built with -DREAL_NEIGHBOUR)
+//   cumask   0 = no masks; 1 = victim stream on CUs 0-127, neighbours on CUs 128-255 (same chip, never the same CU);
+//            2 = victim and neighbours both confined to CUs 0-127 (always share CUs)
+//
+// Every victim launch runs on fixed inputs into zeroed outputs and is compared word for word, on the device, with the
+// result of the same launch on an idle device.  Output: launches with at least one differing word, per output array.
+#include <hip/hip_runtime.h>
+#ifdef REAL_NEIGHBOUR
+#include "../impersonator_amd/csrc/conv.hip"
+#endif
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CHECK(x)                                                                                         \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } \
+    } while (0)
+
+namespace repro {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kTileW = 32, kTileH = 8;
+constexpr float kSliverRatio = 1e-4f, kHugeCoord = 1.0e6f;
+constexpr unsigned kTileBoxEmpty = 0x0000ffffu;
+struct Box { unsigned short x0, y0, x1, y1; };
+
+__device__ __forceinline__ bool backside(const float v[9]) { return (v[7] - v[1]) * (v[3] - v[0]) < (v[4] - v[1]) * (v[6] - v[0]); }
+
+__device__ __forceinline__ void face_inverse(const float v[9], int is, float px[3], float py[3], float inv[9], float &det)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        px[k] = 0.5f * (v[3 * k + 0] * is + is - 1);
+        py[k] = 0.5f * (v[3 * k + 1] * is + is - 1);
+    }
+    float m[9];
+    m[0] = py[1] - py[2]; m[1] = px[2] - px[1]; m[2] = px[1] * py[2] - px[2] * py[1];
+    m[3] = py[2] - py[0]; m[4] = px[0] - px[2]; m[5] = px[2] * py[0] - px[0] * py[2];
+    m[6] = py[0] - py[1]; m[7] = px[1] - px[0]; m[8] = px[0] * py[1] - px[1] * py[0];
+    det = px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) inv[k] = m[k] / det;
+}
+
+__device__ __forceinline__ unsigned record(const float v[9], int is, size_t t, float *faces_inv, Box *pbox)
+{
+    unsigned packed = kTileBoxEmpty;
+    if (!backside(v)) {
+        float px[3], py[3], inv[9], det;
+        face_inverse(v, is, px, py, inv, det);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) faces_inv[t * 9 + k] = inv[k];
+        const float xmn = fminf(fminf(px[0], px[1]), px[2]), xmx = fmaxf(fmaxf(px[0], px[1]), px[2]);
+        const float ymn = fminf(fminf(py[0], py[1]), py[2]), ymx = fmaxf(fmaxf(py[0], py[1]), py[2]);
+        const float ext = fmaxf(xmx - xmn, ymx - ymn);
+        bool finite = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) finite = finite && (px[k] - px[k] == 0.f) && (py[k] - py[k] == 0.f);
+        const bool sweep_all = !finite || !(fabsf(det) > kSliverRatio * ext * ext) ||
+                               fmaxf(fmaxf(fabsf(xmn), fabsf(xmx)), fmaxf(fabsf(ymn), fabsf(ymx))) > kHugeCoord;
+        int x0 = 0, y0 = 0, x1 = is - 1, y1 = is - 1;
+        if (!sweep_all) {
+            const float m = fmaxf(0.02f, ext * 0.025f);
+            x0 = max(0, (int)ceilf(xmn - m));
+            y0 = max(0, (int)ceilf(ymn - m));
+            x1 = min(is - 1, (int)floorf(xmx + m));
+            y1 = min(is - 1, (int)floorf(ymx + m));
+        }
+        if (x0 <= x1 && y0 <= y1) {
+            Box bx;
+            bx.x0 = (unsigned short)x0; bx.y0 = (unsigned short)y0; bx.x1 = (unsigned short)x1; bx.y1 = (unsigned short)y1;
+            pbox[t] = bx;
+            packed = (unsigned)(x0 / kTileW) | (unsigned)(y0 / kTileH) << 8 | (unsigned)(x1 / kTileW) << 16 | (unsigned)(y1 / kTileH) << 24;
+        }
+    }
+    return packed;
+}
+
+__device__ __forceinline__ void project(const float *verts, const float *cam, const int *faces_idx, int b, int nv, int fn, float eye_z,
+                                        float v[9])
+{
+    const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float *p = verts + ((size_t)b * nv + faces_idx[fn * 3 + k]) * 3;
+        v[3 * k + 0] = s * (p[0] + tx);
+        v[3 * k + 1] = -(s * (p[1] + ty));
+        v[3 * k + 2] = p[2] - eye_z;
+    }
+}
+
+// the failing shape and its variants
+template <int MODE>
+__global__ __launch_bounds__(256) void victim_fused(const float *__restrict__ verts, const float *__restrict__ cam,
+                                                    const int *__restrict__ faces_idx, int nv, float eye_z, float *__restrict__ faces,
+                                                    int bs, int nf, int is, float *__restrict__ faces_inv, Box *__restrict__ pbox,
+                                                    unsigned *__restrict__ tbox)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs * nf) return;
+    const int b = i / nf, fn = i - b * nf;
+    const size_t t = (size_t)i;
+    float v[9];
+    project(verts, cam, faces_idx, b, nv, fn, eye_z, v);
+    if (MODE == 1 || MODE == 4) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) faces[t * 9 + k] = v[k];
+        if (MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (MODE == 5) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) asm volatile("global_store_dword %0, %1, off" ::"v"(faces + t * 9 + k), "v"(v[k]) : "memory");
+    }
+    tbox[i] = record(v, is, t, faces_inv, pbox);
+    if (MODE == 3) {
+        float u[9];
+        project(verts, cam, faces_idx, b, nv, fn, eye_z, u);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) faces[t * 9 + k] = u[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void victim_project(const float *__restrict__ verts, const float *__restrict__ cam,
+                                                      const int *__restrict__ faces_idx, int nv, float eye_z, float *__restrict__ faces,
+                                                      int bs, int nf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs * nf) return;
+    float v[9];
+    project(verts, cam, faces_idx, i / nf, nv, i % nf, eye_z, v);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) faces[(size_t)i * 9 + k] = v[k];
+}
+
+__global__ __launch_bounds__(256) void victim_setup(const float *__restrict__ faces, int bs, int nf, int is, float *__restrict__ faces_inv,
+                                                    Box *__restrict__ pbox, unsigned *__restrict__ tbox)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs * nf) return;
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = faces[(size_t)i * 9 + k];
+    tbox[i] = record(v, is, (size_t)i, faces_inv, pbox);
+}
+
+__global__ void compare_words(const unsigned *a, const unsigned *b, size_t n, unsigned *count)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned bad = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) bad += a[i] != b[i];
+    if (bad) atomicAdd(count, bad);
+}
+
+// Stripped neighbour: the shape of conv_igemm_bf16x3<128>'s steady state without its DMA and barriers -- four waves,
+// 96 KiB of LDS (one workgroup per CU), per "stage" 16 ds_read_b128 of swizzled 128-byte rows, each behind one of 24
+// v_mfma_f32_32x32x16_bf16 on four accumulator tiles.  LDS = 0: the MFMA stream alone.
+template <bool LDS>
+__global__ __launch_bounds__(256) void neighbour_kernel(float *sink, int stages)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 24576; i += 256) smem[i] = __uint_as_float(0x3f803f80u + (unsigned)(i * 2654435761u >> 20));
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int frow = lane & 31, fsw = (frow >> 1) & 7;
+    const int a_row = ((wave >> 1) * 64 + frow) * 32, b_row = 128 * 32 + ((wave & 1) * 64 + frow) * 32;
+    float4 f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = make_float4(1.f, 0.5f, 0.25f, 2.f);
+    for (int s = 0; s < stages; ++s) {
+        const float *base = smem + (s % 3) * 8192;
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            const int t = q & 3;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[q & 7]), __builtin_bit_cast(bf16x8, f[(q + 3) & 7]),
+                                                             acc[t], 0, 0, 0);
+            if (LDS && q < 16) {
+                const int col = (((q & 7) ^ fsw) * 4);
+                const float *p = base + ((q & 8) ? b_row : a_row) + ((q & 4) ? 32 * 32 : 0) + col;
+                f[q & 7] = *reinterpret_cast<const float4 *>(p);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep += acc[t][r];
+    if (keep == 123.456f) sink[0] = keep;
+}
+
+}  // namespace repro
+
+using namespace repro;
+
+int main(int argc, char **argv)
+{
+    const int launches = argc > 1 ? atoi(argv[1]) : 300;
+    const int victim = argc > 2 ? atoi(argv[2]) : 1;
+    const int neigh = argc > 3 ? atoi(argv[3]) : 2;
+    const int cumask = argc > 4 ? atoi(argv[4]) : 0;
+    const int bs = 8, is = 256, GW = 84, GH = 82, nv = (GW + 1) * (GH + 1), nf = GW * GH * 2;
+    const float eye_z = -(1.0f / tanf(30.0f * 3.14159265f / 180.0f) + 1.0f);
+
+    // a body-sized sheet of 13776 small triangles (+ two whole-image slivers per frame, as the pipeline's mesh has), 8 cameras
+    std::vector<float> hverts((size_t)bs * nv * 3), hcam(bs * 3);
+    std::vector<int> hfaces(nf * 3);
+    srand(1);
+    for (int b = 0; b < bs; ++b) {
+        hcam[b * 3 + 0] = 0.8f + 0.03f * b; hcam[b * 3 + 1] = 0.01f * b; hcam[b * 3 + 2] = -0.02f * b;
+        for (int y = 0; y <= GH; ++y)
+            for (int x = 0; x <= GW; ++x) {
+                float *p = &hverts[((size_t)b * nv + y * (GW + 1) + x) * 3];
+                p[0] = -0.3f + 0.6f * x / GW + 0.002f * ((float)rand() / RAND_MAX);
+                p[1] = -0.85f + 1.7f * y / GH + 0.002f * ((float)rand() / RAND_MAX);
+                p[2] = 0.1f * sinf(0.2f * x + b) * cosf(0.15f * y);
+            }
+    }
+    for (int y = 0, f = 0; y < GH; ++y)
+        for (int x = 0; x < GW; ++x) {
+            const int v00 = y * (GW + 1) + x, v10 = v00 + 1, v01 = v00 + GW + 1, v11 = v01 + 1;
+            hfaces[f * 3 + 0] = v00; hfaces[f * 3 + 1] = v01; hfaces[f * 3 + 2] = v10; ++f;   // orientation: front-facing after the y flip
+            hfaces[f * 3 + 0] = v10; hfaces[f * 3 + 1] = v01; hfaces[f * 3 + 2] = v11; ++f;
+        }
+    hfaces[0] = 0; hfaces[1] = GW / 2; hfaces[2] = GW;                                         // two degenerate (collinear) faces: slivers
+    hfaces[3] = 0; hfaces[4] = (GW + 1) * (GH / 2); hfaces[5] = (GW + 1) * GH;
+
+    float *verts, *cam, *faces, *faces_inv, *ref_faces, *ref_inv, *sink;
+    int *faces_idx;
+    Box *pbox, *ref_pbox;
+    unsigned *tbox, *ref_tbox, *counts;
+    const size_t nface = (size_t)bs * nf;
+    CHECK(hipMalloc(&verts, hverts.size() * 4)); CHECK(hipMalloc(&cam, hcam.size() * 4)); CHECK(hipMalloc(&faces_idx, hfaces.size() * 4));
+    CHECK(hipMalloc(&faces, nface * 36)); CHECK(hipMalloc(&faces_inv, nface * 36)); CHECK(hipMalloc(&pbox, nface * 8)); CHECK(hipMalloc(&tbox, nface * 4));
+    CHECK(hipMalloc(&ref_faces, nface * 36)); CHECK(hipMalloc(&ref_inv, nface * 36)); CHECK(hipMalloc(&ref_pbox, nface * 8)); CHECK(hipMalloc(&ref_tbox, nface * 4));
+    CHECK(hipMalloc(&counts, 4 * 4)); CHECK(hipMalloc(&sink, 64));
+    CHECK(hipMemcpy(verts, hverts.data(), hverts.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(cam, hcam.data(), hcam.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(faces_idx, hfaces.data(), hfaces.size() * 4, hipMemcpyHostToDevice));
+
+    hipStream_t sv, sn[2];
+    if (cumask) {
+        // 256 CUs = 8 masks of 32 bits; victim on the low half, neighbours on the other (1) or the same (2) half
+        unsigned low[8] = {~0u, ~0u, ~0u, ~0u, 0, 0, 0, 0}, high[8] = {0, 0, 0, 0, ~0u, ~0u, ~0u, ~0u};
+        CHECK(hipExtStreamCreateWithCUMask(&sv, 8, low));
+        for (int k = 0; k < 2; ++k) CHECK(hipExtStreamCreateWithCUMask(&sn[k], 8, cumask == 1 ? high : low));
+    } else {
+        CHECK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) CHECK(hipStreamCreateWithFlags(&sn[k], hipStreamNonBlocking));
+    }
+    const int blocks = (int)((nface + 255) / 256);
+    auto run_victim = [&](hipStream_t st) {
+        CHECK(hipMemsetAsync(faces, 0, nface * 36, st)); CHECK(hipMemsetAsync(faces_inv, 0, nface * 36, st));
+        CHECK(hipMemsetAsync(pbox, 0, nface * 8, st)); CHECK(hipMemsetAsync(tbox, 0, nface * 4, st));
+        switch (victim) {
+            case 1: victim_fused<1><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 3: victim_fused<3><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 4: victim_fused<4><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 5: victim_fused<5><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            default:
+                victim_project<<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf);
+                victim_setup<<<blocks, 256, 0, st>>>(faces, bs, nf, is, faces_inv, pbox, tbox);
+        }
+        CHECK(hipGetLastError());
+    };
+    // reference: the same launch on an idle device
+    run_victim(sv);
+    CHECK(hipStreamSynchronize(sv));
+    CHECK(hipMemcpy(ref_faces, faces, nface * 36, hipMemcpyDeviceToDevice)); CHECK(hipMemcpy(ref_inv, faces_inv, nface * 36, hipMemcpyDeviceToDevice));
+    CHECK(hipMemcpy(ref_pbox, pbox, nface * 8, hipMemcpyDeviceToDevice)); CHECK(hipMemcpy(ref_tbox, tbox, nface * 4, hipMemcpyDeviceToDevice));
+    {
+        std::vector<unsigned> ht(nface);
+        CHECK(hipMemcpy(ht.data(), tbox, nface * 4, hipMemcpyDeviceToHost));
+        size_t live = 0;
+        for (unsigned v : ht) live += v != kTileBoxEmpty;
+        printf("reference: %zu of %zu faces have a non-empty box\n", live, nface);
+    }
+
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&neighbour_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&neighbour_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+#ifdef REAL_NEIGHBOUR
+    lwg::ConvArgs ca = {};
+    {
+        const int N = 8, H = 32, C = 512, K = 9 * C;
+        const size_t xin = (size_t)N * H * H * C;
+        float *xs, *ws, *y;
+        float2 *part;
+        CHECK(hipMalloc(&xs, xin * 4 + 4096)); CHECK(hipMemset(xs, 0x3c, xin * 4)); CHECK(hipMemset(xs + xin, 0, 4096));
+        CHECK(hipMalloc(&ws, (size_t)C * K * 4)); CHECK(hipMemset(ws, 0x3c, (size_t)C * K * 4));
+        CHECK(hipMalloc(&y, xin * 4)); CHECK(hipMalloc(&part, (size_t)(N * H * H / 128) * C * 8));
+        ca.w_split = ws; ca.w = ws; ca.x = xs; ca.ldx = C; ca.N = N; ca.H = H; ca.W = H; ca.Cin = C; ca.cin_log2 = 9; ca.zeros = xs + xin;
+        ca.y = y; ca.ldy = C; ca.Ho = H; ca.Wo = H; ca.Cout = C; ca.Hm = H; ca.Wm = H; ca.stride = 1; ca.pad = 1; ca.os = 1; ca.dil = 1;
+        ca.partials = part; ca.mtiles = N * H * H / 128; ca.nphase = 1; ca.precision = 1; ca.tap_inner = 1;
+        ca.ph[0].KH = ca.ph[0].KW = 3; ca.ph[0].ntaps = 9; ca.ph[0].Kpad = K; ca.ph[0].w_off = 0;
+    }
+#endif
+    auto run_neighbour = [&](hipStream_t st) {
+        if (neigh == 1) neighbour_kernel<false><<<256, 256, 98304, st>>>(sink, 150);
+        if (neigh == 2) neighbour_kernel<true><<<256, 256, 98304, st>>>(sink, 150);
+#ifdef REAL_NEIGHBOUR
+        if (neigh == 3) lwg::launch_conv_igemm_dbg(ca, 128, 200, st);
+#else
+        if (neigh == 3) { fprintf(stderr, "neighbour 3 needs -DREAL_NEIGHBOUR\n"); exit(2); }
+#endif
+    };
+
+    int wrong[4] = {0, 0, 0, 0};
+    unsigned long long words[4] = {0, 0, 0, 0};
+    for (int it = 0; it < launches; ++it) {
+        for (int k = 0; k < 6; ++k) run_neighbour(sn[k & 1]);       // ~0.3 ms of neighbours on each stream
+        CHECK(hipMemsetAsync(counts, 0, 16, sv));
+        run_victim(sv);
+        compare_words<<<256, 256, 0, sv>>>((const unsigned *)faces, (const unsigned *)ref_faces, nface * 9, counts + 0);
+        compare_words<<<256, 256, 0, sv>>>((const unsigned *)faces_inv, (const unsigned *)ref_inv, nface * 9, counts + 1);
+        compare_words<<<256, 256, 0, sv>>>((const unsigned *)pbox, (const unsigned *)ref_pbox, nface * 2, counts + 2);
+        compare_words<<<256, 256, 0, sv>>>(tbox, ref_tbox, nface, counts + 3);
+        unsigned h[4];
+        CHECK(hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, sv));
+        CHECK(hipStreamSynchronize(sv));
+        for (int k = 0; k < 4; ++k) { wrong[k] += h[k] != 0; words[k] += h[k]; }
+        if ((it & 7) == 7) { CHECK(hipStreamSynchronize(sn[0])); CHECK(hipStreamSynchronize(sn[1])); }
+    }
+    CHECK(hipDeviceSynchronize());
+    printf("victim %d neighbour %d cumask %d: launches with differing words (of %d): f2verts %d, faces_inv %d, pbox %d, tbox %d; "
+           "words: %llu %llu %llu %llu\n", victim, neigh, cumask, launches, wrong[0], wrong[1], wrong[2], wrong[3], words[0], words[1],
+           words[2], words[3]);
+    return 0;
+}

@@ -68,6 +68,10 @@ int main(int argc, char **argv)
         a.w = w; a.zeros = zeros; a.y = y; a.ldy = s.Cout; a.Ho = Ho; a.Wo = Ho; a.Cout = s.Cout;
         a.Hm = Ho; a.Wm = Ho; a.stride = s.stride; a.pad = pad; a.os = 1; a.dil = 1;
         a.partials = part; a.mtiles = mtiles; a.nphase = 1;
+        {   // LWG_K_ORDER=channel: the round-2 walk of the reduction (default: taps innermost)
+            const char *ko = getenv("LWG_K_ORDER");
+            a.tap_inner = (ko && ko[0] == 'c') ? 0 : 1;
+        }
         a.ph[0].KH = a.ph[0].KW = s.k; a.ph[0].ntaps = s.k * s.k; a.ph[0].Kpad = K; a.ph[0].w_off = 0;
         const double flop = 2.0 * s.N * Ho * Ho * (double)s.Cout * K;
         printf("%-30s", s.name);
