@@ -619,7 +619,9 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     // two waves sits in a DMA issue (~60 cycles), a counted wait or the stage barrier, the other one's MFMAs keep the
     // matrix pipe busy.
     static_assert((NW == 4 || NW == 8) && NS >= 3, "wave layout");
-    constexpr int A_CH = BMT / 8 / NW, B_CH = BN / 8 / NW;   // 1-KiB DMA chunks (8 rows x 128 B) per wave per stage
+    // DBG & 1024 (timing experiment only, results are garbage): one activation chunk per wave and stage instead of four --
+    // the DMA count a halo-resident activation operand would have
+    constexpr int A_CH = (DBG & 1024) ? 1 : BMT / 8 / NW, B_CH = BN / 8 / NW;   // 1-KiB DMA chunks (8 rows x 128 B) per wave per stage
     constexpr int LPS = A_CH + B_CH;
     constexpr int STAGE = (BMT + BN) * BK;                // floats (4-byte units) per ring slot
     constexpr int TILES = WM * WN;
@@ -664,8 +666,12 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     // The three reads of a stage are consumed at the NEXT stage's site, behind the lgkmcnt(0) that is there anyway, so
     // the instrumented kernel has no wait the production kernel does not have.
     unsigned long long tr_a = 0, tr_b = 0, tr_c = 0, tr_wait = 0, tr_bar = 0, tr_t0 = 0, tr_loop0 = 0, tr_loop1 = 0;
+    unsigned long long tr_d0 = 0, tr_d1 = 0, tr_d2 = 0, tr_d3 = 0, tr_dma = 0, tr_rt0 = 0;
     unsigned tr_stages = 0;
-    if (DBG & 512) tr_t0 = __builtin_amdgcn_s_memtime();
+    if (DBG & 512) {
+        tr_t0 = __builtin_amdgcn_s_memtime();
+        tr_rt0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: gives the shader clock the kernel really ran at
+    }
 
     // unfused phases: blockIdx.z counts the phase index down (most taps first, see conv_igemm_dma_f32)
     const int pz0 = a.fuse_phases ? 0 : a.nphase - 1 - (int)blockIdx.z;
@@ -804,7 +810,10 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
             if (q == QB) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (DBG & 512) {
-                    if (tr_stages) { tr_wait += tr_b - tr_a; tr_bar += tr_c - tr_b; }   // the previous stage's reads have landed
+                    if (tr_stages) {   // the previous stage's reads have landed
+                        tr_wait += tr_b - tr_a; tr_bar += tr_c - tr_b;
+                        tr_dma += (tr_d1 - tr_d0) + (tr_d3 - tr_d2);
+                    }
                     ++tr_stages;
                     tr_a = __builtin_amdgcn_s_memtime();
                 }
@@ -850,7 +859,13 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
                 const int pb = (q * LPS) / Q;                 // ... and before it: equal unless a piece rides behind q
                 if (pc != pb) {
                     __builtin_amdgcn_sched_barrier(0);
+                    // traced twin: cycles from before to after the issue of the stage's first activation piece and
+                    // first weight piece (both ahead of the stage's blocking site, where the reads are consumed)
+                    if ((DBG & 512) && pb == 0) tr_d0 = __builtin_amdgcn_s_memtime();
+                    if ((DBG & 512) && pb == A_CH) tr_d2 = __builtin_amdgcn_s_memtime();
                     dma_piece(pb, kt + (NS - 1), slot2);
+                    if ((DBG & 512) && pb == 0) tr_d1 = __builtin_amdgcn_s_memtime();
+                    if ((DBG & 512) && pb == A_CH) tr_d3 = __builtin_amdgcn_s_memtime();
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -914,7 +929,9 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         // barrier, stages, (xcc_id << 8 | cu_id-ish hw id)
         const unsigned long long tr_end = __builtin_amdgcn_s_memtime();
         unsigned long long *o = a.trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
-        o[0] = tr_t0; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = tr_end; o[4] = tr_wait; o[5] = tr_bar; o[6] = tr_stages;
+        const unsigned long long tr_rt1 = __builtin_amdgcn_s_memrealtime();
+        o[0] = tr_t0; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = tr_end; o[4] = tr_wait; o[5] = tr_bar;
+        o[6] = (unsigned long long)tr_stages | (tr_dma << 16) | ((tr_rt1 - tr_rt0) << 44);   // stages < 2^16, dma cycles < 2^28, 100 MHz ticks
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1318,6 +1335,14 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         }
         if (bn == 64) {
             conv_igemm_bf16x3<64, 1, 2><<<grid, 256, lds3, st>>>(a);
+        } else if (ring && ring[0] == 'x') {   // LWG_RING=x: timing experiment, WRONG RESULTS (see DBG & 1024)
+            static DeviceOnce optx;
+            if (!optx.done()) {
+                LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<128, 2, 2, 4, 1024>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (BM + 128) * BK * (int)sizeof(float)));
+                optx.mark();
+            }
+            conv_igemm_bf16x3<128, 2, 2, 4, 1024><<<grid, 256, (size_t)4 * (BM + 128) * BK * sizeof(float), st>>>(a);
         } else if (ring && ring[0] == '5') {   // measurement switch: 5 slots = all 160 KiB of a CU's LDS
             static DeviceOnce opt5;
             if (!opt5.done()) {
@@ -1462,6 +1487,9 @@ int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
         case 204: launch_k_dbg<3, 4>(a, bn, st); break;   // no barrier
         case 213: launch_k_dbg<3, 13>(a, bn, st); break;  // MFMAs only
         case 240: launch_k_dbg<4, 0>(a, bn, st); break;   // 4-slot ring
+        case 241: launch_k_dbg<4, 1>(a, bn, st); break;   // 4-slot ring, no steady-state DMA
+        case 245: launch_k_dbg<4, 13>(a, bn, st); break;  // 4-slot ring, MFMAs only
+        case 1240: launch_k_dbg<4, 1024>(a, bn, st); break;   // 4-slot ring, a quarter of the activation DMAs (timing only)
         case 232: launch_k_dbg<3, 32>(a, bn, st); break;  // no epilogue
         case 264: launch_k_dbg<3, 64>(a, bn, st); break;  // natural tile order (no XCD bands)
         case 328: launch_k_dbg<3, 128>(a, bn, st); break; // 4-byte epilogue stores

@@ -52,29 +52,29 @@ def run(lanes, lines):
         rec = host[off // 8: off // 8 + gx * gy * gz * waves * 8].reshape(gz, gy, gx, waves, 8).astype(np.int64)
         by_shape.setdefault((cin, cout, hm, n, gx, gy, gz, stages), []).append(rec)
     lines.append("### %d lane%s: %d traced launches over %d step(s)\n" % (lanes, "" if lanes == 1 else "s", len(launches), STEPS))
-    lines.append("| layer (Cin->Cout @ Hm, grid) | launches | kernel span (cycles) | entry skew | prologue | main loop | epilogue | "
-                 "cycles per stage (min %d) | data wait | barrier wait | issue + rest | tail (first wave out -> last) |" % MFMA_CYCLES_PER_STAGE)
-    lines.append("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    lines.append("| layer (Cin->Cout @ Hm, grid) | launches | prologue (cycles) | main loop | epilogue | cycles per stage (min %d) | "
+                 "data wait | barrier wait | cycles per DMA issue | shader clock (GHz) | wave lifetime (us) |" % MFMA_CYCLES_PER_STAGE)
+    lines.append("|---|---|---|---|---|---|---|---|---|---|---|")
     for key in sorted(by_shape, key=lambda k: -len(by_shape[k]) * k[4] * k[5] * k[6]):
         cin, cout, hm, n, gx, gy, gz, stages = key
         recs = by_shape[key]
-        span, skew, pro, loop, epi, per_stage, wait, bar, tail = [], [], [], [], [], [], [], [], []
+        pro, loop, epi, per_stage, wait, bar, dma, ghz, us = [], [], [], [], [], [], [], [], []
         for r in recs:
-            t0, l0, l1, t1, w, b, st = (r[..., i] for i in range(7))
-            first = t0.min()
-            span.append(t1.max() - first)
-            skew.append(np.mean(t0 - first))
+            t0, l0, l1, t1, w, b, packed = (r[..., i] for i in range(7))
+            st, dm, rt = packed & 0xffff, (packed >> 16) & 0xfffffff, (packed >> 44) & 0xfffff
             pro.append(np.mean(l0 - t0))
             loop.append(np.mean(l1 - l0))
             epi.append(np.mean(t1 - l1))
             per_stage.append(np.mean((l1 - l0) / np.maximum(st, 1)))
             wait.append(np.mean(w / np.maximum(l1 - l0, 1)))
             bar.append(np.mean(b / np.maximum(l1 - l0, 1)))
-            tail.append(t1.max() - t1.min())
+            dma.append(np.mean(dm / np.maximum(2 * (st - 1), 1)))       # two timed pieces per stage, from the second stage on
+            ghz.append(np.mean((t1 - t0) / np.maximum(rt, 1)) * 0.1)     # shader cycles per 10-ns tick
+            us.append(np.mean(rt) * 0.01)
         m = lambda v: float(np.mean(v))
-        lines.append("| %d->%d @%d (%dx%dx%d, %d stages) | %d | %.0f | %.0f | %.0f | %.0f | %.0f | %.0f | %.1f %% | %.1f %% | %.1f %% | %.0f |" % (
-            cin, cout, hm, gx, gy, gz, stages, len(recs), m(span), m(skew), m(pro), m(loop), m(epi), m(per_stage),
-            100 * m(wait), 100 * m(bar), 100 * (1 - m(wait) - m(bar)), m(tail)))
+        lines.append("| %d->%d @%d (%dx%dx%d, %d stages) | %d | %.0f | %.0f | %.0f | %.0f | %.1f %% | %.1f %% | %.0f | %.2f | %.1f |" % (
+            cin, cout, hm, gx, gy, gz, stages, len(recs), m(pro), m(loop), m(epi), m(per_stage),
+            100 * m(wait), 100 * m(bar), m(dma), m(ghz), m(us)))
     # the trunk layer in detail: distribution over workgroups and XCDs
     trunk = [k for k in by_shape if k[0] == 512 and k[1] == 512]
     if trunk:
@@ -94,8 +94,10 @@ def main():
     lines = ["# Cycle accounting of conv_igemm_bf16x3<128, 2, 2, 4> inside the bench pipeline (tools/conv_trace.py)\n",
              "s_memtime counts shader-clock cycles.  `data wait` = cycles between the reads before and after the stage's "
              "`s_waitcnt vmcnt(N) lgkmcnt(0)`; `barrier wait` = cycles in the `s_barrier` that follows (waves of a workgroup "
-             "waiting for the slowest one's data); `issue + rest` = everything else in the main loop (MFMA issue, DMA issue, "
-             "LDS fragment reads, address updates).  A stage issues 24 MFMAs of 32 cycles = %d cycles per wave at least.\n" % MFMA_CYCLES_PER_STAGE]
+             "waiting for the slowest one's data); `cycles per DMA issue` = s_memtime before to after one global_load_lds_dwordx4 "
+             "(+ its s_mov m0), averaged over the first activation piece and the first weight piece of every stage (a wave issues "
+             "8 per stage); the shader clock is the wave's cycle count over its 100 MHz s_memrealtime ticks.  A stage issues 24 "
+             "MFMAs of 32 cycles = %d cycles per wave at least.\n" % MFMA_CYCLES_PER_STAGE]
     for lanes in (1, 2):
         run(lanes, lines)
     text = "\n".join(lines) + "\n"

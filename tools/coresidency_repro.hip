@@ -171,6 +171,50 @@ __global__ __launch_bounds__(256) void victim_setup(const float *__restrict__ fa
     tbox[i] = record(v, is, (size_t)i, faces_inv, pbox);
 }
 
+// Micro-victim (victims 10-14): the suspected mechanism in isolation, in inline asm so that the instruction sequence is
+// exactly this: a 96-bit store from v[40:42], K wait states (victim 10 + k: K = 0, 1, 2, 4, 8; the ISA asks for 1 after a
+// store of more than 64 bits, hipcc emits s_nop 1 = 2), then VALU writes of NEW values to v40-42, then the registers are
+// read back.  counts[0] += lanes whose registers do not hold the new values (a VALU write was lost), and a second
+// kernel checks the stored words against the OLD values (counts[1]: the store picked up new data = the documented hazard).
+template <int K>
+__global__ __launch_bounds__(256) void victim_asm(unsigned *__restrict__ out_old, unsigned n, int iters, unsigned *__restrict__ counts)
+{
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    unsigned lost = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned a0 = tid * 3u + (unsigned)it * 7919u, a1 = a0 ^ 0x55aa55aau, a2 = a0 + 0x01234567u;
+        const unsigned b0 = ~a0, b1 = ~a1, b2 = ~a2;
+        unsigned *p = out_old + ((size_t)it * n + tid) * 3;
+        unsigned r0, r1, r2;
+        asm volatile("v_mov_b32 v40, %4\n\tv_mov_b32 v41, %5\n\tv_mov_b32 v42, %6\n\t"
+                     "s_nop 4\n\t"
+                     "global_store_dwordx3 %3, v[40:42], off\n\t"
+                     "s_nop %10\n\t"
+                     "v_mov_b32 v40, %7\n\tv_mov_b32 v41, %8\n\tv_mov_b32 v42, %9\n\t"
+                     "s_nop 4\n\t"
+                     "v_mov_b32 %0, v40\n\tv_mov_b32 %1, v41\n\tv_mov_b32 %2, v42\n\t"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                     : "v"(p), "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2), "n"(K > 0 ? K - 1 : 0)
+                     : "v40", "v41", "v42", "memory");
+        lost += (r0 != b0) + (r1 != b1) + (r2 != b2);
+    }
+    if (lost) atomicAdd(counts + 0, lost);
+}
+
+__global__ void victim_asm_check(const unsigned *__restrict__ out_old, unsigned n, int iters, unsigned *__restrict__ counts)
+{
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned a0 = tid * 3u + (unsigned)it * 7919u, a1 = a0 ^ 0x55aa55aau, a2 = a0 + 0x01234567u;
+        const unsigned *p = out_old + ((size_t)it * n + tid) * 3;
+        bad += (p[0] != a0) + (p[1] != a1) + (p[2] != a2);
+    }
+    if (bad) atomicAdd(counts + 1, bad);
+}
+
 __global__ void compare_words(const unsigned *a, const unsigned *b, size_t n, unsigned *count)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,11 +377,43 @@ int main(int argc, char **argv)
         if (neigh == 2) neighbour_kernel<true><<<256, 256, 98304, st>>>(sink, 150);
 #ifdef REAL_NEIGHBOUR
         if (neigh == 3) lwg::launch_conv_igemm_dbg(ca, 128, 200, st);
+        if (neigh >= 100 && lwg::launch_conv_igemm_dbg(ca, 128, neigh, st) != 0) { fprintf(stderr, "unknown variant %d\n", neigh); exit(2); }
 #else
-        if (neigh == 3) { fprintf(stderr, "neighbour 3 needs -DREAL_NEIGHBOUR\n"); exit(2); }
+        if (neigh >= 3) { fprintf(stderr, "neighbour %d needs -DREAL_NEIGHBOUR\n", neigh); exit(2); }
 #endif
     };
 
+    bool dumped = false;
+    if (victim >= 10) {
+        const int iters = 32;
+        const unsigned n = (unsigned)nface;
+        unsigned *out_old;
+        CHECK(hipMalloc(&out_old, (size_t)iters * n * 12));
+        int bad_launch[2] = {0, 0};
+        unsigned long long tot[2] = {0, 0};
+        for (int it = 0; it < launches; ++it) {
+            for (int k = 0; k < 6; ++k) run_neighbour(sn[k & 1]);
+            CHECK(hipMemsetAsync(counts, 0, 16, sv));
+            switch (victim) {
+                case 10: victim_asm<0><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts); break;
+                case 11: victim_asm<1><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts); break;
+                case 12: victim_asm<2><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts); break;
+                case 13: victim_asm<4><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts); break;
+                default: victim_asm<8><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts); break;
+            }
+            victim_asm_check<<<blocks, 256, 0, sv>>>(out_old, n, iters, counts);
+            unsigned h[4];
+            CHECK(hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, sv));
+            CHECK(hipStreamSynchronize(sv));
+            for (int k = 0; k < 2; ++k) { bad_launch[k] += h[k] != 0; tot[k] += h[k]; }
+            if ((it & 7) == 7) { CHECK(hipStreamSynchronize(sn[0])); CHECK(hipStreamSynchronize(sn[1])); }
+        }
+        CHECK(hipDeviceSynchronize());
+        printf("asm victim %d (wait states %d) neighbour %d cumask %d: launches (of %d) with lost VALU writes %d (%llu registers), with "
+               "stored words != old values %d (%llu words)\n", victim, victim == 10 ? 0 : victim == 11 ? 1 : victim == 12 ? 2 : victim == 13 ? 4 : 8,
+               neigh, cumask, launches, bad_launch[0], tot[0], bad_launch[1], tot[1]);
+        return 0;
+    }
     int wrong[4] = {0, 0, 0, 0};
     unsigned long long words[4] = {0, 0, 0, 0};
     for (int it = 0; it < launches; ++it) {
@@ -352,6 +428,35 @@ int main(int argc, char **argv)
         CHECK(hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, sv));
         CHECK(hipStreamSynchronize(sv));
         for (int k = 0; k < 4; ++k) { wrong[k] += h[k] != 0; words[k] += h[k]; }
+        if (!dumped && (h[1] || h[3]) && getenv("REPRO_DUMP")) {
+            // what is wrong: per face (= lane) expected / got, so that the pattern over lanes and the values can be read
+            dumped = true;
+            std::vector<float> gi(nface * 9), ri(nface * 9), gf(nface * 9);
+            std::vector<unsigned> gt(nface), rt(nface);
+            CHECK(hipMemcpy(gi.data(), faces_inv, nface * 36, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ri.data(), ref_inv, nface * 36, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(gf.data(), faces, nface * 36, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(gt.data(), tbox, nface * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(rt.data(), ref_tbox, nface * 4, hipMemcpyDeviceToHost));
+            int shown = 0;
+            size_t run_start = 0, nbad = 0;
+            for (size_t i = 0; i < nface; ++i) {
+                const bool bad = gt[i] != rt[i] || memcmp(&gi[i * 9], &ri[i * 9], 36) != 0;
+                if (bad) {
+                    if (!nbad || i != run_start + nbad) { if (nbad) printf("  run of %zu faces from %zu (wave %zu, lane %zu)\n", nbad, run_start, run_start / 64, run_start % 64); run_start = i; nbad = 0; }
+                    ++nbad;
+                    if (shown < 6) {
+                        ++shown;
+                        printf("  face %zu (block %zu wave %zu lane %zu): tbox exp %08x got %08x\n    inv exp", i, i / 256, (i / 64) % 4, i % 64, rt[i], gt[i]);
+                        for (int k = 0; k < 9; ++k) printf(" %.6g", ri[i * 9 + k]);
+                        printf("\n    inv got");
+                        for (int k = 0; k < 9; ++k) printf(" %.6g(%08x)", gi[i * 9 + k], *(unsigned *)&gi[i * 9 + k]);
+                        printf("\n    f2v got");
+                        for (int k = 0; k < 9; ++k) printf(" %.6g", gf[i * 9 + k]);
+                        printf("\n");
+                    }
+                }
+            }
+            if (nbad) printf("  run of %zu faces from %zu (wave %zu, lane %zu)\n", nbad, run_start, run_start / 64, run_start % 64);
+        }
         if ((it & 7) == 7) { CHECK(hipStreamSynchronize(sn[0])); CHECK(hipStreamSynchronize(sn[1])); }
     }
     CHECK(hipDeviceSynchronize());
