@@ -75,7 +75,7 @@ int conv_trace_launch(int idx, long long *v10);
 
 // bn = 64 or 128 output channels per workgroup tile.  *variant (optional) receives which kernel instantiation ran:
 enum { kIgemmReg64 = 0, kIgemmReg128 = 1, kIgemmSmallCin = 2, kIgemmDma64 = 3, kIgemmDma128 = 4, kIgemmBf16x3_64 = 5,
-       kIgemmBf16x3_128 = 6, kDirectStemBf16x3 = 7, kIgemmVariants = 8 };
+       kIgemmBf16x3_128 = 6, kDirectStemBf16x3 = 7, kHaloBf16x3_128 = 8, kHaloBf16x3_64 = 9, kIgemmVariants = 10 };
 extern const char *const kIgemmVariantNames[kIgemmVariants];
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant = nullptr);
 

@@ -952,6 +952,264 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv3x3_halo_bf16x3 -- 3x3 / stride 1 / pad 1 convolutions (the trunk and the skipper convs: 15 of the 19 launches of
+// a step) with the ACTIVATION operand resident in LDS as a halo.
+//
+// Why (profiles/r03_conv_trace.md, tools/conv_trace.py): inside the pipeline conv_igemm_bf16x3<128> spends 3 % of its
+// main loop waiting for data and 2 % in barriers, yet a stage takes ~1250 cycles against the 768 its 24 MFMAs need.
+// What it is short of is global->LDS transfer: 32 KiB per stage and CU = 32 DMA instructions, half of them re-loading
+// activation pixels the CU already holds -- tap (kh,kw) of a 128-pixel tile is the same pixels shifted by one.  With a
+// quarter of the activation DMAs (wrong results, timing only) the same kernel runs 24 % faster in the pipeline.
+//
+// So: a workgroup's 128 output pixels are TR rows x TC columns of one image (TC = min(W, 128), consecutive pixels, the
+// epilogue is the implicit GEMM's); for one 32-channel slice it keeps the (TR+2) x (TC+2) input halo in LDS (204 / 264
+// / 390 pixels x 128 B) and runs all nine taps from it -- tap (kh,kw) of MFMA row tile i is the 32 consecutive halo
+// pixels starting at (r_i + kh) * (TC+2) + c_i + kw.  Two halo slots: slice s+1 is fetched while slice s computes.  Per
+// stage a CU now moves 16 KiB of weights + 1/9 halo = 19 / 20 / 21.5 KiB instead of 32 (64-channel tile: 11.7 instead of 24).
+// The weight operand keeps the DMA ring of conv_igemm_bf16x3 (NS slots, NS-1 stages in flight, same fragment layout).
+//   * LDS image of a halo pixel = its 128-byte [hi x32 | lo x32] run with the 16-byte slots XOR-swizzled by (p >> 1) & 7,
+//     p = halo pixel index: 32 consecutive pixels from ANY start read conflict-free with ds_read_b128 (rows 2k, 2k+1
+//     share a swizzle and sit 128 B = 32 banks apart); the four fragments of a row (hi/lo x two k-blocks) are the base
+//     address ^ 32 / ^ 64 / ^ 96.
+//   * the nine taps of a slice are nine stage bodies (everything tap-dependent is an immediate or one SGPR add); the
+//     weight ring slot is a run-time offset.
+//   * halo pieces (1 KiB = 8 pixels each, NHW per wave and slice, the last ones may repeat a chunk so that every wave
+//     issues the same number) ride behind the MFMAs of taps 0..6, ahead of the stage's weight pieces; counted
+//     s_waitcnt: the pieces younger than the next stage's weights are known per tap at compile time.
+template <int NHW, int B_CH, int Q, int QB, int NS>
+struct HaloSched {
+    static constexpr int nh(int t) { return t < 7 ? NHW / 7 + (t < NHW % 7 ? 1 : 0) : 0; }   // halo pieces issued in tap t's stage
+    static constexpr int hstart(int t) { int n = 0; for (int u = 0; u < t; ++u) n += nh(u); return n; }
+    static constexpr int lps(int t) { return nh(t) + B_CH; }
+    static constexpr int pos(int t, int p) { return (p + 1) * Q / lps(t) - 1; }              // piece p rides behind this MFMA
+    static constexpr int issued(int t) { int n = 0; for (int p = 0; p < lps(t); ++p) n += pos(t, p) < QB ? 1 : 0; return n; }
+    // pieces younger than the LAST weight piece of the stage that loaded stage k+1's weights (= stage k - (NS-2)):
+    // everything issued in the NS-3 stages in between plus this stage's pieces ahead of the barrier
+    static constexpr int nwait(int t) { int n = issued(t); for (int d = 1; d <= NS - 3; ++d) n += lps((t + 9 - d) % 9); return n; }
+};
+
+template <int BN, int WM, int WN, int NS, int TC>
+__global__ __launch_bounds__(256) void conv3x3_halo_bf16x3(const ConvArgs a)
+{
+    constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BM / (32 * WM);
+    static_assert(WAVES_M * WAVES_N == 4 && (NS == 3 || NS == 4) && BM % TC == 0 && TC % 32 == 0, "layout");
+    constexpr int TR = BM / TC, HC = TC + 2, HR = TR + 2, HP = HR * HC;
+    constexpr int NCH = (HP + 7) / 8;              // 1-KiB chunks (8 halo pixels) of one halo
+    constexpr int NHW = (NCH + 3) / 4;             // chunks a wave loads per slice
+    constexpr int HALO = NCH * 8 * BK;             // floats per halo slot
+    constexpr int B_CH = BN / 8 / 4, BSTAGE = BN * BK, BOFF = 2 * HALO;
+    constexpr int TILES = WM * WN, Q = 6 * TILES, QB = Q * 3 / 4, NL = 2 * (WM + WN);
+    constexpr int RPM = (NL + (Q - QB) - 1) / (Q - QB);
+    using S = HaloSched<NHW, B_CH, Q, QB, NS>;
+    static_assert(S::hstart(9) == NHW && Q >= NHW / 7 + 1 + B_CH, "halo pieces fit taps 0..6, one piece per MFMA at most");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    int bx = blockIdx.x;
+    const int by = blockIdx.y;
+    if (!a.natural_order && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD bands
+    const int m0 = bx * BM, n0 = by * BN;
+    const int hw_m = a.Hm * a.Wm, img = m0 / hw_m, rem0 = m0 - img * hw_m;
+    const int h0 = rem0 / a.Wm, w0 = rem0 - h0 * a.Wm;      // tile origin: TR rows x TC columns (w0 = 0 unless W > TC)
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    auto uniform_ptr = [](const void *p) {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+    };
+    auto dma16 = [&](unsigned voff, const char *sbase, unsigned lds_byte) {
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(voff), "s"(sbase), "s"(lds_byte)
+                     : "memory", "m0");
+    };
+    const ConvPhase ph = a.ph[0];
+    const int lr = lane >> 3, ls = lane & 7;
+    const float *xin = a.x + (size_t)img * a.H * a.W * a.ldx;
+    const char *x_base = uniform_ptr(xin);
+    const char *w_base = uniform_ptr(a.w_split + ph.w_off);
+    const unsigned zoff_b = (unsigned)((const char *)a.zeros - (const char *)xin);
+
+    // ---- halo chunks of this wave: chunk c = (wave + 4 j) mod NCH covers halo pixels 8c .. 8c+7; lane -> (pixel 8c + lane>>3,
+    //      16-byte slot lane&7), fetched from the swizzled source slot.  The byte offsets do not depend on the slice.
+    unsigned hoff[NHW];
+#pragma unroll
+    for (int j = 0; j < NHW; ++j) {
+        int c = wave + 4 * j;
+        if (c >= NCH) c -= NCH;
+        const int p = c * 8 + lr;
+        const int hr = p / HC, hc = p - hr * HC;
+        const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
+        const bool ok = p < HP && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+        hoff[j] = ok ? (unsigned)(((gh * a.W + gw) * a.ldx + (ls ^ ((p >> 1) & 7)) * 4) * 4) : zoff_b;
+    }
+    unsigned wvoff[B_CH];
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+        const int row = (wave * B_CH + j) * 8 + lr;
+        wvoff[j] = (unsigned)(((n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4) * 4);
+    }
+    const unsigned cin4 = (unsigned)a.Cin * 4u;
+    const int nslices = a.Cin / BK;
+    const unsigned wave_b = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((BOFF + wave * B_CH * 8 * BK) * 4));
+
+    // halo piece j of channel slice `sl` into halo slot hs
+    auto halo_piece = [&](int j, int sl, int hs) {
+        int c = wave + 4 * j;
+        if (c >= NCH) c -= NCH;
+        dma16(hoff[j], x_base + __builtin_amdgcn_readfirstlane((unsigned)sl * (BK * 4u)),
+              __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((hs * HALO + c * 8 * BK) * 4)));
+    };
+    // weight piece jb of reduction stage (tap it, slice is) into ring slot `slot`
+    auto weight_piece = [&](int jb, int it, int is, int slot) {
+        dma16(wvoff[jb], w_base + __builtin_amdgcn_readfirstlane((unsigned)it * cin4 + (unsigned)is * (BK * 4u)),
+              __builtin_amdgcn_readfirstlane(wave_b + (unsigned)((slot * BSTAGE + jb * 8 * BK) * 4)));
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment addressing
+    const int frow = lane & 31, half = lane >> 5, fsw = (frow >> 1) & 7;
+    int pl[WM];            // halo pixel of this lane's row of MFMA row tile i at tap (0,0)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = wave_m * 32 * WM + i * 32;
+        pl[i] = (m / TC) * HC + (m % TC) + frow;
+    }
+    // byte address (within smem) of the hi fragment of k-block 0; ^32: hi of k-block 1, ^64 / ^96: the lo fragments
+    auto a_addr = [&](int i, int tap, int hs) {
+        const int p = pl[i] + (tap / 3) * HC + (tap % 3);
+        return hs * (HALO * 4) + p * 128 + ((half ^ ((p >> 1) & 7)) << 4);
+    };
+    const int b_row = (wave_n * 32 * WN + frow) * BK;
+    int fcol[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fcol[c] = (((2 * c + half) ^ fsw) * 4);
+    struct Frags { float4 ah[WM], al[WM], bh[WN], bl[WN]; };
+    const char *smem_b = reinterpret_cast<const char *>(smem);
+    // fragment register idx of k-block kb, in the order the products consume them: lo(A), hi(B), hi(A), lo(B)
+    auto load_one = [&](const int (&aa)[WM], int bslot, int kb, Frags &f, int idx) {
+        const float *Bs = smem + BOFF + bslot * BSTAGE + b_row;
+        if (idx < WM) f.al[idx] = *reinterpret_cast<const float4 *>(smem_b + (aa[idx] ^ (64 + 32 * kb)));
+        else if (idx < WM + WN) f.bh[idx - WM] = *reinterpret_cast<const float4 *>(Bs + (idx - WM) * 32 * BK + fcol[kb]);
+        else if (idx < 2 * WM + WN) f.ah[idx - WM - WN] = *reinterpret_cast<const float4 *>(smem_b + (aa[idx - WM - WN] ^ (32 * kb)));
+        else f.bl[idx - 2 * WM - WN] = *reinterpret_cast<const float4 *>(Bs + (idx - 2 * WM - WN) * 32 * BK + fcol[2 + kb]);
+    };
+    Frags fr;          // k-block-0 fragments of the stage about to run
+    int cur_a[WM];     // A fragment base addresses of the stage about to run
+
+    // One stage = tap T of channel slice `sl`, weights in ring slot `slot`.  ISSUE: the stage also issues the halo pieces
+    // due in tap T (for slice sl+1, into the other halo slot) and the weights of stage k+NS-1; false for the last NS-1
+    // stages of the kernel.
+    auto stage_body = [&](auto tap_c, auto issue_c, int sl, int slot) {
+        constexpr int T = decltype(tap_c)::value;
+        constexpr bool ISSUE = decltype(issue_c)::value;
+        constexpr int TN = (T + 1) % 9;                       // next stage's tap
+        constexpr int IT = (T + NS - 1) % 9;                  // tap of the stage whose weights are issued here
+        const int slot1 = slot + 1 == NS ? 0 : slot + 1;      // next stage's weights
+        const int slot2 = slot == 0 ? NS - 1 : slot - 1;      // ring slot being refilled (read last by stage k-1)
+        const int hs = sl & 1, hs_next = T == 8 ? hs ^ 1 : hs;
+        const int is = sl + (T + NS - 1 >= 9 ? 1 : 0);        // slice of the stage whose weights are issued here
+        const int sl_halo = sl + 1 < nslices ? sl + 1 : 0;    // the last slice fetches a halo nobody reads
+        Frags f1, nx;
+        int nxt_a[WM];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int kb = q / (3 * TILES), r = q % (3 * TILES);
+            const int t = r / TILES, i = (r / WN) % WM, j = r % WN;   // cross terms first, hi*hi last
+            if (q == QB) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (ISSUE) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(S::nwait(T)) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int ii = 0; ii < WM; ++ii) nxt_a[ii] = a_addr(ii, TN, hs_next);
+            }
+            const Frags &f = kb == 0 ? fr : f1;
+            const float4 a4 = t == 0 ? f.al[i] : f.ah[i];
+            const float4 b4 = t == 1 ? f.bl[j] : f.bh[j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a4),
+                                                                __builtin_bit_cast(bf16x8_t, b4), acc[i][j], 0, 0, 0);
+            if (q < NL) {
+                load_one(cur_a, slot, 1, f1, q);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            } else if (q >= QB && RPM * (q - QB) < NL) {
+#pragma unroll
+                for (int r2 = 0; r2 < RPM; ++r2)
+                    if (RPM * (q - QB) + r2 < NL) load_one(nxt_a, slot1, 0, nx, RPM * (q - QB) + r2);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+            }
+            if (ISSUE) {
+#pragma unroll
+                for (int p = 0; p < S::lps(T); ++p)
+                    if (q == S::pos(T, p)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (p < S::nh(T)) halo_piece(S::hstart(T) + p, sl_halo, hs ^ 1);
+                        else weight_piece(p - S::nh(T), IT, is, slot2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+        }
+        fr = nx;
+#pragma unroll
+        for (int ii = 0; ii < WM; ++ii) cur_a[ii] = nxt_a[ii];
+    };
+
+    // ---- prologue: halo of slice 0, weights of stages 0 .. NS-2 (taps 0 .. NS-2 of slice 0); the first stage landed
+#pragma unroll
+    for (int j = 0; j < NHW; ++j) halo_piece(j, 0, 0);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+#pragma unroll
+        for (int jb = 0; jb < B_CH; ++jb) weight_piece(jb, st, 0, st);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * B_CH) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ii = 0; ii < WM; ++ii) cur_a[ii] = a_addr(ii, 0, 0);
+#pragma unroll
+    for (int idx = 0; idx < NL; ++idx) load_one(cur_a, 0, 0, fr, idx);
+
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    int slot = 0;
+    auto bump = [&]() { slot = slot + 1 == NS ? 0 : slot + 1; };
+#define LWG_HALO_STAGE(T, ISS) stage_body(std::integral_constant<int, T>{}, ISS{}, sl, slot); bump();
+    for (int sl = 0; sl + 1 < nslices; ++sl) {
+        LWG_HALO_STAGE(0, yes) LWG_HALO_STAGE(1, yes) LWG_HALO_STAGE(2, yes) LWG_HALO_STAGE(3, yes) LWG_HALO_STAGE(4, yes)
+        LWG_HALO_STAGE(5, yes) LWG_HALO_STAGE(6, yes) LWG_HALO_STAGE(7, yes) LWG_HALO_STAGE(8, yes)
+    }
+    {
+        const int sl = nslices - 1;   // last slice: its final NS-1 stages have nothing left to fetch
+        LWG_HALO_STAGE(0, yes) LWG_HALO_STAGE(1, yes) LWG_HALO_STAGE(2, yes) LWG_HALO_STAGE(3, yes) LWG_HALO_STAGE(4, yes)
+        LWG_HALO_STAGE(5, yes)
+        if constexpr (NS == 3) { LWG_HALO_STAGE(6, yes) } else { LWG_HALO_STAGE(6, no) }
+        LWG_HALO_STAGE(7, no) LWG_HALO_STAGE(8, no)
+    }
+#undef LWG_HALO_STAGE
+
+    __syncthreads();   // the epilogue's staging area aliases the halo
+    igemm_epilogue<BN, WM, WN, true, 4, BM>(a, ph, 0, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
+}
+
+// ------------------------------------------------------------------------------------------------
 // grid (C/16, N), 256 threads = 16 tile slices x 16 channels (64-byte coalesced rows of float2 partials)
 constexpr int FIN_CH = 16, FIN_SL = 16;
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float2 *__restrict__ partials, int nphase, int mtiles,
@@ -1203,7 +1461,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 const char *const kIgemmVariantNames[kIgemmVariants] = {
     "conv_igemm_f32<64, 1, 2, false, 0>", "conv_igemm_f32<128, 2, 2, false, 0>", "conv_igemm_f32<64, 1, 2, true, 0>",
     "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>",
-    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2, 4, 0>", "stem_bf16x3_kernel"};
+    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2, 4, 0>", "stem_bf16x3_kernel",
+    // the halo kernels run as <.., NS, TC> with TC = min(W, 128): the names are the prefix rocprofv3 prints
+    "conv3x3_halo_bf16x3<128, 2, 2", "conv3x3_halo_bf16x3<64, 1, 2"};
 
 // ---- measurement hook: per-wave cycle accounting of the 128-wide bf16x3 kernel (lwg_conv_trace, tools/conv_trace.py)
 constexpr int kTraceMaxLaunches = 4096;
@@ -1309,6 +1569,34 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         }
         for (int p = 0; p < a.nphase; ++p)
             if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the bf16x3 path");
+        // 3x3 / stride 1 / pad 1 with whole 128-pixel row blocks: the halo-resident kernel (conv3x3_halo_bf16x3)
+        static const char *halo_env = getenv("LWG_HALO");   // "0": the DMA-ring kernel everywhere (A/B switch)
+        const ConvPhase &p0 = a.ph[0];
+        if (!(halo_env && halo_env[0] == '0') && a.nphase == 1 && p0.KH == 3 && p0.KW == 3 && a.stride == 1 && a.pad == 1 &&
+            a.dil == 1 && a.os == 1 && a.H == a.Hm && a.W == a.Wm && p0.Kpad == 9 * a.Cin && !g_trace.buf &&
+            (a.Wm == 32 || a.Wm == 64 || a.Wm % 128 == 0) && (bn == 128 || a.Wm % 128 == 0)) {
+            const int tc = a.Wm < 128 ? a.Wm : 128;
+            static DeviceOnce halo_opt[4];
+            auto run = [&](auto kern, int ns, int tcv, DeviceOnce &once) -> int {
+                const int hp = (128 / tcv + 2) * (tcv + 2), nch = (hp + 7) / 8;
+                const size_t bytes = ((size_t)2 * nch * 8 * BK + (size_t)ns * bn * BK) * sizeof(float);
+                if (!once.done()) {
+                    LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+                    once.mark();
+                }
+                kern<<<grid, 256, bytes, st>>>(a);
+                return LWG_OK;
+            };
+            int rc;
+            if (bn == 128 && tc == 32) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32>, 4, 32, halo_opt[0]);
+            else if (bn == 128 && tc == 64) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 64>, 4, 64, halo_opt[1]);
+            else if (bn == 128) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 3, 128>, 3, 128, halo_opt[2]);
+            else rc = run(&conv3x3_halo_bf16x3<64, 1, 2, 4, 128>, 4, 128, halo_opt[3]);
+            if (rc != LWG_OK) return rc;
+            if (variant) *variant = bn == 128 ? kHaloBf16x3_128 : kHaloBf16x3_64;
+            LWG_LAUNCH_CHECK("conv3x3_halo_bf16x3");
+            return LWG_OK;
+        }
         static const char *ring = getenv("LWG_RING");   // "3": the round-2 3-slot ring on the 128-wide tile (A/B switch)
         const bool ring4 = !(ring && ring[0] == '3');
         if (g_trace.buf && bn == 128 && ring4) {
@@ -1481,6 +1769,11 @@ int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             conv_igemm_bf16x3<64, 2, 2, 3, 0, 256><<<grid, 256, lds, st>>>(a);
             break;
+        }
+        case 300: {   // whatever launch_conv_igemm picks for the bf16x3 path (the halo kernel where it applies)
+            ConvArgs b = a;
+            b.precision = 1;
+            return launch_conv_igemm(b, bn, st, nullptr);
         }
         case 200: launch_k_dbg<3, 0>(a, bn, st); break;
         case 201: launch_k_dbg<3, 1>(a, bn, st); break;   // no DMA

@@ -1,0 +1,148 @@
+"""Blast radius of the co-residency effect of DESIGN.md section 5.1 (kernels that compute wrong values in single quarter-waves
+only while conv_igemm_bf16x3 workgroups share their CUs): the once-per-source path (`personalize`: rasteriser, morph,
+InpaintSANet, source encoder) and one training iteration (three-stream generator forward, hand-written backward,
+discriminator update) run on one stream WHILE a second stream streams bf16x3 trunk convolutions, and every result is
+compared bit for bit with the same work on an otherwise idle device.  The grid_sample gradient adds with atomics (as
+torch's does), so the source stream's gradients -- the only tensors downstream of it -- are compared to 1e-5 instead.
+The motion-imitation pipeline itself has its own comparisons (tests/test_gpu_imitator.py::test_lane_pipeline_stress,
+tests/test_gpu_raster.py::test_rasteriser_beside_bf16x3_convolutions)."""
+import threading
+import time
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from impersonator_amd.utils import synthetic
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+class Bf16x3Neighbour(object):
+    """Keeps conv_igemm_bf16x3<128,...> launches (the 512->512 3x3 trunk layer, batch 16) queued on its own stream from a
+    helper thread for as long as the `with` block runs."""
+
+    def __init__(self):
+        g = torch.Generator().manual_seed(1)
+        self.x = (torch.rand(16, 32, 32, 512, generator=g) * 2 - 1).cuda()
+        self.w = (torch.randn(512, 512, 3, 3, generator=g) * 0.02).cuda()
+        self.stream = torch.cuda.Stream()
+        self.launched = 0
+        self._stop = threading.Event()
+        self._thread = None
+
+    def _run(self):
+        from impersonator_amd import ops
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(self.stream):
+            while not self._stop.is_set():
+                for _ in range(8):
+                    ops.conv2d_forward(self.x, self.w, None, 1, 1, False, "bf16x3")
+                    self.launched += 1
+                if self.launched % 64 == 0:
+                    self.stream.synchronize()     # bounded queue: at most 64 launches (~15 ms) ahead of the device
+
+    def __enter__(self):
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        while self.launched < 16:      # the device is busy with them before the victim starts
+            time.sleep(0.001)
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join()
+        self.stream.synchronize()
+
+
+def _personalize_once():
+    from impersonator_amd import demo
+    from impersonator_amd.networks.inpaintor import InpaintSANet
+    net = InpaintSANet(c_dim=4).eval()
+    shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.random_inpaintor_state_dict(shapes, 1).items()})
+    imitator, src_smpl, src_img, _ = demo.build_synthetic_imitator(batch_size=1, seed=0, affine="random")
+    imitator.bgnet = net.cuda()
+
+    def run():
+        imitator.personalize(src_img, src_smpl=src_smpl)      # no bg_img: the inpaintor produces the background
+        si = imitator.src_info
+        torch.cuda.synchronize()
+        out = dict(fim=si["fim"], wim=si["wim"], cond=si["cond"], p2verts=si["p2verts_c"], bg=si["bg"])
+        enc, res = si["feats"]
+        out.update({"enc%d" % i: t for i, t in enumerate(enc)})
+        out.update({"res%d" % i: t for i, t in enumerate(res)})
+        return {k: v.detach().clone() for k, v in out.items()}
+    return run
+
+
+def test_personalize_beside_bf16x3_convolutions():
+    run = _personalize_once()
+    ref = run()
+    again = run()
+    assert all(torch.equal(ref[k], again[k]) for k in ref), "personalize is not run-to-run deterministic on an idle device"
+    with Bf16x3Neighbour() as nb:
+        for trial in range(12):
+            got = run()
+            bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+            assert not bad, "trial %d beside %d bf16x3 launches: %s differ" % (trial, nb.launched, bad)
+        assert nb.launched > 100
+
+
+def _train_once(precision):
+    from impersonator_amd.models.impersonator_trainer import Impersonator
+    from oracle import torch_ref
+    opt = types.SimpleNamespace(image_size=64, batch_size=2, map_name='uv_seg', norm_type='instance', repeat_num=6, is_train=True,
+                                conv_precision=precision)
+    gsd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=2, affine="random"))
+    dsd = helpers.discriminator_state_dict(seed=3)
+    b = helpers.train_batch(seed=9, n=2, size=64)
+
+    def run():
+        m = Impersonator(opt)
+        m._G.load_state_dict(gsd)
+        m._D.load_state_dict(dsd)
+        m.set_input(b["input_G_tsf"].cuda(), b["real_tsf"].cuda(), input_G_bg=b["input_G_bg"].cuda(), input_G_src=b["input_G_src"].cuda(),
+                    T=b["T"].cuda(), real_src=b["real_src"].cuda(), bg_mask=b["bg_mask"].cuda())
+        losses = m.optimize_parameters()
+        torch.cuda.synchronize()
+        tr = m._generator_trainer()
+        out = {"loss/" + k: torch.tensor(v) for k, v in losses.items()}
+        out["fake_tsf"] = tr.fake_tsf.detach().clone()
+        out["fake_src"] = tr.fake_src.detach().clone()
+        out["d_grad"] = m._D.flat_buffers()[1].detach().clone()
+        out["d_par"] = m._D.flat_buffers()[0].detach().clone()
+        for k, g in tr.G.items():
+            out["g/" + k] = g.detach().clone()
+        m._D.release()
+        m._G.release()
+        return out
+    return run
+
+
+def _downstream_of_atomics(key):
+    # the grid_sample gradient (atomic adds) feeds the source stream's backward only
+    return key.startswith("g/src_model") or key == "g/heads:src_model" or key == "loss/never"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_training_iteration_beside_bf16x3_convolutions(precision):
+    run = _train_once(precision)
+    ref = run()
+
+    def compare(got, what):
+        for k in ref:
+            if _downstream_of_atomics(k):
+                # encoders / res-blocks of the source stream sit behind the Liquid-Warping-Block gradient
+                d = float((ref[k] - got[k]).abs().max())
+                assert d <= 1e-5 * max(1.0, float(ref[k].abs().max())), (what, k, d)
+            else:
+                assert torch.equal(ref[k], got[k]), (what, k, float((ref[k].float() - got[k].float()).abs().max()))
+
+    compare(run(), "idle device, second run")
+    with Bf16x3Neighbour() as nb:
+        for trial in range(6):
+            compare(run(), "trial %d beside %d bf16x3 launches" % (trial, nb.launched))
+        assert nb.launched > 100

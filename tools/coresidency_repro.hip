@@ -17,6 +17,8 @@
 //            3 = fused, the nine stores moved BEHIND the arithmetic
 //            4 = fused as 1 + s_waitcnt vmcnt(0) right after the stores
 //            5 = fused as 1 with the nine stores issued as single dwords (probe DESIGN.md section 9 lists)
+//            10-14 = asm micro-victim: ONE 96-bit store, K = 0/1/2/4/8 wait states, VALU overwrite of its data registers
+//            20 + 10*W + S = asm micro-victim 2: S (1-3) back-to-back stores of W (2-4) dwords, s_nop 1, VALU overwrite
 //   neighbour 0 = none (control), 1 = MFMA stream only, 2 = ds_read_b128 + MFMA stream (stripped conv main loop:
 //            96 KiB of LDS per workgroup = one workgroup per CU, one wave per SIMD, one 16-byte LDS read behind every MFMA),
 //            3 = the product's conv_igemm_bf16x3<128> itself (only when built with -DREAL_NEIGHBOUR)
@@ -202,6 +204,75 @@ __global__ __launch_bounds__(256) void victim_asm(unsigned *__restrict__ out_old
     if (lost) atomicAdd(counts + 0, lost);
 }
 
+// Micro-victim 2 (victims 20 + 10*W + S, W = store width in dwords 2..4, S = 1..3 back-to-back stores): S stores of W
+// dwords from consecutive register groups starting at v40, then the two wait states hipcc leaves after a wide store
+// (s_nop 1), then VALU writes of new values to ALL the stored registers, then read-back.  What the fused rasteriser setup
+// kernel does around its three global_store_dwordx3.
+template <int W, int S>
+__global__ __launch_bounds__(256) void victim_asm2(unsigned *__restrict__ out_old, unsigned n, int iters, unsigned *__restrict__ counts)
+{
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    unsigned lost = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned a = tid * 12u + (unsigned)it * 7919u, b = ~a;
+        unsigned *p = out_old + ((size_t)it * n + tid) * 12;     // 48 bytes per thread and iteration: 16-byte aligned
+        unsigned bad;
+        // v40..v51 = a + k (old); store groups; s_nop 1; v40..v51 = b + k (new); count registers that are not new
+#define LWG_OLD(k) "v_add_u32 v" #k ", %2, " #k " - 40\n\t"
+#define LWG_NEW(k) "v_add_u32 v" #k ", %3, " #k " - 40\n\t"
+#define LWG_CHK(k) "v_add_u32 v52, %3, " #k " - 40\n\tv_cmp_ne_u32 vcc, v52, v" #k "\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+        asm volatile("v_mov_b32 %0, 0\n\t"
+                     LWG_OLD(40) LWG_OLD(41) LWG_OLD(42) LWG_OLD(43) LWG_OLD(44) LWG_OLD(45) LWG_OLD(46) LWG_OLD(47) LWG_OLD(48)
+                     LWG_OLD(49) LWG_OLD(50) LWG_OLD(51)
+                     "s_nop 4\n\t"
+                     ".if %4 == 2\n\t"
+                     "global_store_dwordx2 %1, v[40:41], off\n\t"
+                     ".if %5 > 1\n\tglobal_store_dwordx2 %1, v[42:43], off offset:8\n\t.endif\n\t"
+                     ".if %5 > 2\n\tglobal_store_dwordx2 %1, v[44:45], off offset:16\n\t.endif\n\t"
+                     ".endif\n\t"
+                     ".if %4 == 3\n\t"
+                     "global_store_dwordx3 %1, v[40:42], off\n\t"
+                     ".if %5 > 1\n\tglobal_store_dwordx3 %1, v[44:46], off offset:12\n\t.endif\n\t"
+                     ".if %5 > 2\n\tglobal_store_dwordx3 %1, v[48:50], off offset:24\n\t.endif\n\t"
+                     ".endif\n\t"
+                     ".if %4 == 4\n\t"
+                     "global_store_dwordx4 %1, v[40:43], off\n\t"
+                     ".if %5 > 1\n\tglobal_store_dwordx4 %1, v[44:47], off offset:16\n\t.endif\n\t"
+                     ".if %5 > 2\n\tglobal_store_dwordx4 %1, v[48:51], off offset:32\n\t.endif\n\t"
+                     ".endif\n\t"
+                     "s_nop 1\n\t"
+                     LWG_NEW(40) LWG_NEW(41) LWG_NEW(42) LWG_NEW(43) LWG_NEW(44) LWG_NEW(45) LWG_NEW(46) LWG_NEW(47) LWG_NEW(48)
+                     LWG_NEW(49) LWG_NEW(50) LWG_NEW(51)
+                     "s_nop 4\n\t"
+                     LWG_CHK(40) LWG_CHK(41) LWG_CHK(42) LWG_CHK(43) LWG_CHK(44) LWG_CHK(45) LWG_CHK(46) LWG_CHK(47) LWG_CHK(48)
+                     LWG_CHK(49) LWG_CHK(50) LWG_CHK(51)
+                     : "=&v"(bad)
+                     : "v"(p), "v"(a), "v"(b), "n"(W), "n"(S)
+                     : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "vcc", "memory");
+#undef LWG_OLD
+#undef LWG_NEW
+#undef LWG_CHK
+        lost += bad;
+    }
+    if (lost) atomicAdd(counts + 0, lost);
+}
+
+template <int W, int S>
+__global__ void victim_asm2_check(const unsigned *__restrict__ out_old, unsigned n, int iters, unsigned *__restrict__ counts)
+{
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    unsigned bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned a = tid * 12u + (unsigned)it * 7919u;
+        const unsigned *p = out_old + ((size_t)it * n + tid) * 12;
+        for (int g = 0; g < S; ++g)
+            for (int j = 0; j < W; ++j) bad += p[g * W + j] != a + (W == 3 ? 4 * g : W * g) + j;   // 96-bit groups start at even registers
+    }
+    if (bad) atomicAdd(counts + 1, bad);
+}
+
 __global__ void victim_asm_check(const unsigned *__restrict__ out_old, unsigned n, int iters, unsigned *__restrict__ counts)
 {
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,6 +455,36 @@ int main(int argc, char **argv)
     };
 
     bool dumped = false;
+    if (victim >= 40) {
+        const int iters = 32, W = (victim - 20) / 10, S = (victim - 20) % 10;
+        const unsigned n = (unsigned)nface;
+        unsigned *out_old;
+        CHECK(hipMalloc(&out_old, (size_t)iters * n * 48));
+        int bad_launch[2] = {0, 0};
+        unsigned long long tot[2] = {0, 0};
+        for (int it = 0; it < launches; ++it) {
+            for (int k = 0; k < 6; ++k) run_neighbour(sn[k & 1]);
+            CHECK(hipMemsetAsync(counts, 0, 16, sv));
+#define LWG_CASE(w, s_)                                                                              \
+    if (W == w && S == s_) {                                                                          \
+        victim_asm2<w, s_><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts);                        \
+        victim_asm2_check<w, s_><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts);                  \
+    }
+            LWG_CASE(2, 1) LWG_CASE(2, 2) LWG_CASE(2, 3) LWG_CASE(3, 1) LWG_CASE(3, 2) LWG_CASE(3, 3) LWG_CASE(4, 1) LWG_CASE(4, 2) LWG_CASE(4, 3)
+#undef LWG_CASE
+            CHECK(hipGetLastError());
+            unsigned h[4];
+            CHECK(hipMemcpyAsync(h, counts, 16, hipMemcpyDeviceToHost, sv));
+            CHECK(hipStreamSynchronize(sv));
+            for (int k = 0; k < 2; ++k) { bad_launch[k] += h[k] != 0; tot[k] += h[k]; }
+            if ((it & 7) == 7) { CHECK(hipStreamSynchronize(sn[0])); CHECK(hipStreamSynchronize(sn[1])); }
+        }
+        CHECK(hipDeviceSynchronize());
+        printf("asm victim %d (%d back-to-back stores of %d dwords, s_nop 1, VALU overwrite) neighbour %d cumask %d: launches (of %d) with lost "
+               "VALU writes %d (%llu registers), with stored words != old values %d (%llu words)\n", victim, S, W, neigh, cumask, launches,
+               bad_launch[0], tot[0], bad_launch[1], tot[1]);
+        return 0;
+    }
     if (victim >= 10) {
         const int iters = 32;
         const unsigned n = (unsigned)nface;
