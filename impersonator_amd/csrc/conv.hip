@@ -43,7 +43,9 @@ constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B align
 // WIDE: the raw output goes through LDS (one 32x32 tile per wave at a time, 36-float pitch) so that it leaves as
 // 16-byte stores, 8 per tile, instead of 32 four-byte ones: the epilogue is store-ISSUE bound.  Callers must have a
 // barrier between their last LDS reads and this call; the statistics scratch sits behind the staging area.
-template <int BN, int WM, int WN, bool WIDE = false, int NWAVES = 4, int BMT = BM>
+// TC2 > 0: the tile's rows are a 2-D block of (BMT / TC2) image rows x TC2 columns whose origin pixel is `rem0` (row r of the
+// tile = pixel rem0 + (r / TC2) * Wm + r % TC2) instead of BMT consecutive pixels.
+template <int BN, int WM, int WN, bool WIDE = false, int NWAVES = 4, int BMT = BM, int TC2 = 0>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, int phase, f32x16 (&acc)[WM][WN],
                                                float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0,
                                                int mtile)
@@ -65,7 +67,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                 for (int q = 0; q < 4; ++q) {
                     const int row = q * 8 + rrow;
                     const float4 v = *reinterpret_cast<const float4 *>(stage + row * TP + rcol);
-                    const int rem = rem0 + wave_m * 32 * WM + i * 32 + row;
+                    const int trow = wave_m * 32 * WM + i * 32 + row;
+                    const int rem = rem0 + (TC2 > 0 ? (trow / (TC2 > 0 ? TC2 : 1)) * a.Wm + trow % (TC2 > 0 ? TC2 : 1) : trow);
                     const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
                     const size_t opix = ((size_t)img * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
                     *reinterpret_cast<float4 *>(a.y + opix * a.ldy + n0 + wave_n * 32 * WN + j * 32 + rcol) = v;
@@ -78,7 +81,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
-            const int rem = rem0 + row;
+            const int rem = rem0 + (TC2 > 0 ? (row / (TC2 > 0 ? TC2 : 1)) * a.Wm + row % (TC2 > 0 ? TC2 : 1) : row);
             const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
             const size_t opix = ((size_t)img * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
             float *yo = a.y + opix * a.ldy + n0 + wave_n * 32 * WN + col;
@@ -961,11 +964,12 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
 // activation pixels the CU already holds -- tap (kh,kw) of a 128-pixel tile is the same pixels shifted by one.  With a
 // quarter of the activation DMAs (wrong results, timing only) the same kernel runs 24 % faster in the pipeline.
 //
-// So: a workgroup's 128 output pixels are TR rows x TC columns of one image (TC = min(W, 128), consecutive pixels, the
-// epilogue is the implicit GEMM's); for one 32-channel slice it keeps the (TR+2) x (TC+2) input halo in LDS (204 / 264
-// / 390 pixels x 128 B) and runs all nine taps from it -- tap (kh,kw) of MFMA row tile i is the 32 consecutive halo
-// pixels starting at (r_i + kh) * (TC+2) + c_i + kw.  Two halo slots: slice s+1 is fetched while slice s computes.  Per
-// stage a CU now moves 16 KiB of weights + 1/9 halo = 19 / 20 / 21.5 KiB instead of 32 (64-channel tile: 11.7 instead of 24).
+// So: a workgroup's 128 output pixels are a block of TR = 4 rows x TC = 32 columns of one image (for W = 32: 128
+// consecutive pixels, the implicit GEMM's tile); for one 32-channel slice it keeps the (TR+2) x (TC+2) = 204-pixel input
+// halo in LDS (26 KiB) and runs all nine taps from it -- tap (kh,kw) of MFMA row tile i (= image row i of the block) is the
+// 32 consecutive halo pixels starting at (i + kh) * (TC+2) + kw.  Two halo slots: slice s+1 is fetched while slice s
+// computes.  Per stage a CU now moves 16 KiB of weights + 26/9 KiB of halo = 19 KiB instead of 32 (64-channel tile: 11 instead
+// of 24, and its 76 KiB of LDS still let two workgroups share a CU).
 // The weight operand keeps the DMA ring of conv_igemm_bf16x3 (NS slots, NS-1 stages in flight, same fragment layout).
 //   * LDS image of a halo pixel = its 128-byte [hi x32 | lo x32] run with the 16-byte slots XOR-swizzled by (p >> 1) & 7,
 //     p = halo pixel index: 32 consecutive pixels from ANY start read conflict-free with ds_read_b128 (rows 2k, 2k+1
@@ -1010,9 +1014,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16x3(const ConvArgs a)
     int bx = blockIdx.x;
     const int by = blockIdx.y;
     if (!a.natural_order && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD bands
-    const int m0 = bx * BM, n0 = by * BN;
-    const int hw_m = a.Hm * a.Wm, img = m0 / hw_m, rem0 = m0 - img * hw_m;
-    const int h0 = rem0 / a.Wm, w0 = rem0 - h0 * a.Wm;      // tile origin: TR rows x TC columns (w0 = 0 unless W > TC)
+    const int n0 = by * BN;
+    // tile bx = TR rows x TC columns of one image, tiles of an image in row-major order
+    const int tiles_x = a.Wm / TC, tiles_img = tiles_x * (a.Hm / TR);
+    const int img = bx / tiles_img, trem = bx - img * tiles_img;
+    const int h0 = (trem / tiles_x) * TR, w0 = (trem % tiles_x) * TC;
+    const int rem0 = h0 * a.Wm + w0;                         // origin pixel (the epilogue's 2-D row mapping starts here)
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     auto uniform_ptr = [](const void *p) {
         const unsigned long long v = (unsigned long long)p;
@@ -1206,7 +1213,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16x3(const ConvArgs a)
 #undef LWG_HALO_STAGE
 
     __syncthreads();   // the epilogue's staging area aliases the halo
-    igemm_epilogue<BN, WM, WN, true, 4, BM>(a, ph, 0, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
+    igemm_epilogue<BN, WM, WN, true, 4, BM, TC>(a, ph, 0, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1574,8 +1581,8 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         const ConvPhase &p0 = a.ph[0];
         if (!(halo_env && halo_env[0] == '0') && a.nphase == 1 && p0.KH == 3 && p0.KW == 3 && a.stride == 1 && a.pad == 1 &&
             a.dil == 1 && a.os == 1 && a.H == a.Hm && a.W == a.Wm && p0.Kpad == 9 * a.Cin && !g_trace.buf &&
-            (a.Wm == 32 || a.Wm == 64 || a.Wm % 128 == 0) && (bn == 128 || a.Wm % 128 == 0)) {
-            const int tc = a.Wm < 128 ? a.Wm : 128;
+            a.Wm % 32 == 0 && a.Hm % 4 == 0) {
+            const int tc = 32;
             static DeviceOnce halo_opt[4];
             auto run = [&](auto kern, int ns, int tcv, DeviceOnce &once) -> int {
                 const int hp = (128 / tcv + 2) * (tcv + 2), nch = (hp + 7) / 8;
@@ -1588,10 +1595,8 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
                 return LWG_OK;
             };
             int rc;
-            if (bn == 128 && tc == 32) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32>, 4, 32, halo_opt[0]);
-            else if (bn == 128 && tc == 64) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 64>, 4, 64, halo_opt[1]);
-            else if (bn == 128) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 3, 128>, 3, 128, halo_opt[2]);
-            else rc = run(&conv3x3_halo_bf16x3<64, 1, 2, 4, 128>, 4, 128, halo_opt[3]);
+            if (bn == 128) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32>, 4, tc, halo_opt[0]);
+            else rc = run(&conv3x3_halo_bf16x3<64, 1, 2, 3, 32>, 3, tc, halo_opt[1]);   // 52 + 24 KiB: two workgroups per CU
             if (rc != LWG_OK) return rc;
             if (variant) *variant = bn == 128 ? kHaloBf16x3_128 : kHaloBf16x3_64;
             LWG_LAUNCH_CHECK("conv3x3_halo_bf16x3");

@@ -17,6 +17,8 @@
 //            3 = fused, the nine stores moved BEHIND the arithmetic
 //            4 = fused as 1 + s_waitcnt vmcnt(0) right after the stores
 //            5 = fused as 1 with the nine stores issued as single dwords (probe DESIGN.md section 9 lists)
+//            6 = fused as 1 + 24 wait states (s_nop) between the stores and everything after them
+//            7 = fused, the 36 bytes stored as three (dwordx2 + dword) pairs
 //            10-14 = asm micro-victim: ONE 96-bit store, K = 0/1/2/4/8 wait states, VALU overwrite of its data registers
 //            20 + 10*W + S = asm micro-victim 2: S (1-3) back-to-back stores of W (2-4) dwords, s_nop 1, VALU overwrite
 //   neighbour 0 = none (control), 1 = MFMA stream only, 2 = ds_read_b128 + MFMA stream (stripped conv main loop:
@@ -132,10 +134,21 @@ __global__ __launch_bounds__(256) void victim_fused(const float *__restrict__ ve
     const size_t t = (size_t)i;
     float v[9];
     project(verts, cam, faces_idx, b, nv, fn, eye_z, v);
-    if (MODE == 1 || MODE == 4) {
+    if (MODE == 1 || MODE == 4 || MODE == 6) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) faces[t * 9 + k] = v[k];
         if (MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // 6: every later VALU instruction is held back by 24 wait states and a dependency on all nine registers
+        if (MODE == 6)
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]),
+                         "+v"(v[7]), "+v"(v[8])::"memory");
+    }
+    if (MODE == 7) {   // the same 36 bytes as 64-bit + 32-bit stores
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            asm volatile("global_store_dwordx2 %0, %1, off\n\tglobal_store_dword %0, %2, off offset:8" ::"v"(faces + t * 9 + 3 * k),
+                         "v"(*reinterpret_cast<const double *>(&v[3 * k])), "v"(v[3 * k + 2]) : "memory");
+        }
     }
     if (MODE == 5) {
 #pragma unroll
@@ -406,6 +419,8 @@ int main(int argc, char **argv)
             case 3: victim_fused<3><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 4: victim_fused<4><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 5: victim_fused<5><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 6: victim_fused<6><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 7: victim_fused<7><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             default:
                 victim_project<<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf);
                 victim_setup<<<blocks, 256, 0, st>>>(faces, bs, nf, is, faces_inv, pbox, tbox);
