@@ -48,7 +48,7 @@ constexpr int LDK = BK + 4;  // LDS row pitch in floats (144 B: keeps 16-B align
 template <int BN, int WM, int WN, bool WIDE = false, int NWAVES = 4, int BMT = BM, int TC2 = 0>
 __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhase &ph, int phase, f32x16 (&acc)[WM][WN],
                                                float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0,
-                                               int mtile)
+                                               int mtile, int sub_stride = 0)
 {
     // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rsel = 4 * (lane >> 5);
@@ -129,7 +129,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                 const float d = p.x - mean;
                 m2 += p.y + 32.f * d * d;
             }
-            a.partials[((size_t)phase * a.mtiles + (size_t)mtile * (BMT / BM) + sub) * a.Cout + n0 + ch] = make_float2(mean, m2);
+            // TC2 == 0: `mtile` counts BMT-row tiles; TC2 > 0: `mtile` is the index of the tile's first 128-row block and
+            // the following blocks sit `sub_stride` entries apart
+            const size_t pidx = TC2 > 0 ? (size_t)mtile + (size_t)sub * sub_stride : (size_t)mtile * (BMT / BM) + sub;
+            a.partials[((size_t)phase * a.mtiles + pidx) * a.Cout + n0 + ch] = make_float2(mean, m2);
         }
     }
 }
@@ -992,16 +995,20 @@ struct HaloSched {
     static constexpr int nwait(int t) { int n = issued(t); for (int d = 1; d <= NS - 3; ++d) n += lps((t + 9 - d) % 9); return n; }
 };
 
-template <int BN, int WM, int WN, int NS, int TC>
-__global__ __launch_bounds__(256) void conv3x3_halo_bf16x3(const ConvArgs a)
+// BMT = 256: eight waves (two per SIMD, 204 registers each) on an 8 x 32-pixel block -- the two 128-pixel halves share the
+// weight stage, so a CU moves 16 KiB of weights + 43/9 KiB of halo per TWO stages' worth of MFMAs.  For launches with at
+// least one such tile per CU (the skippers at batch 8, the trunk from batch 16).
+template <int BN, int WM, int WN, int NS, int TC, int BMT = BM>
+__global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void conv3x3_halo_bf16x3(const ConvArgs a)
 {
-    constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BM / (32 * WM);
-    static_assert(WAVES_M * WAVES_N == 4 && (NS == 3 || NS == 4) && BM % TC == 0 && TC % 32 == 0, "layout");
-    constexpr int TR = BM / TC, HC = TC + 2, HR = TR + 2, HP = HR * HC;
+    constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BMT / (32 * WM), NW = WAVES_M * WAVES_N;
+    static_assert((NW == 4 || NW == 8) && (NS == 3 || NS == 4) && BMT % TC == 0 && TC % 32 == 0, "layout");
+    constexpr int TR = BMT / TC, HC = TC + 2, HR = TR + 2, HP = HR * HC;
     constexpr int NCH = (HP + 7) / 8;              // 1-KiB chunks (8 halo pixels) of one halo
-    constexpr int NHW = (NCH + 3) / 4;             // chunks a wave loads per slice
+    constexpr int NHW = (NCH + NW - 1) / NW;       // chunks a wave loads per slice
     constexpr int HALO = NCH * 8 * BK;             // floats per halo slot
-    constexpr int B_CH = BN / 8 / 4, BSTAGE = BN * BK, BOFF = 2 * HALO;
+    constexpr int B_CH = BN / 8 / NW, BSTAGE = BN * BK, BOFF = 2 * HALO;
+    static_assert(B_CH >= 1, "a weight chunk per wave");
     constexpr int TILES = WM * WN, Q = 6 * TILES, QB = Q * 3 / 4, NL = 2 * (WM + WN);
     constexpr int RPM = (NL + (Q - QB) - 1) / (Q - QB);
     using S = HaloSched<NHW, B_CH, Q, QB, NS>;
@@ -1042,12 +1049,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16x3(const ConvArgs a)
     const char *w_base = uniform_ptr(a.w_split + ph.w_off);
     const unsigned zoff_b = (unsigned)((const char *)a.zeros - (const char *)xin);
 
-    // ---- halo chunks of this wave: chunk c = (wave + 4 j) mod NCH covers halo pixels 8c .. 8c+7; lane -> (pixel 8c + lane>>3,
+    // ---- halo chunks of this wave: chunk c = (wave + NW j) mod NCH covers halo pixels 8c .. 8c+7; lane -> (pixel 8c + lane>>3,
     //      16-byte slot lane&7), fetched from the swizzled source slot.  The byte offsets do not depend on the slice.
     unsigned hoff[NHW];
 #pragma unroll
     for (int j = 0; j < NHW; ++j) {
-        int c = wave + 4 * j;
+        int c = wave + NW * j;
         if (c >= NCH) c -= NCH;
         const int p = c * 8 + lr;
         const int hr = p / HC, hc = p - hr * HC;
@@ -1067,7 +1074,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16x3(const ConvArgs a)
 
     // halo piece j of channel slice `sl` into halo slot hs
     auto halo_piece = [&](int j, int sl, int hs) {
-        int c = wave + 4 * j;
+        int c = wave + NW * j;
         if (c >= NCH) c -= NCH;
         dma16(hoff[j], x_base + __builtin_amdgcn_readfirstlane((unsigned)sl * (BK * 4u)),
               __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((hs * HALO + c * 8 * BK) * 4)));
@@ -1213,7 +1220,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16x3(const ConvArgs a)
 #undef LWG_HALO_STAGE
 
     __syncthreads();   // the epilogue's staging area aliases the halo
-    igemm_epilogue<BN, WM, WN, true, 4, BM, TC>(a, ph, 0, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, bx);
+    // statistics: one (mean, M2) per 4 x 32 block, numbered row-major within the image whatever the tile height, so that
+    // the combination order in in_finalize (and with it every bit) does not depend on which variant ran
+    const int part0 = img * (tiles_x * (a.Hm / 4)) + (h0 / 4) * tiles_x + (w0 / TC);
+    igemm_epilogue<BN, WM, WN, true, NW, BMT, TC>(a, ph, 0, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, part0, tiles_x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1584,19 +1594,25 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
             a.Wm % 32 == 0 && a.Hm % 4 == 0) {
             const int tc = 32;
             static DeviceOnce halo_opt[4];
-            auto run = [&](auto kern, int ns, int tcv, DeviceOnce &once) -> int {
-                const int hp = (128 / tcv + 2) * (tcv + 2), nch = (hp + 7) / 8;
+            auto run = [&](auto kern, int ns, int bmt, DeviceOnce &once) -> int {
+                const int hp = (bmt / tc + 2) * (tc + 2), nch = (hp + 7) / 8;
                 const size_t bytes = ((size_t)2 * nch * 8 * BK + (size_t)ns * bn * BK) * sizeof(float);
                 if (!once.done()) {
                     LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
                     once.mark();
                 }
-                kern<<<grid, 256, bytes, st>>>(a);
+                const dim3 g(grid.x / (bmt / BM), grid.y, 1);
+                kern<<<g, bmt == 256 ? 512 : 256, bytes, st>>>(a);
                 return LWG_OK;
             };
+            // 8 x 32-pixel tiles with eight waves once every CU still gets one (the weight stage is shared by twice the MFMAs)
+            static const char *tall_env = getenv("LWG_HALO_TALL");   // "0": 4 x 32 tiles only (A/B switch)
+            const bool tall = bn == 128 && a.Hm % 8 == 0 && (long)(a.mtiles / 2) * (a.Cout / 128) >= device_cu_count() &&
+                              !(tall_env && tall_env[0] == '0');
             int rc;
-            if (bn == 128) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32>, 4, tc, halo_opt[0]);
-            else rc = run(&conv3x3_halo_bf16x3<64, 1, 2, 3, 32>, 3, tc, halo_opt[1]);   // 52 + 24 KiB: two workgroups per CU
+            if (tall) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 256>, 4, 256, halo_opt[2]);
+            else if (bn == 128) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32>, 4, 128, halo_opt[0]);
+            else rc = run(&conv3x3_halo_bf16x3<64, 1, 2, 3, 32>, 3, 128, halo_opt[1]);   // 52 + 24 KiB: two workgroups per CU
             if (rc != LWG_OK) return rc;
             if (variant) *variant = bn == 128 ? kHaloBf16x3_128 : kHaloBf16x3_64;
             LWG_LAUNCH_CHECK("conv3x3_halo_bf16x3");

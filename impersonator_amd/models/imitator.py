@@ -221,6 +221,8 @@ class Imitator(BaseModel):
     # configuration in which two rasteriser code shapes used to miscompute beside conv_igemm_bf16x3 -- an effect
     # that was removed by replacing those shapes, not explained.  Opt in with LWG_OVERLAP_GEOMETRY=1 / the keyword.
     overlap_geometry = False
+    # consecutive batches of a round that run as one generator launch sequence (see predict_batches); env LWG_FUSE
+    fuse = 1
     # entries of tsf_info with one row per frame (hmr.get_details + SMPLRenderer.transfer, imitator.py:236-268)
     PER_FRAME_KEYS = ('theta', 'cam', 'pose', 'shape', 'verts', 'j2d', 'j3d', 'fim', 'wim', 'cond', 'tsf_img', 'T')
 
@@ -257,6 +259,7 @@ class Imitator(BaseModel):
         import os
         nl = max(1, int(lanes if lanes is not None else os.environ.get("LWG_LANES", self.lanes)))
         depth = max(1, int(os.environ.get("LWG_ROUND_DEPTH", self.round_depth)))
+        fuse = max(1, int(os.environ.get("LWG_FUSE", self.fuse)))
         if overlap_geometry is None:
             env = os.environ.get("LWG_OVERLAP_GEOMETRY")
             overlap = self.overlap_geometry if env is None else env not in ("0", "", "false", "False")
@@ -287,30 +290,51 @@ class Imitator(BaseModel):
                     whole = torch.cat([c.reshape(n, -1) for (c, _), n in zip(items, sizes)], dim=0)
                     tsf_inputs = self.transfer_params_by_smpl(whole, cam_strategy, t=items[0][1])
                     info, k0 = self.tsf_info, 0
+                    whole_inputs, whole_T = tsf_inputs, info['T']
                     for (_, t), n in zip(items, sizes):
                         # the per-frame entries are named, not inferred from a leading dimension
                         part = {k: (v[k0:k0 + n] if k in self.PER_FRAME_KEYS else v) for k, v in info.items()}
-                        prepared.append((t, tsf_inputs[k0:k0 + n], part))
+                        prepared.append((t, tsf_inputs[k0:k0 + n], part, k0, n))
                         k0 += n
                 else:
+                    whole_inputs = whole_T = None
                     for chunk, t in items:
                         tsf_inputs = self.transfer_params_by_smpl(chunk, cam_strategy, t=t)
-                        prepared.append((t, tsf_inputs, self.tsf_info))
+                        prepared.append((t, tsf_inputs, self.tsf_info, 0, int(tsf_inputs.shape[0])))
                 ready = torch.cuda.Event()
                 ready.record(side)
+            # generator calls: `fuse` consecutive batches of the round as ONE launch sequence (their inputs are adjacent
+            # slices of the round's tensors): the trunk convolutions of 16 frames are 256 tiles of 8 x 32 pixels -- twice
+            # the MFMAs per weight stage of the 4 x 32 tiles 8 frames leave room for (conv3x3_halo_bf16x3)
+            groups, k = [], 0
+            while k < len(prepared):
+                g = [k]
+                while whole_inputs is not None and not self._opt.front_warp and len(g) < fuse and k + len(g) < len(prepared):
+                    g.append(k + len(g))
+                groups.append(g)
+                k += len(g)
             out = []
-            for k, (t, tsf_inputs, info) in enumerate(prepared):
-                st, gen = lane_list[k % nl]   # batch k of the round goes to lane k mod lanes, in order
+            for gi, g in enumerate(groups):
+                st, gen = lane_list[gi % nl]   # call gi of the round goes to lane gi mod lanes, in order
                 with torch.cuda.stream(st):
                     st.wait_event(ready)
-                    self.tsf_info = info
-                    preds = self.forward(tsf_inputs, info['T'], generator=gen)
-                    for v in [tsf_inputs] + [x for x in info.values() if torch.is_tensor(x)]:
-                        v.record_stream(st)   # allocated under the side stream, consumed here ...
-                        v.record_stream(main)  # ... and by whoever reads tsf_info after the yield
+                    if len(g) == 1:
+                        t, tsf_inputs, info, _, _ = prepared[g[0]]
+                        self.tsf_info = info
+                        preds = [self.forward(tsf_inputs, info['T'], generator=gen)]
+                    else:
+                        lo, hi = prepared[g[0]][3], prepared[g[-1]][3] + prepared[g[-1]][4]
+                        self.tsf_info = prepared[g[0]][2]
+                        both = self.forward(whole_inputs[lo:hi], whole_T[lo:hi], generator=gen)
+                        preds = [both[prepared[j][3] - lo:prepared[j][3] - lo + prepared[j][4]] for j in g]
+                    for j in g:
+                        for v in [prepared[j][1]] + [x for x in prepared[j][2].values() if torch.is_tensor(x)]:
+                            v.record_stream(st)   # allocated under the side stream, consumed here ...
+                            v.record_stream(main)  # ... and by whoever reads tsf_info after the yield
                     done = torch.cuda.Event()
                     done.record(st)
-                out.append((t, preds, info, done))
+                for j, p in zip(g, preds):
+                    out.append((prepared[j][0], p, prepared[j][2], done))
             return out
 
         def rounds():

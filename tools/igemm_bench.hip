@@ -18,6 +18,7 @@ int main(int argc, char **argv)
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
     const Shape shapes[] = {
         {"res 512->512 @32 (bn128)", 8, 32, 512, 512, 3, 1, 128},
+        {"res 512->512 @32 N=16 (bn128)", 16, 32, 512, 512, 3, 1, 128},
         {"skip0 512->256 @64 (bn128)", 8, 64, 512, 256, 3, 1, 128},
         {"skip1 256->128 @128 (bn128)", 8, 128, 256, 128, 3, 1, 128},
         {"skip2 128->64 @256 (bn64)", 8, 256, 128, 64, 3, 1, 64},
