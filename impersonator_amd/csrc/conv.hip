@@ -998,12 +998,27 @@ struct HaloSched {
 // BMT = 256: eight waves (two per SIMD, 204 registers each) on an 8 x 32-pixel block -- the two 128-pixel halves share the
 // weight stage, so a CU moves 16 KiB of weights + 43/9 KiB of halo per TWO stages' worth of MFMAs.  For launches with at
 // least one such tile per CU (the skippers at batch 8, the trunk from batch 16).
-template <int BN, int WM, int WN, int NS, int TC, int BMT = BM>
+//
+// CT = 1: ConvTranspose2d(k3, s2, p1, output_padding 1) as ONE launch.  Its four output parities (phases) are stride-1
+// correlations with 1 / 2 / 2 / 4 taps reading in(i + ty, j + tx), ty, tx in {0, 1} (generator.hip, init_convT): nine
+// (phase, tap) pairs per channel slice, all from the same (TR+1) x (TC+1) input halo.  The nine stage bodies are those
+// pairs; each accumulates into its phase's own set of tiles (4 x 64 AGPRs on the 128-channel tile) and the epilogue
+// runs once per phase.  The implicit-GEMM path ran the phases as separate workgroups of 4..16 stages each, most of
+// their life in prologue and epilogue (profiles/r03_conv_trace_ring.md).
+struct HaloCT {
+    static constexpr int phase(int t) { return t == 0 ? 0 : t < 3 ? 1 : t < 5 ? 2 : 3; }
+    static constexpr int tap(int t) { return t == 0 ? 0 : t < 3 ? t - 1 : t < 5 ? t - 3 : t - 5; }     // tap index inside its phase
+    static constexpr int dy(int t) { return (t == 4 || t == 7 || t == 8) ? 1 : 0; }
+    static constexpr int dx(int t) { return (t == 2 || t == 6 || t == 8) ? 1 : 0; }
+};
+
+template <int BN, int WM, int WN, int NS, int TC, int BMT = BM, int CT = 0>
 __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void conv3x3_halo_bf16x3(const ConvArgs a)
 {
+    constexpr int NPH = CT ? 4 : 1, PADL = CT ? 0 : 1;   // accumulator sets; halo rows / columns above and left of the tile
     constexpr int WAVES_N = BN / (32 * WN), WAVES_M = BMT / (32 * WM), NW = WAVES_M * WAVES_N;
     static_assert((NW == 4 || NW == 8) && (NS == 3 || NS == 4) && BMT % TC == 0 && TC % 32 == 0, "layout");
-    constexpr int TR = BMT / TC, HC = TC + 2, HR = TR + 2, HP = HR * HC;
+    constexpr int TR = BMT / TC, HC = TC + 2 - (CT ? 1 : 0), HR = TR + 2 - (CT ? 1 : 0), HP = HR * HC;
     constexpr int NCH = (HP + 7) / 8;              // 1-KiB chunks (8 halo pixels) of one halo
     constexpr int NHW = (NCH + NW - 1) / NW;       // chunks a wave loads per slice
     constexpr int HALO = NCH * 8 * BK;             // floats per halo slot
@@ -1046,7 +1061,6 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     const int lr = lane >> 3, ls = lane & 7;
     const float *xin = a.x + (size_t)img * a.H * a.W * a.ldx;
     const char *x_base = uniform_ptr(xin);
-    const char *w_base = uniform_ptr(a.w_split + ph.w_off);
     const unsigned zoff_b = (unsigned)((const char *)a.zeros - (const char *)xin);
 
     // ---- halo chunks of this wave: chunk c = (wave + NW j) mod NCH covers halo pixels 8c .. 8c+7; lane -> (pixel 8c + lane>>3,
@@ -1058,16 +1072,21 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         if (c >= NCH) c -= NCH;
         const int p = c * 8 + lr;
         const int hr = p / HC, hc = p - hr * HC;
-        const int gh = h0 - 1 + hr, gw = w0 - 1 + hc;
+        const int gh = h0 - PADL + hr, gw = w0 - PADL + hc;
         const bool ok = p < HP && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
         hoff[j] = ok ? (unsigned)(((gh * a.W + gw) * a.ldx + (ls ^ ((p >> 1) & 7)) * 4) * 4) : zoff_b;
     }
-    unsigned wvoff[B_CH];
+    unsigned wvoff[NPH][B_CH];   // lane offsets into the phase's [Cout][ntaps * Cin] matrix
 #pragma unroll
-    for (int j = 0; j < B_CH; ++j) {
-        const int row = (wave * B_CH + j) * 8 + lr;
-        wvoff[j] = (unsigned)(((n0 + row) * ph.Kpad + (ls ^ ((row >> 1) & 7)) * 4) * 4);
-    }
+    for (int pp = 0; pp < NPH; ++pp)
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) {
+            const int row = (wave * B_CH + j) * 8 + lr;
+            wvoff[pp][j] = (unsigned)(((n0 + row) * a.ph[pp].Kpad + (ls ^ ((row >> 1) & 7)) * 4) * 4);
+        }
+    const char *w_phase[NPH];
+#pragma unroll
+    for (int pp = 0; pp < NPH; ++pp) w_phase[pp] = uniform_ptr(a.w_split + a.ph[pp].w_off);
     const unsigned cin4 = (unsigned)a.Cin * 4u;
     const int nslices = a.Cin / BK;
     const unsigned wave_b = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((BOFF + wave * B_CH * 8 * BK) * 4));
@@ -1081,17 +1100,20 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     };
     // weight piece jb of reduction stage (tap it, slice is) into ring slot `slot`
     auto weight_piece = [&](int jb, int it, int is, int slot) {
-        dma16(wvoff[jb], w_base + __builtin_amdgcn_readfirstlane((unsigned)it * cin4 + (unsigned)is * (BK * 4u)),
+        const int pp = CT ? HaloCT::phase(it) : 0, ti = CT ? HaloCT::tap(it) : it;
+        dma16(wvoff[pp][jb], w_phase[pp] + __builtin_amdgcn_readfirstlane((unsigned)ti * cin4 + (unsigned)is * (BK * 4u)),
               __builtin_amdgcn_readfirstlane(wave_b + (unsigned)((slot * BSTAGE + jb * 8 * BK) * 4)));
     };
 
-    f32x16 acc[WM][WN];
+    f32x16 acc[NPH][WM][WN];
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int pp = 0; pp < NPH; ++pp)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pp][i][j][r] = 0.f;
 
     // ---- fragment addressing
     const int frow = lane & 31, half = lane >> 5, fsw = (frow >> 1) & 7;
@@ -1103,7 +1125,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     }
     // byte address (within smem) of the hi fragment of k-block 0; ^32: hi of k-block 1, ^64 / ^96: the lo fragments
     auto a_addr = [&](int i, int tap, int hs) {
-        const int p = pl[i] + (tap / 3) * HC + (tap % 3);
+        const int p = pl[i] + (CT ? HaloCT::dy(tap) * HC + HaloCT::dx(tap) : (tap / 3) * HC + (tap % 3));
         return hs * (HALO * 4) + p * 128 + ((half ^ ((p >> 1) & 7)) << 4);
     };
     const int b_row = (wave_n * 32 * WN + frow) * BK;
@@ -1157,8 +1179,9 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
             const Frags &f = kb == 0 ? fr : f1;
             const float4 a4 = t == 0 ? f.al[i] : f.ah[i];
             const float4 b4 = t == 1 ? f.bl[j] : f.bh[j];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a4),
-                                                                __builtin_bit_cast(bf16x8_t, b4), acc[i][j], 0, 0, 0);
+            constexpr int PP = CT ? HaloCT::phase(T) : 0;
+            acc[PP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a4),
+                                                                    __builtin_bit_cast(bf16x8_t, b4), acc[PP][i][j], 0, 0, 0);
             if (q < NL) {
                 load_one(cur_a, slot, 1, f1, q);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1223,7 +1246,11 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     // statistics: one (mean, M2) per 4 x 32 block, numbered row-major within the image whatever the tile height, so that
     // the combination order in in_finalize (and with it every bit) does not depend on which variant ran
     const int part0 = img * (tiles_x * (a.Hm / 4)) + (h0 / 4) * tiles_x + (w0 / TC);
-    igemm_epilogue<BN, WM, WN, true, NW, BMT, TC>(a, ph, 0, acc, smem, tid, lane, wave_m, wave_n, img, rem0, n0, part0, tiles_x);
+#pragma unroll
+    for (int pp = 0; pp < NPH; ++pp) {
+        if (pp) __syncthreads();   // the previous phase's statistics scratch has been read
+        igemm_epilogue<BN, WM, WN, true, NW, BMT, TC>(a, a.ph[pp], pp, acc[pp], smem, tid, lane, wave_m, wave_n, img, rem0, n0, part0, tiles_x);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1616,6 +1643,37 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
             if (rc != LWG_OK) return rc;
             if (variant) *variant = bn == 128 ? kHaloBf16x3_128 : kHaloBf16x3_64;
             LWG_LAUNCH_CHECK("conv3x3_halo_bf16x3");
+            return LWG_OK;
+        }
+        // ConvTranspose2d(k3, s2, p1, op1) given as its four phases: one launch of the halo kernel (CT = 1)
+        if (!(halo_env && halo_env[0] == '0') && a.nphase == 4 && a.os == 2 && a.stride == 1 && a.pad == 0 && a.dil == 1 &&
+            a.H == a.Hm && a.W == a.Wm && a.Wm % 32 == 0 && a.Hm % 4 == 0 && !g_trace.buf && a.Cout % 64 == 0 &&
+            a.ph[0].KH == 1 && a.ph[0].KW == 1 && a.ph[1].KH == 1 && a.ph[1].KW == 2 && a.ph[2].KH == 2 && a.ph[2].KW == 1 &&
+            a.ph[3].KH == 2 && a.ph[3].KW == 2 && a.ph[0].Kpad == a.Cin && a.ph[1].Kpad == 2 * a.Cin && a.ph[2].Kpad == 2 * a.Cin &&
+            a.ph[3].Kpad == 4 * a.Cin) {
+            const bool wide = a.Cout % 128 == 0 && (long)a.mtiles * (a.Cout / 128) >= device_cu_count();
+            const int cbn = wide ? 128 : 64, ns = wide ? 4 : 3;
+            const int nch = ((4 + 1) * (32 + 1) + 7) / 8;
+            const size_t bytes = ((size_t)2 * nch * 8 * BK + (size_t)ns * cbn * BK) * sizeof(float);
+            const dim3 g(a.mtiles, a.Cout / cbn, 1);
+            static DeviceOnce ct_opt[2];
+            if (wide) {
+                auto kern = &conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 128, 1>;
+                if (!ct_opt[0].done()) {
+                    LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+                    ct_opt[0].mark();
+                }
+                kern<<<g, 256, bytes, st>>>(a);
+            } else {
+                auto kern = &conv3x3_halo_bf16x3<64, 1, 2, 3, 32, 128, 1>;
+                if (!ct_opt[1].done()) {
+                    LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+                    ct_opt[1].mark();
+                }
+                kern<<<g, 256, bytes, st>>>(a);
+            }
+            if (variant) *variant = wide ? kHaloBf16x3_128 : kHaloBf16x3_64;
+            LWG_LAUNCH_CHECK("conv3x3_halo_bf16x3 (transposed)");
             return LWG_OK;
         }
         static const char *ring = getenv("LWG_RING");   // "3": the round-2 3-slot ring on the 128-wide tile (A/B switch)
