@@ -49,7 +49,7 @@ def kernel_peak(name):
 
 BATCH = 8
 IMAGE_SIZE = 256
-TRAFFIC_FILE = "r02_traffic.json"
+TRAFFIC_FILE = "r03_traffic.json"
 
 
 # sources of the kernels the timed step launches (the training and inpainting kernels are not among them)
@@ -359,7 +359,9 @@ def main():
                  "executed_tflops": round(achieved * (3.0 if x3 else 1.0), 2),
                  "traffic": None, "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
                  "flop_per_launch": kfl / max(kn, 1),
-                 "measured": "HIP events around each launch, steps re-run on one lane (kernels not overlapped)",
+                 "measured": "HIP events around each launch, steps re-run on one lane (kernels not overlapped).  An event pair spans "
+                             "the launch's dispatch latency too (~10 us on a dependent chain): rocprofv3's kernel durations "
+                             "(profiles/r03_kernel_stats.md) are that much shorter, the fractions here that much lower",
                  "frac_note": ("achieved = ALGORITHMIC flops (2*M*Cout*taps*Cin, real taps and channels) / launch time; "
                                "frac = frac_algorithmic = achieved / peak of the MFMA instruction used (bf16 dense 2500, "
                                "fp32 157.3).  A bf16x3 kernel executes 3 bf16 MFMA products per algorithmic multiply-add: "
@@ -380,16 +382,22 @@ def main():
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             stamp = tj.get("_stamp", {})
-            # rocprofv3 prints every template argument (the tile height too), the variant table of the library does not
-            t = tj.get(name) or next((v for k, v in tj.items() if k.startswith(name.rstrip('>') + ',')), None)
+            # rocprofv3 prints every template argument; a variant of the library's table may cover several instantiations
+            # (tile heights of the halo kernel): launch-weighted mean over the matching rows
+            rows = [v for k, v in tj.items() if k == name or k.startswith(name.rstrip('>') + ',')]
+            rows = [v for v in rows if "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v and v.get("launches")]
+            t = None
+            if rows:
+                nl = sum(v["launches"] for v in rows)
+                t = {"fetch_bytes_per_launch": sum(v["launches"] * v["fetch_bytes_per_launch"] for v in rows) / nl,
+                     "write_bytes_per_launch": sum(v["launches"] * v["write_bytes_per_launch"] for v in rows) / nl}
             if stamp.get("csrc_sha256") != csrc_digest():
                 block["traffic_note"] = ("profiles/%s was measured on other kernel sources (stamp %s..., now %s...): "
                                          "not attached" % (TRAFFIC_FILE, str(stamp.get("csrc_sha256"))[:10], csrc_digest()[:10]))
             elif t and "fetch_bytes_per_launch" in t and "write_bytes_per_launch" in t:
                 block["traffic"] = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
                 block["traffic_note"] = ("fabric-side bytes per launch (profiles/%s, commit %s): %.0f MB read + %.0f MB "
-                                         "written; Infinity-Cache hits included, every XCD's L2 fetches its own copy of "
-                                         "the weights" % (TRAFFIC_FILE, stamp.get("commit", "?"),
+                                         "written; Infinity-Cache hits included" % (TRAFFIC_FILE, stamp.get("commit", "?"),
                                                           t["fetch_bytes_per_launch"] / 1e6, t["write_bytes_per_launch"] / 1e6))
         return block
 
@@ -425,7 +433,8 @@ def main():
                                    "%d-frame synthetic reference sequence" % args.frames,
                        "batch_per_gpu": BATCH, "image_size": IMAGE_SIZE, "parallelism": "frame-sharded replicas x%d" % world,
                        "grid_sample_align_corners": False,
-                       "streams": "%d generator lane(s) + 1 geometry stream per GPU" % lanes,
+                       "streams": "%d generator lane(s) + 1 geometry stream per GPU; consecutive batches fused in pairs per "
+                                  "generator launch sequence: %s" % (lanes, os.environ.get("LWG_FUSE", str(imitator.fuse))),
                        "precision": precision + (" (fp32 operands carried as 2 bf16 terms, 3 MFMA products, fp32 "
                                                  "accumulate; 8e-5 L-inf on the image vs fp32, bound 1e-3)"
                                                  if precision == "bf16x3" else " (exact fp32 MFMA)")},

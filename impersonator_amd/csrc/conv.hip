@@ -1033,6 +1033,12 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    // measurement hook (lwg_conv_trace): four clock reads per wave, taken only when a record buffer is set
+    unsigned long long tr_t0 = 0, tr_rt0 = 0, tr_loop0 = 0, tr_loop1 = 0;
+    if (a.trace) {
+        tr_t0 = __builtin_amdgcn_s_memtime();
+        tr_rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     int bx = blockIdx.x;
     const int by = blockIdx.y;
     if (!a.natural_order && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD bands
@@ -1226,6 +1232,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
 
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
+    if (a.trace) tr_loop0 = __builtin_amdgcn_s_memtime();
     int slot = 0;
     auto bump = [&]() { slot = slot + 1 == NS ? 0 : slot + 1; };
 #define LWG_HALO_STAGE(T, ISS) stage_body(std::integral_constant<int, T>{}, ISS{}, sl, slot); bump();
@@ -1242,6 +1249,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     }
 #undef LWG_HALO_STAGE
 
+    if (a.trace) tr_loop1 = __builtin_amdgcn_s_memtime();
     __syncthreads();   // the epilogue's staging area aliases the halo
     // statistics: one (mean, M2) per 4 x 32 block, numbered row-major within the image whatever the tile height, so that
     // the combination order in in_finalize (and with it every bit) does not depend on which variant ran
@@ -1250,6 +1258,13 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     for (int pp = 0; pp < NPH; ++pp) {
         if (pp) __syncthreads();   // the previous phase's statistics scratch has been read
         igemm_epilogue<BN, WM, WN, true, NW, BMT, TC>(a, a.ph[pp], pp, acc[pp], smem, tid, lane, wave_m, wave_n, img, rem0, n0, part0, tiles_x);
+    }
+    if (a.trace && lane == 0) {   // record layout of conv_igemm_bf16x3's traced twin; no per-stage wait accounting here
+        const unsigned long long tr_end = __builtin_amdgcn_s_memtime(), tr_rt1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *o = a.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+        o[0] = tr_t0; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = tr_end; o[4] = 0; o[5] = 0;
+        o[6] = (unsigned long long)(9 * nslices) | ((tr_rt1 - tr_rt0) << 44);
+        o[7] = 0;
     }
 }
 
@@ -1532,8 +1547,23 @@ int conv_trace_launch(int idx, long long *v)
     return LWG_OK;
 }
 
-int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
+// record block for one traced launch of `waves`-wave workgroups on grid (gx, gy); null when tracing is off or the buffer is full
+static unsigned long long *trace_block(const ConvArgs &a, int gx, int gy, int waves, int stages)
 {
+    if (!g_trace.buf) return nullptr;
+    const size_t need = (size_t)gx * gy * waves * 8 * sizeof(unsigned long long);
+    if (g_trace.used + need > g_trace.bytes || g_trace.n >= kTraceMaxLaunches) return nullptr;
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(static_cast<char *>(g_trace.buf) + g_trace.used);
+    TraceLaunch &L = g_trace.launch[g_trace.n++];
+    L.offset = g_trace.used; L.gx = gx; L.gy = gy; L.gz = 1; L.waves = waves; L.stages = stages; L.cin = a.Cin; L.cout = a.Cout;
+    L.hm = a.Hm; L.n = a.N;
+    g_trace.used += need;
+    return p;
+}
+
+int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant)
+{
+    ConvArgs a = a_in;   // (the halo launches attach a trace block)
     if (a.Cout % bn != 0 || (bn != 64 && bn != 128))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cout=%d not a multiple of the %d-channel tile", a.Cout, bn);
     if (!a.general && ((a.Hm * a.Wm) % BM != 0 || a.mtiles * BM != a.N * a.Hm * a.Wm))
@@ -1617,7 +1647,7 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         static const char *halo_env = getenv("LWG_HALO");   // "0": the DMA-ring kernel everywhere (A/B switch)
         const ConvPhase &p0 = a.ph[0];
         if (!(halo_env && halo_env[0] == '0') && a.nphase == 1 && p0.KH == 3 && p0.KW == 3 && a.stride == 1 && a.pad == 1 &&
-            a.dil == 1 && a.os == 1 && a.H == a.Hm && a.W == a.Wm && p0.Kpad == 9 * a.Cin && !g_trace.buf &&
+            a.dil == 1 && a.os == 1 && a.H == a.Hm && a.W == a.Wm && p0.Kpad == 9 * a.Cin &&
             a.Wm % 32 == 0 && a.Hm % 4 == 0) {
             const int tc = 32;
             static DeviceOnce halo_opt[4];
@@ -1629,6 +1659,7 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
                     once.mark();
                 }
                 const dim3 g(grid.x / (bmt / BM), grid.y, 1);
+                a.trace = trace_block(a, g.x, g.y, bmt == 256 ? 8 : 4, 9 * a.Cin / BK);
                 kern<<<g, bmt == 256 ? 512 : 256, bytes, st>>>(a);
                 return LWG_OK;
             };
@@ -1647,7 +1678,7 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
         }
         // ConvTranspose2d(k3, s2, p1, op1) given as its four phases: one launch of the halo kernel (CT = 1)
         if (!(halo_env && halo_env[0] == '0') && a.nphase == 4 && a.os == 2 && a.stride == 1 && a.pad == 0 && a.dil == 1 &&
-            a.H == a.Hm && a.W == a.Wm && a.Wm % 32 == 0 && a.Hm % 4 == 0 && !g_trace.buf && a.Cout % 64 == 0 &&
+            a.H == a.Hm && a.W == a.Wm && a.Wm % 32 == 0 && a.Hm % 4 == 0 && a.Cout % 64 == 0 &&
             a.ph[0].KH == 1 && a.ph[0].KW == 1 && a.ph[1].KH == 1 && a.ph[1].KW == 2 && a.ph[2].KH == 2 && a.ph[2].KW == 1 &&
             a.ph[3].KH == 2 && a.ph[3].KW == 2 && a.ph[0].Kpad == a.Cin && a.ph[1].Kpad == 2 * a.Cin && a.ph[2].Kpad == 2 * a.Cin &&
             a.ph[3].Kpad == 4 * a.Cin) {
@@ -1656,6 +1687,7 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant)
             const int nch = ((4 + 1) * (32 + 1) + 7) / 8;
             const size_t bytes = ((size_t)2 * nch * 8 * BK + (size_t)ns * cbn * BK) * sizeof(float);
             const dim3 g(a.mtiles, a.Cout / cbn, 1);
+            a.trace = trace_block(a, g.x, g.y, 4, -(int)(9 * a.Cin / BK));   // negative stage count marks a transposed conv
             static DeviceOnce ct_opt[2];
             if (wide) {
                 auto kern = &conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 128, 1>;

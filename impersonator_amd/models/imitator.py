@@ -221,8 +221,11 @@ class Imitator(BaseModel):
     # configuration in which two rasteriser code shapes used to miscompute beside conv_igemm_bf16x3 -- an effect
     # that was removed by replacing those shapes, not explained.  Opt in with LWG_OVERLAP_GEOMETRY=1 / the keyword.
     overlap_geometry = False
-    # consecutive batches of a round that run as one generator launch sequence (see predict_batches); env LWG_FUSE
-    fuse = 1
+    # consecutive batches of a round that run as ONE generator launch sequence (see predict_batches); env LWG_FUSE.
+    # Two batches of 8 = 16 frames give the trunk convolutions 256 tiles of 8 x 32 pixels (eight waves sharing a weight
+    # stage): conv kernels 0.42 -> 0.48 of the matrix-pipe peak, +2.5..4.5 % frames/s (profiles/r03_conv_experiments.md).
+    # Results are bit-identical to unfused batches (every kernel is batch-invariant; tests/test_gpu_bench_config.py).
+    fuse = 2
     # entries of tsf_info with one row per frame (hmr.get_details + SMPLRenderer.transfer, imitator.py:236-268)
     PER_FRAME_KEYS = ('theta', 'cam', 'pose', 'shape', 'verts', 'j2d', 'j3d', 'fim', 'wim', 'cond', 'tsf_img', 'T')
 

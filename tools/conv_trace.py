@@ -50,6 +50,8 @@ def run(lanes, lines):
     by_shape = {}
     for off, gx, gy, gz, waves, stages, cin, cout, hm, n in launches:
         rec = host[off // 8: off // 8 + gx * gy * gz * waves * 8].reshape(gz, gy, gx, waves, 8).astype(np.int64)
+        if not rec[..., 3].any():
+            continue   # launch never ran (the buffer was filled behind it)
         by_shape.setdefault((cin, cout, hm, n, gx, gy, gz, stages), []).append(rec)
     lines.append("### %d lane%s: %d traced launches over %d step(s)\n" % (lanes, "" if lanes == 1 else "s", len(launches), STEPS))
     lines.append("| layer (Cin->Cout @ Hm, grid) | launches | prologue (cycles) | main loop | epilogue | cycles per stage (min %d) | "
@@ -72,13 +74,15 @@ def run(lanes, lines):
             ghz.append(np.mean((t1 - t0) / np.maximum(rt, 1)) * 0.1)     # shader cycles per 10-ns tick
             us.append(np.mean(rt) * 0.01)
         m = lambda v: float(np.mean(v))
-        lines.append("| %d->%d @%d (%dx%dx%d, %d stages) | %d | %.0f | %.0f | %.0f | %.0f | %.1f %% | %.1f %% | %.0f | %.2f | %.1f |" % (
-            cin, cout, hm, gx, gy, gz, stages, len(recs), m(pro), m(loop), m(epi), m(per_stage),
+        kind = "convT " if stages < 0 else ""
+        waves = recs[0].shape[-2]
+        lines.append("| %s%d->%d @%d N=%d (%dx%dx%d x %d waves, %d stages) | %d | %.0f | %.0f | %.0f | %.0f | %.1f %% | %.1f %% | %.0f | %.2f | %.1f |" % (
+            kind, cin, cout, hm, n, gx, gy, gz, waves, abs(stages), len(recs), m(pro), m(loop), m(epi), m(per_stage),
             100 * m(wait), 100 * m(bar), m(dma), m(ghz), m(us)))
     # the trunk layer in detail: distribution over workgroups and XCDs
     trunk = [k for k in by_shape if k[0] == 512 and k[1] == 512]
     if trunk:
-        r = np.concatenate([x.reshape(-1, 4, 8) for x in by_shape[trunk[0]]])      # [launch x workgroup][wave][8]
+        r = np.concatenate([x.reshape(-1, x.shape[-2], 8) for x in by_shape[trunk[0]]])      # [launch x workgroup][wave][8]
         loopc = (r[..., 2] - r[..., 1]).astype(np.float64)
         w, b = r[..., 4] / loopc, r[..., 5] / loopc
         xcc = (r[:, 0, 7] >> 32) & 0xf
@@ -91,7 +95,7 @@ def run(lanes, lines):
 
 
 def main():
-    lines = ["# Cycle accounting of conv_igemm_bf16x3<128, 2, 2, 4> inside the bench pipeline (tools/conv_trace.py)\n",
+    lines = ["# Cycle accounting of the generator's conv kernels inside the bench pipeline (tools/conv_trace.py; LWG_HALO=%s LWG_FUSE=%s)\n" % (os.environ.get("LWG_HALO", "1"), os.environ.get("LWG_FUSE", "default")),
              "s_memtime counts shader-clock cycles.  `data wait` = cycles between the reads before and after the stage's "
              "`s_waitcnt vmcnt(N) lgkmcnt(0)`; `barrier wait` = cycles in the `s_barrier` that follows (waves of a workgroup "
              "waiting for the slowest one's data); `cycles per DMA issue` = s_memtime before to after one global_load_lds_dwordx4 "

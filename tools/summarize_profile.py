@@ -26,7 +26,7 @@ def stats(path, out, bench=None):
         if bench:
             f.write("bench.py line of the same code (un-profiled run):\n\n```json\n%s\n```\n\n" % open(bench).read().strip())
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
-        for r in rows[:22]:
+        for r in rows[:24]:
             f.write("| `%s` | %s | %.3f | %.1f | %.2f |\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                             float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 
@@ -39,7 +39,7 @@ def pmc(counters, trace, out):
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace))}
     agg = collections.OrderedDict()
     for k, d in disp.items():
-        if "igemm" not in d["name"] and "stem_bf16x3" not in d["name"]:
+        if "igemm" not in d["name"] and "stem_bf16x3" not in d["name"] and "halo" not in d["name"]:
             continue
         a = agg.setdefault((d["name"], d["grid"]), collections.defaultdict(float))
         a["n"] += 1
