@@ -1732,6 +1732,23 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
                 return LWG_OK;
             }
         }
+        // 256 x 128 tiles on eight waves (two per SIMD) where every CU still gets one: the two 128-row halves share the
+        // weight stage and a workgroup's prologue / epilogue are paid once per 256 rows -- the stride-2 encoders
+        static const char *tall_ring_env = getenv("LWG_RING_TALL");   // "0": 128-row tiles only (A/B switch)
+        if (bn == 128 && !a.fuse_phases && a.nphase == 1 && (a.mtiles & 1) == 0 && !g_trace.buf &&
+            (long)(a.mtiles / 2) * (a.Cout / 128) >= device_cu_count() && !(tall_ring_env && tall_ring_env[0] == '0')) {
+            static DeviceOnce opt_tall;
+            const size_t lds_t = (size_t)3 * (256 + 128) * BK * sizeof(float);
+            if (!opt_tall.done()) {
+                LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<128, 2, 2, 3, 0, 256>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+                opt_tall.mark();
+            }
+            conv_igemm_bf16x3<128, 2, 2, 3, 0, 256><<<dim3(grid.x / 2, grid.y, 1), 512, lds_t, st>>>(a);
+            if (variant) *variant = kIgemmBf16x3_128;
+            LWG_LAUNCH_CHECK("conv_igemm_bf16x3 (256-row tiles)");
+            return LWG_OK;
+        }
         if (bn == 64) {
             conv_igemm_bf16x3<64, 1, 2><<<grid, 256, lds3, st>>>(a);
         } else if (ring && ring[0] == 'x') {   // LWG_RING=x: timing experiment, WRONG RESULTS (see DBG & 1024)

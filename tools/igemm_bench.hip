@@ -23,6 +23,9 @@ int main(int argc, char **argv)
         {"skip1 256->128 @128 (bn128)", 8, 128, 256, 128, 3, 1, 128},
         {"skip2 128->64 @256 (bn64)", 8, 256, 128, 64, 3, 1, 64},
         {"enc3 256->512 s2 @64 (bn128)", 8, 64, 256, 512, 3, 2, 128},
+        {"enc3 256->512 s2 @64 N=16 (bn128)", 16, 64, 256, 512, 3, 2, 128},
+        {"enc2 128->256 s2 @128 (bn128)", 8, 128, 128, 256, 3, 2, 128},
+        {"enc1 64->128 s2 @256 (bn128)", 8, 256, 64, 128, 3, 2, 128},
     };
     // 100: fp32 DMA kernel; 200 / 240: bf16x3 DMA ring with 3 / 4 slots; 300: the product's choice (halo kernel on 3x3 s1);
     // 1240: ring kernel with a quarter of the activation DMAs (timing only); 241 / 245: no steady-state DMA / MFMAs only
