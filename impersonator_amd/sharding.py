@@ -29,7 +29,12 @@ def init_process_group(backend=None):
             # LWG_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL wants a GPU per rank) -- how the multi-rank code
             # paths are exercised where only one device is visible
             backend = os.environ.get("LWG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kwargs = {}
+        if backend == "nccl" and torch.cuda.is_available():
+            # RCCL: bind the rank to its GPU before the first collective (barrier() otherwise guesses the device)
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            kwargs["device_id"] = torch.device("cuda", local_rank % torch.cuda.device_count())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, local_rank, world
 
 
