@@ -1751,6 +1751,7 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
         }
         if (bn == 64) {
             conv_igemm_bf16x3<64, 1, 2><<<grid, 256, lds3, st>>>(a);
+#ifdef LWG_EXPERIMENTS   // builds for profiles/r03_conv_experiments.md only (hipcc -DLWG_EXPERIMENTS): never in the shipped library
         } else if (ring && ring[0] == 'x') {   // LWG_RING=x: timing experiment, WRONG RESULTS (see DBG & 1024)
             static DeviceOnce optx;
             if (!optx.done()) {
@@ -1767,6 +1768,7 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
                 opt5.mark();
             }
             conv_igemm_bf16x3<128, 2, 2, 5><<<grid, 256, (size_t)5 * (BM + 128) * BK * sizeof(float), st>>>(a);
+#endif
         } else if (ring4) {
             static DeviceOnce opt4;
             if (!opt4.done()) {
