@@ -19,8 +19,10 @@
 //            5 = fused as 1 with the nine stores issued as single dwords (probe DESIGN.md section 9 lists)
 //            6 = fused as 1 + 24 wait states (s_nop) between the stores and everything after them
 //            7 = fused, the 36 bytes stored as three (dwordx2 + dword) pairs
+//            8 = fused stores, then the back-face test's two products and its result written out as data (no branch)
 //            10-14 = asm micro-victim: ONE 96-bit store, K = 0/1/2/4/8 wait states, VALU overwrite of its data registers
-//            20 + 10*W + S = asm micro-victim 2: S (1-3) back-to-back stores of W (2-4) dwords, s_nop 1, VALU overwrite
+//            20 + 10*W + S = asm micro-victim 2: S (1-3) back-to-back stores of W (2-4) dwords, s_nop 1, VALU overwrite;
+//            + 100: the overwrite as 64-bit v_pk_mov_b32 on register pairs
 //   neighbour 0 = none (control), 1 = MFMA stream only, 2 = ds_read_b128 + MFMA stream (stripped conv main loop:
 //            96 KiB of LDS per workgroup = one workgroup per CU, one wave per SIMD, one 16-byte LDS read behind every MFMA),
 //            3 = the product's conv_igemm_bf16x3<128> itself (only when built with -DREAL_NEIGHBOUR)
@@ -163,6 +165,29 @@ __global__ __launch_bounds__(256) void victim_fused(const float *__restrict__ ve
     }
 }
 
+// victim 8: the fused shape with the decision turned into DATA.  Stores as victim 1, then the two products of the back-face
+// test and the test's result (as 0/1 through v_cndmask, no branch) go to a debug buffer and the record is computed for every
+// lane regardless.  If the products are right and the flag is wrong, the compare / VCC is what breaks; if a product is wrong, a
+// VGPR write was lost.
+__global__ __launch_bounds__(256) void victim_probe(const float *__restrict__ verts, const float *__restrict__ cam,
+                                                    const int *__restrict__ faces_idx, int nv, float eye_z, float *__restrict__ faces,
+                                                    int bs, int nf, float *__restrict__ dbg)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs * nf) return;
+    const int b = i / nf, fn = i - b * nf;
+    float v[9];
+    project(verts, cam, faces_idx, b, nv, fn, eye_z, v);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) faces[(size_t)i * 9 + k] = v[k];
+    const float c1 = (v[7] - v[1]) * (v[3] - v[0]), c2 = (v[4] - v[1]) * (v[6] - v[0]);
+    const float flag = c1 < c2 ? 1.f : 0.f;
+    dbg[(size_t)i * 4 + 0] = c1;
+    dbg[(size_t)i * 4 + 1] = c2;
+    dbg[(size_t)i * 4 + 2] = flag;
+    dbg[(size_t)i * 4 + 3] = v[2] + v[5] + v[8];
+}
+
 __global__ __launch_bounds__(256) void victim_project(const float *__restrict__ verts, const float *__restrict__ cam,
                                                       const int *__restrict__ faces_idx, int nv, float eye_z, float *__restrict__ faces,
                                                       int bs, int nf)
@@ -221,7 +246,9 @@ __global__ __launch_bounds__(256) void victim_asm(unsigned *__restrict__ out_old
 // dwords from consecutive register groups starting at v40, then the two wait states hipcc leaves after a wide store
 // (s_nop 1), then VALU writes of new values to ALL the stored registers, then read-back.  What the fused rasteriser setup
 // kernel does around its three global_store_dwordx3.
-template <int W, int S>
+// PK = 1: the overwrite is done by v_pk_mov_b32 on register pairs (a 64-bit VALU write, what the compiled victim's
+// v_pk_add_f32 / v_pk_mul_f32 do) instead of twelve 32-bit v_add_u32.
+template <int W, int S, int PK = 0>
 __global__ __launch_bounds__(256) void victim_asm2(unsigned *__restrict__ out_old, unsigned n, int iters, unsigned *__restrict__ counts)
 {
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,10 +261,14 @@ __global__ __launch_bounds__(256) void victim_asm2(unsigned *__restrict__ out_ol
         // v40..v51 = a + k (old); store groups; s_nop 1; v40..v51 = b + k (new); count registers that are not new
 #define LWG_OLD(k) "v_add_u32 v" #k ", %2, " #k " - 40\n\t"
 #define LWG_NEW(k) "v_add_u32 v" #k ", %3, " #k " - 40\n\t"
+#define LWG_PRE(k) "v_add_u32 v" #k ", %3, " #k " - 60\n\t"
+#define LWG_PKM(d, s_) "v_pk_mov_b32 v[" #d ":" #d "+1], v[" #s_ ":" #s_ "+1], v[" #s_ ":" #s_ "+1] op_sel:[0,1]\n\t"
 #define LWG_CHK(k) "v_add_u32 v52, %3, " #k " - 40\n\tv_cmp_ne_u32 vcc, v52, v" #k "\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
         asm volatile("v_mov_b32 %0, 0\n\t"
                      LWG_OLD(40) LWG_OLD(41) LWG_OLD(42) LWG_OLD(43) LWG_OLD(44) LWG_OLD(45) LWG_OLD(46) LWG_OLD(47) LWG_OLD(48)
                      LWG_OLD(49) LWG_OLD(50) LWG_OLD(51)
+                     LWG_PRE(60) LWG_PRE(61) LWG_PRE(62) LWG_PRE(63) LWG_PRE(64) LWG_PRE(65) LWG_PRE(66) LWG_PRE(67) LWG_PRE(68)
+                     LWG_PRE(69) LWG_PRE(70) LWG_PRE(71)
                      "s_nop 4\n\t"
                      ".if %4 == 2\n\t"
                      "global_store_dwordx2 %1, v[40:41], off\n\t"
@@ -255,17 +286,24 @@ __global__ __launch_bounds__(256) void victim_asm2(unsigned *__restrict__ out_ol
                      ".if %5 > 2\n\tglobal_store_dwordx4 %1, v[48:51], off offset:32\n\t.endif\n\t"
                      ".endif\n\t"
                      "s_nop 1\n\t"
+                     ".if %6 == 0\n\t"
                      LWG_NEW(40) LWG_NEW(41) LWG_NEW(42) LWG_NEW(43) LWG_NEW(44) LWG_NEW(45) LWG_NEW(46) LWG_NEW(47) LWG_NEW(48)
                      LWG_NEW(49) LWG_NEW(50) LWG_NEW(51)
+                     ".else\n\t"
+                     LWG_PKM(40, 60) LWG_PKM(42, 62) LWG_PKM(44, 64) LWG_PKM(46, 66) LWG_PKM(48, 68) LWG_PKM(50, 70)
+                     ".endif\n\t"
                      "s_nop 4\n\t"
                      LWG_CHK(40) LWG_CHK(41) LWG_CHK(42) LWG_CHK(43) LWG_CHK(44) LWG_CHK(45) LWG_CHK(46) LWG_CHK(47) LWG_CHK(48)
                      LWG_CHK(49) LWG_CHK(50) LWG_CHK(51)
                      : "=&v"(bad)
-                     : "v"(p), "v"(a), "v"(b), "n"(W), "n"(S)
-                     : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "vcc", "memory");
+                     : "v"(p), "v"(a), "v"(b), "n"(W), "n"(S), "n"(PK)
+                     : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v60", "v61", "v62", "v63",
+                       "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "vcc", "memory");
 #undef LWG_OLD
 #undef LWG_NEW
 #undef LWG_CHK
+#undef LWG_PRE
+#undef LWG_PKM
         lost += bad;
     }
     if (lost) atomicAdd(counts + 0, lost);
@@ -470,8 +508,44 @@ int main(int argc, char **argv)
     };
 
     bool dumped = false;
+    if (victim == 8) {
+        float *dbg, *ref_dbg;
+        CHECK(hipMalloc(&dbg, nface * 16)); CHECK(hipMalloc(&ref_dbg, nface * 16));
+        victim_probe<<<blocks, 256, 0, sv>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, ref_dbg);
+        CHECK(hipStreamSynchronize(sv));
+        std::vector<float> hr(nface * 4), hg(nface * 4);
+        CHECK(hipMemcpy(hr.data(), ref_dbg, nface * 16, hipMemcpyDeviceToHost));
+        int bad_launch = 0;
+        unsigned long long wrong_c = 0, wrong_flag_only = 0, wrong_sum = 0, lanes_hi = 0, lanes_any = 0;
+        for (int it = 0; it < launches; ++it) {
+            for (int k = 0; k < 6; ++k) run_neighbour(sn[k & 1]);
+            CHECK(hipMemsetAsync(dbg, 0, nface * 16, sv));
+            CHECK(hipMemsetAsync(counts, 0, 16, sv));
+            victim_probe<<<blocks, 256, 0, sv>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, dbg);
+            compare_words<<<256, 256, 0, sv>>>((const unsigned *)dbg, (const unsigned *)ref_dbg, nface * 4, counts);
+            unsigned h;
+            CHECK(hipMemcpyAsync(&h, counts, 4, hipMemcpyDeviceToHost, sv));
+            CHECK(hipStreamSynchronize(sv));
+            if (h) {
+                ++bad_launch;
+                CHECK(hipMemcpy(hg.data(), dbg, nface * 16, hipMemcpyDeviceToHost));
+                for (size_t f = 0; f < nface; ++f) {
+                    const bool c = memcmp(&hg[f * 4], &hr[f * 4], 8) != 0, fl = hg[f * 4 + 2] != hr[f * 4 + 2], sm = hg[f * 4 + 3] != hr[f * 4 + 3];
+                    if (c || fl || sm) { ++lanes_any; lanes_hi += (f % 64) >= 48; }
+                    wrong_c += c; wrong_flag_only += (fl && !c); wrong_sum += sm;
+                }
+            }
+            if ((it & 7) == 7) { CHECK(hipStreamSynchronize(sn[0])); CHECK(hipStreamSynchronize(sn[1])); }
+        }
+        CHECK(hipDeviceSynchronize());
+        printf("victim 8 (decision as data) neighbour %d cumask %d: %d of %d launches differ; lanes with a wrong product %llu, with right products "
+               "but a wrong flag %llu, with a wrong z-sum %llu; wrong lanes in 48-63: %llu of %llu\n", neigh, cumask, bad_launch, launches,
+               wrong_c, wrong_flag_only, wrong_sum, lanes_hi, lanes_any);
+        return 0;
+    }
     if (victim >= 40) {
-        const int iters = 32, W = (victim - 20) / 10, S = (victim - 20) % 10;
+        const int pk = victim >= 140 ? 1 : 0;
+        const int iters = 32, W = (victim - 100 * pk - 20) / 10, S = (victim - 100 * pk - 20) % 10;
         const unsigned n = (unsigned)nface;
         unsigned *out_old;
         CHECK(hipMalloc(&out_old, (size_t)iters * n * 48));
@@ -482,7 +556,8 @@ int main(int argc, char **argv)
             CHECK(hipMemsetAsync(counts, 0, 16, sv));
 #define LWG_CASE(w, s_)                                                                              \
     if (W == w && S == s_) {                                                                          \
-        victim_asm2<w, s_><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts);                        \
+        if (pk) victim_asm2<w, s_, 1><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts);             \
+        else victim_asm2<w, s_><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts);                   \
         victim_asm2_check<w, s_><<<blocks, 256, 0, sv>>>(out_old, n, iters, counts);                  \
     }
             LWG_CASE(2, 1) LWG_CASE(2, 2) LWG_CASE(2, 3) LWG_CASE(3, 1) LWG_CASE(3, 2) LWG_CASE(3, 3) LWG_CASE(4, 1) LWG_CASE(4, 2) LWG_CASE(4, 3)
