@@ -1667,6 +1667,8 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
             static const char *tall_env = getenv("LWG_HALO_TALL");   // "0": 4 x 32 tiles only (A/B switch)
             const bool tall = bn == 128 && a.Hm % 8 == 0 && (long)(a.mtiles / 2) * (a.Cout / 128) >= device_cu_count() &&
                               !(tall_env && tall_env[0] == '0');
+            // (the 64-channel tile on eight waves of 32 x 64 -- one 110 KiB workgroup instead of two of 76 -- measured slower:
+            // 380 -> 348 TFLOP/s on skipper.2, gpurun_out/r03o)
             int rc;
             if (tall) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 256>, 4, 256, halo_opt[2]);
             else if (bn == 128) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32>, 4, 128, halo_opt[0]);
