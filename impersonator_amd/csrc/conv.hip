@@ -1520,8 +1520,8 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsArgs a)
 const char *const kIgemmVariantNames[kIgemmVariants] = {
     "conv_igemm_f32<64, 1, 2, false, 0>", "conv_igemm_f32<128, 2, 2, false, 0>", "conv_igemm_f32<64, 1, 2, true, 0>",
     "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>",
-    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2, 4, 0>", "stem_bf16x3_kernel",
-    // the halo kernels run as <.., NS, TC> with TC = min(W, 128): the names are the prefix rocprofv3 prints
+    // kernels that run as several instantiations (ring depth / tile height) are named by the prefix rocprofv3 prints
+    "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2", "stem_bf16x3_kernel",
     "conv3x3_halo_bf16x3<128, 2, 2", "conv3x3_halo_bf16x3<64, 1, 2"};
 
 // ---- measurement hook: per-wave cycle accounting of the 128-wide bf16x3 kernel (lwg_conv_trace, tools/conv_trace.py)

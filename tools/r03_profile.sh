@@ -6,8 +6,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-T0=$(date +%s.%N)
-timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? wall=$(echo "$(date +%s.%N) - $T0" | bc) s"
+T0=$(date +%s)
+timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"
 python $R/bench.py --lanes 1 --no-cpu-baseline --no-roofline --no-fp32-mode --no-secondary > $O/bench_lanes1.json 2>/dev/null
 python $R/bench.py --lanes 3 --no-cpu-baseline --no-roofline --no-fp32-mode --no-secondary > $O/bench_lanes3.json 2>/dev/null
 LWG_FUSE=1 python $R/bench.py --no-cpu-baseline --no-fp32-mode --no-secondary > $O/bench_fuse1.json 2>/dev/null
