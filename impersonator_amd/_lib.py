@@ -38,6 +38,8 @@ _PROTOS = {
     "lwg_transfer_workspace_bytes": (_sz, [_i, _i, _i]),
     "lwg_transfer_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lwg_smpl_swap": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lwg_smpl_project_joints": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "lwg_smpl_workspace_bytes": (_sz, [_i]),
     "lwg_smpl_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lwg_pack_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

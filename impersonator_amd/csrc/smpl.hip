@@ -209,12 +209,70 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(const float *__restric
     }
 }
 
+// ---- host glue of the per-frame prelude as two elementwise kernels (models/imitator.py:216-234 swap_smpl, the slicing
+// of networks/hmr.py:302-330 get_details, networks/batch_smpl.py:221-234 batch_orth_proj_idrot): a dozen tiny torch
+// launches per round otherwise.  One thread per output float; operation order as the reference's tensor expressions.
+__global__ void smpl_swap_kernel(const float *__restrict__ tgt, int n, int nbeta, int strategy, const float *__restrict__ src_cam,
+                                 const float *__restrict__ src_shape, const float *__restrict__ first_cam, float *__restrict__ theta,
+                                 float *__restrict__ cam, float *__restrict__ pose, float *__restrict__ shape)
+{
+    const int D = 75 + nbeta, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int f = i / D, c = i - f * D;
+    float v;
+    if (c < 3) {
+        const float t = tgt[(size_t)f * D + c];
+        if (strategy == 1) v = c == 0 ? src_cam[0] : src_cam[c] + (t - first_cam[c]);   // 'smooth': cam[:, 1:] += tgt - first
+        else if (strategy == 2) v = src_cam[c];                                          // 'source'
+        else v = t;                                                                      // 'copy' / theta given as is
+        cam[f * 3 + c] = v;
+    } else if (c < 75) {
+        v = tgt[(size_t)f * D + c];
+        pose[f * 72 + c - 3] = v;
+    } else {
+        v = strategy == 0 ? tgt[(size_t)f * D + c] : src_shape[c - 75];
+        shape[f * nbeta + c - 75] = v;
+    }
+    theta[i] = v;
+}
+
+__global__ void smpl_j2d_kernel(const float *__restrict__ j3d, const float *__restrict__ cam, int n, int nj, float *__restrict__ j2d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * nj * 2) return;
+    const int f = i / (nj * 2), r = i - f * nj * 2, j = r >> 1, c = r & 1;
+    j2d[i] = cam[f * 3] * (j3d[((size_t)f * nj + j) * 3 + c] + cam[f * 3 + 1 + c]);
+}
+
 }  // namespace
 }  // namespace lwg
 
 using namespace lwg;
 
 extern "C" {
+
+int lwg_smpl_swap(const float *tgt_smpl, int bs, int num_betas, int strategy, const float *src_cam, const float *src_shape,
+                  const float *first_cam, float *theta, float *cam, float *pose, float *shape, lwg_stream_t stream)
+{
+    LWG_REQUIRE(tgt_smpl && theta && cam && pose && shape, "smpl_swap: NULL argument");
+    LWG_REQUIRE(bs > 0 && num_betas > 0 && strategy >= 0 && strategy <= 3, "smpl_swap: bad arguments");
+    LWG_REQUIRE(strategy == 0 || strategy == 3 || src_cam, "smpl_swap: the 'smooth' and 'source' strategies need src_cam");
+    LWG_REQUIRE(strategy == 0 || src_shape, "smpl_swap: src_shape missing");
+    LWG_REQUIRE(strategy != 1 || first_cam, "smpl_swap: 'smooth' needs first_cam");
+    const int total = bs * (75 + num_betas);
+    smpl_swap_kernel<<<ceil_div(total, 256), 256, 0, as_stream(stream)>>>(tgt_smpl, bs, num_betas, strategy, src_cam, src_shape, first_cam,
+                                                                          theta, cam, pose, shape);
+    LWG_LAUNCH_CHECK("smpl_swap_kernel");
+    return LWG_OK;
+}
+
+int lwg_smpl_project_joints(const float *j3d, const float *cam, int bs, int num_joints, float *j2d, lwg_stream_t stream)
+{
+    LWG_REQUIRE(j3d && cam && j2d && bs > 0 && num_joints > 0, "smpl_project_joints: bad arguments");
+    smpl_j2d_kernel<<<ceil_div((long)bs * num_joints * 2, 256), 256, 0, as_stream(stream)>>>(j3d, cam, bs, num_joints, j2d);
+    LWG_LAUNCH_CHECK("smpl_j2d_kernel");
+    return LWG_OK;
+}
 
 size_t lwg_smpl_workspace_bytes(int bs) { return bs > 0 ? (size_t)bs * (NPF + NJ * 12) * sizeof(float) : 0; }
 

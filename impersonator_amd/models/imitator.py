@@ -174,8 +174,12 @@ class Imitator(BaseModel):
         if t == 0 and cam_strategy == 'smooth':
             self.first_cam = tgt_smpl[0:1, 0:3].clone()
 
-        tsf_smpl = self.swap_smpl(src_info['cam'], src_info['shape'], tgt_smpl, cam_strategy=cam_strategy)
-        tsf_info = self.hmr.get_details(tsf_smpl)
+        if tgt_smpl.is_cuda and hasattr(self.hmr, 'get_details_swapped') and (cam_strategy != 'smooth' or self.first_cam is not None):
+            # swap_smpl + get_details as liblwg launches (same values; the tensor-op forms below stay the API and the CPU path)
+            tsf_info = self.hmr.get_details_swapped(tgt_smpl, src_info['cam'], src_info['shape'], self.first_cam, cam_strategy)
+        else:
+            tsf_smpl = self.swap_smpl(src_info['cam'], src_info['shape'], tgt_smpl, cam_strategy=cam_strategy)
+            tsf_info = self.hmr.get_details(tsf_smpl)
         out = self.render.transfer(tsf_info['cam'], tsf_info['verts'], src_info['p2verts_c'], src_info['img'])
         tsf_info['fim'] = out['fim']
         tsf_info['wim'] = out['wim']

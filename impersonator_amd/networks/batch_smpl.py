@@ -187,6 +187,32 @@ class HumanModelRecovery(nn.Module):
         raise NotImplementedError("the HMR image regressor (networks/hmr.py:200-300) is not part of the "
                                   "Imitator.forward() path; pass src_smpl / tgt_smpls")
 
+    STRATEGIES = {'smooth': 1, 'source': 2}   # anything else: the target's own camera (models/imitator.py:216-234)
+
+    @torch.no_grad()
+    def get_details_swapped(self, tgt_smpl, src_cam, src_shape, first_cam, cam_strategy='smooth'):
+        """`get_details(Imitator.swap_smpl(src_cam, src_shape, tgt_smpl, cam_strategy))` for CUDA tensors as liblwg launches
+        only: lwg_smpl_swap (camera policy, theta and its contiguous parts), the SMPL kernels, lwg_smpl_project_joints.  Same
+        values bit for bit as the tensor expressions (tests/test_gpu_imitator.py)."""
+        from .. import _lib
+        lib = _lib.load()
+        tgt = tgt_smpl.float().contiguous()
+        n, nb = tgt.shape[0], tgt.shape[1] - 75
+        dev = tgt.device
+        theta = torch.empty((n, 75 + nb), device=dev, dtype=torch.float32)
+        cam = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        pose = torch.empty((n, 72), device=dev, dtype=torch.float32)
+        shape = torch.empty((n, nb), device=dev, dtype=torch.float32)
+        strategy = self.STRATEGIES.get(cam_strategy, 3)
+        sc = src_cam.float().contiguous() if strategy in (1, 2) else None
+        fc = first_cam.float().contiguous() if strategy == 1 else None
+        _lib.check(lib.lwg_smpl_swap(_lib.ptr(tgt), n, nb, strategy, _lib.ptr(sc), _lib.ptr(src_shape.float().contiguous()), _lib.ptr(fc),
+                                     _lib.ptr(theta), _lib.ptr(cam), _lib.ptr(pose), _lib.ptr(shape), _lib.stream_ptr()))
+        verts, j3d, _ = self.smpl.forward_theta(theta)
+        j2d = torch.empty((n, j3d.shape[1], 2), device=dev, dtype=torch.float32)
+        _lib.check(lib.lwg_smpl_project_joints(_lib.ptr(j3d), _lib.ptr(cam), n, j3d.shape[1], _lib.ptr(j2d), _lib.stream_ptr()))
+        return {'theta': theta, 'cam': cam, 'pose': pose, 'shape': shape, 'verts': verts, 'j2d': j2d, 'j3d': j3d}
+
     def get_details(self, theta):
         cam = theta[:, 0:3].contiguous()
         pose = theta[:, 3:75].contiguous()

@@ -111,6 +111,17 @@ LWG_API int lwg_transfer_frame(const float *verts, const float *cam, const int32
  * posedirs (207, nv*3), weights (nv,24), joint_regressor (nv,num_out_joints), parents (24).
  * J_template (24,3) and J_shapedirs (num_betas, 72) are the joint regressor applied to v_template / shapedirs
  * (the regression J_regressor^T v_shaped of batch_smpl.py:318-321 is linear in the shape; precomputed once). */
+/* The tensor glue around SMPL.forward on the per-frame path, as two launches.
+ * smpl_swap: Imitator.swap_smpl (models/imitator.py:216-234) + the slicing of HumanModelRecovery.get_details
+ *   (networks/hmr.py:302-330): tgt_smpl (bs, 75+num_betas) -> theta (bs, 75+num_betas) = [cam, tgt pose, src shape] and its
+ *   contiguous parts cam (bs,3), pose (bs,72), shape (bs,num_betas).  strategy 1 'smooth': cam = [src_s, src_t + (tgt_t -
+ *   first_t)]; 2 'source': src_cam; 3 'copy': the target's own camera; 0: theta = tgt_smpl unchanged (get_details only).
+ *   src_cam (3), src_shape (num_betas), first_cam (3): device pointers, NULL where the strategy does not read them.
+ * smpl_project_joints: batch_orth_proj_idrot (networks/batch_smpl.py:221-234): j2d (bs,J,2) = cam_s * (j3d_xy + cam_t). */
+LWG_API int lwg_smpl_swap(const float *tgt_smpl, int bs, int num_betas, int strategy, const float *src_cam,
+                          const float *src_shape, const float *first_cam, float *theta, float *cam, float *pose, float *shape,
+                          lwg_stream_t stream);
+LWG_API int lwg_smpl_project_joints(const float *j3d, const float *cam, int bs, int num_joints, float *j2d, lwg_stream_t stream);
 LWG_API size_t lwg_smpl_workspace_bytes(int bs);
 LWG_API int lwg_smpl_forward(const float *theta, int bs, int num_betas, int nv, int num_out_joints,
                              const float *v_template, const float *shapedirs, const float *posedirs,

@@ -81,6 +81,21 @@ def test_reference_call_sequence_and_camera_strategies(imi):
     assert torch.allclose(cam.cpu(), torch.from_numpy(smpls[5:6, :3]))               # 'copy' keeps the target camera
 
 
+def test_swap_smpl_and_get_details_as_kernels_equal_the_tensor_expressions(imi):
+    """lwg_smpl_swap + lwg_smpl_project_joints (the per-frame prelude's glue as two launches) against Imitator.swap_smpl +
+    HumanModelRecovery.get_details (models/imitator.py:216-234, networks/hmr.py:302-330), bit for bit, every strategy."""
+    imitator, _, _, _ = imi
+    smpls = torch.from_numpy(demo.synthetic_smpls(64, seed=0)).cuda()
+    imitator.first_cam = smpls[0:1, 0:3].clone()
+    si = imitator.src_info
+    for strat in ("smooth", "source", "copy"):
+        ref = imitator.hmr.get_details(imitator.swap_smpl(si["cam"], si["shape"], smpls[8:24], cam_strategy=strat))
+        got = imitator.hmr.get_details_swapped(smpls[8:24], si["cam"], si["shape"], imitator.first_cam, strat)
+        assert set(ref) == set(got)
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (strat, k)
+
+
 def test_front_warp(imi):
     imitator, _, _, _ = imi
     smpls = demo.synthetic_smpls(64, seed=0)
