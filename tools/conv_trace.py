@@ -101,7 +101,10 @@ def main():
              "waiting for the slowest one's data); `cycles per DMA issue` = s_memtime before to after one global_load_lds_dwordx4 "
              "(+ its s_mov m0), averaged over the first activation piece and the first weight piece of every stage (a wave issues "
              "8 per stage); the shader clock is the wave's cycle count over its 100 MHz s_memrealtime ticks.  A stage issues 24 "
-             "MFMAs of 32 cycles = %d cycles per wave at least.\n" % MFMA_CYCLES_PER_STAGE]
+             "MFMAs of 32 cycles = %d cycles per wave at least; in an eight-wave launch two waves share a SIMD's matrix pipe, so "
+             "%d cycles per wave-stage is its floor.  The halo kernels (conv3x3_halo_bf16x3: every row without a wait figure, "
+             "`convT` rows = its transposed-conv form) record entry / loop start / loop end / exit only: their wait columns read 0.0 = "
+             "not measured.  The ring kernel's traced twin always has four waves and a 4-slot ring.\n" % (MFMA_CYCLES_PER_STAGE, 2 * MFMA_CYCLES_PER_STAGE)]
     for lanes in (1, 2):
         run(lanes, lines)
     text = "\n".join(lines) + "\n"
