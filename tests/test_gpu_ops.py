@@ -55,6 +55,28 @@ def test_conv_bf16x3_route(case):
                            ops.conv2d_forward(xg, wg, b, stride, pad, transposed))
 
 
+@pytest.mark.parametrize("H,W", [(4, 32), (12, 96), (8, 64), (36, 160)])
+@pytest.mark.parametrize("cin,cout,N", [(32, 64, 2), (64, 128, 5), (128, 64, 1), (64, 256, 9)])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_halo_kernel_shapes(H, W, cin, cout, N, transposed):
+    """conv3x3_halo_bf16x3 away from the generator's shapes: image widths that are not powers of two (three or five 32-column
+    tiles per row), a single 4 x 32 tile, one channel slice (power-of-two channel counts: the op-level entry point asks for them), 64- and 128-channel tiles, tile counts that are not multiples of
+    eight (no XCD re-deal), the 8 x 32-tile variant (enough tiles at N = 9) -- 3x3 stride-1 and the one-launch transposed conv,
+    against float64 torch."""
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(H * 1000 + W + cin + cout + N)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn((cin, cout, 3, 3) if transposed else (cout, cin, 3, 3), generator=g) * 0.05
+    y = (F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1, output_padding=1) if transposed
+         else F.conv2d(x.double(), w.double(), None, stride=1, padding=1))
+    xg, wg = x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda().contiguous()
+    stride = 2 if transposed else 1
+    y16 = ops.conv2d_forward(xg, wg, None, stride, 1, transposed, precision="bf16x3")
+    y32 = ops.conv2d_forward(xg, wg, None, stride, 1, transposed)
+    assert not torch.equal(y16, y32), "the bf16x3 route did not run"
+    assert _rel(y16.cpu().permute(0, 3, 1, 2).double(), y) < 3e-5
+
+
 @pytest.mark.parametrize("N", [3, 1])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_weight_gradient_bf16x3(case, N):
