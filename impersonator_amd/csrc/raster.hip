@@ -178,16 +178,22 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const float *__restri
     if (i >= bs * nfp) return;
     const int b = i / nfp, fn = i - b * nfp;
     unsigned packed = kTileBoxEmpty;
+    // Every store of this kernel comes LAST, from registers nothing rewrites afterwards, as one asm block per
+    // predicate: the co-residency miscompute of DESIGN.md section 5.1 needs a VALU rewrite of a multi-dword store's data
+    // registers shortly behind the store; tools/store_hazard_lint.py (and tests/test_store_hazard_lint.py) check that the
+    // geometry kernels contain no such site.
+    bool keep = false, has_box = false;
+    float inv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned box_lo = 0, box_hi = 0;
+    const size_t t = (size_t)b * nf + (fn < nf ? fn : 0);
     if (fn < nf) {
-        const size_t t = (size_t)b * nf + fn;
         float v[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) v[k] = faces[t * 9 + k];
         if (!backside(v)) {
-            float px[3], py[3], inv[9], det;
+            float px[3], py[3], det;
             face_inverse(v, is, px, py, inv, det);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) faces_inv[t * 9 + k] = inv[k];
+            keep = true;
 
             const float xmn = fminf(fminf(px[0], px[1]), px[2]), xmx = fmaxf(fmaxf(px[0], px[1]), px[2]);
             const float ymn = fminf(fminf(py[0], py[1]), py[2]), ymx = fmaxf(fmaxf(py[0], py[1]), py[2]);
@@ -210,15 +216,28 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const float *__restri
                 y1 = min(is - 1, (int)floorf(ymx + m));
             }
             if (x0 <= x1 && y0 <= y1) {
-                Box bx;
-                bx.x0 = (unsigned short)x0; bx.y0 = (unsigned short)y0; bx.x1 = (unsigned short)x1; bx.y1 = (unsigned short)y1;
-                pbox[t] = bx;
+                has_box = true;
+                box_lo = (unsigned)x0 | (unsigned)y0 << 16;      // Box {x0, y0, x1, y1} as two dwords
+                box_hi = (unsigned)x1 | (unsigned)y1 << 16;
                 packed = (unsigned)((x0 / kTileW) >> tl.shx) | (unsigned)((y0 / kTileH) >> tl.shy) << 8 |
                          (unsigned)((x1 / kTileW) >> tl.shx) << 16 | (unsigned)((y1 / kTileH) >> tl.shy) << 24;
             }
         }
     }
-    tbox[i] = packed;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const f4 i0 = {inv[0], inv[1], inv[2], inv[3]}, i1 = {inv[4], inv[5], inv[6], inv[7]};
+    const u2 bxw = {box_lo, box_hi};
+    float *pinv = faces_inv + t * 9;
+    Box *pb = pbox + t;
+    unsigned *pt = tbox + i;
+    // all operands of all three blocks are inputs of the first one: nothing is computed between the stores
+    asm volatile("; stores last" ::"v"(pinv), "v"(i0), "v"(i1), "v"(inv[8]), "v"(pb), "v"(bxw), "v"(pt), "v"(packed));
+    if (keep)
+        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\tglobal_store_dword %0, %3, off offset:32"
+                     ::"v"(pinv), "v"(i0), "v"(i1), "v"(inv[8]) : "memory");
+    if (has_box) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(pb), "v"(bxw) : "memory");
+    asm volatile("global_store_dword %0, %1, off" ::"v"(pt), "v"(packed) : "memory");
 }
 
 // ------------------------------------------------------------------------------------------------ launch 2: tiles
@@ -429,9 +448,13 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
         if (o.tsf_img) o.tsf_img[((size_t)b * 3 + c) * npix + pn] = acc;
     }
     if (o.x0) {
-        float4 *dst = reinterpret_cast<float4 *>(o.x0 + i * 8);
-        dst[0] = make_float4(rgb[0], rgb[1], rgb[2], cnd[0]);
-        dst[1] = make_float4(cnd[1], cnd[2], 0.f, 0.f);
+        // the pixel's eight floats as two 16-byte stores from eight registers that are ready beforehand (left to the
+        // compiler this became dwordx3 + dwordx3 + a zero pair materialised in the first store's data registers three
+        // wait states behind it: the shape of DESIGN.md section 5.1)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 lo = {rgb[0], rgb[1], rgb[2], cnd[0]}, hi = {cnd[1], cnd[2], 0.f, 0.f};
+        float *dst = o.x0 + i * 8;
+        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(dst), "v"(lo), "v"(hi) : "memory");
     }
 }
 
