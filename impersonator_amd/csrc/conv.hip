@@ -28,6 +28,7 @@
 
 #include "conv.h"
 #include "sample.h"
+#include "settled_store.h"
 
 namespace lwg {
 namespace {
@@ -50,6 +51,13 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                                                float *smem, int tid, int lane, int wave_m, int wave_n, int img, int rem0, int n0,
                                                int mtile, int sub_stride = 0)
 {
+    // Everything below is loop-invariant in the callers: without this the compiler computes output addresses ahead of the
+    // main loop and carries them through it in registers (or spills them: the eight-wave ring kernel sits at its 256).
+    // The lane and thread ids are re-derived here for the same reason (nothing of the epilogue stays live across the loop).
+    unsigned ones = ~0u;
+    asm volatile("" : "+s"(ones));
+    lane = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+    tid = (wave_m * (BN / (32 * WN)) + wave_n) * 64 + lane;
     // ---- epilogue 1: raw output.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rsel = 4 * (lane >> 5);
     if constexpr (WIDE) {
@@ -63,16 +71,20 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + rsel) * TP + col] = acc[i][j][r];
                 // same wave wrote and reads: no barrier needed, only the LDS ordering of one wave
+                float4 v[4];
+                float *dst[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = q * 8 + rrow;
-                    const float4 v = *reinterpret_cast<const float4 *>(stage + row * TP + rcol);
+                    v[q] = *reinterpret_cast<const float4 *>(stage + row * TP + rcol);
                     const int trow = wave_m * 32 * WM + i * 32 + row;
                     const int rem = rem0 + (TC2 > 0 ? (trow / (TC2 > 0 ? TC2 : 1)) * a.Wm + trow % (TC2 > 0 ? TC2 : 1) : trow);
                     const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
                     const size_t opix = ((size_t)img * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
-                    *reinterpret_cast<float4 *>(a.y + opix * a.ldy + n0 + wave_n * 32 * WN + j * 32 + rcol) = v;
+                    dst[q] = a.y + opix * a.ldy + n0 + wave_n * 32 * WN + j * 32 + rcol;
                 }
+                // the tile's four 16-byte stores + 24 wait states as one statement (settled_store.h: DESIGN.md 5.1)
+                store_4x4_settled(dst[0], dst[1], dst[2], dst[3], v[0], v[1], v[2], v[3]);
             }
         smem += NWAVES * 32 * TP;   // statistics scratch behind the staging tiles
     } else {
@@ -90,6 +102,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
         }
     }
 
+    // lane ^ 32's value (__shfl_xor derives the lane id on its own: one more loop-invariant value for the compiler to hoist)
+    auto other_half = [&](float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+    };
     // ---- epilogue 2: per-tile InstanceNorm statistics (mean, M2) per channel over the tile's 128 pixels.
     // Reduced per 32-row MFMA tile first and combined over the four row tiles in a fixed order, so the numbers do not
     // depend on which wave layout (BN/WM/WN variant) produced them: results stay bit-identical across batch sizes.
@@ -102,7 +118,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                 float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-                s += __shfl_xor(s, 32);
+                s += other_half(s);
                 const float mu = s * (1.f / 32.f);
                 float q = 0.f;
 #pragma unroll
@@ -110,7 +126,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
                     const float d = acc[i][j][r] - mu;
                     q += d * d;
                 }
-                q += __shfl_xor(q, 32);
+                q += other_half(q);
                 if (lane < 32) red[(wave_m * WM + i) * BN + wave_n * 32 * WN + j * 32 + col] = make_float2(mu, q);
             }
         __syncthreads();
@@ -132,7 +148,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
             // TC2 == 0: `mtile` counts BMT-row tiles; TC2 > 0: `mtile` is the index of the tile's first 128-row block and
             // the following blocks sit `sub_stride` entries apart
             const size_t pidx = TC2 > 0 ? (size_t)mtile + (size_t)sub * sub_stride : (size_t)mtile * (BMT / BM) + sub;
-            a.partials[((size_t)phase * a.mtiles + pidx) * a.Cout + n0 + ch] = make_float2(mean, m2);
+            store_x2_settled(a.partials + ((size_t)phase * a.mtiles + pidx) * a.Cout + n0 + ch, make_float2(mean, m2));
         }
     }
 }
@@ -649,7 +665,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     const int by = blockIdx.y;
     if (!(DBG & 64) && !a.natural_order && (gridDim.x & 7) == 0) bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int m0 = bx * BMT, n0 = by * BN;
-    const int hw_m = a.Hm * a.Wm, img = m0 / hw_m, rem0 = m0 - img * hw_m;
+    const int hw_m = a.Hm * a.Wm, img = __builtin_amdgcn_readfirstlane(m0 / hw_m), rem0 = m0 - img * hw_m;   // the division runs on the VALU
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     auto uniform_ptr = [](const void *p) {   // wave-uniform pointer pinned to SGPRs (the "s" asm operand below)
         const unsigned long long v = (unsigned long long)p;
@@ -936,12 +952,12 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         const unsigned long long tr_end = __builtin_amdgcn_s_memtime();
         unsigned long long *o = a.trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
         const unsigned long long tr_rt1 = __builtin_amdgcn_s_memrealtime();
-        o[0] = tr_t0; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = tr_end; o[4] = tr_wait; o[5] = tr_bar;
-        o[6] = (unsigned long long)tr_stages | (tr_dma << 16) | ((tr_rt1 - tr_rt0) << 44);   // stages < 2^16, dma cycles < 2^28, 100 MHz ticks
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        o[7] = ((unsigned long long)xcc << 32) | hwid;
+        store_u64x8_settled(o, tr_t0, tr_loop0, tr_loop1, tr_end, tr_wait, tr_bar,
+                            (unsigned long long)tr_stages | (tr_dma << 16) | ((tr_rt1 - tr_rt0) << 44),   // stages < 2^16, dma cycles < 2^28, 100 MHz ticks
+                            ((unsigned long long)xcc << 32) | hwid);
     }
     if (DBG & 32) {   // bench only: keep every MFMA alive without an epilogue
         float keep = 0.f;
@@ -1045,8 +1061,9 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     const int n0 = by * BN;
     // tile bx = TR rows x TC columns of one image, tiles of an image in row-major order
     const int tiles_x = a.Wm / TC, tiles_img = tiles_x * (a.Hm / TR);
-    const int img = bx / tiles_img, trem = bx - img * tiles_img;
-    const int h0 = (trem / tiles_x) * TR, w0 = (trem % tiles_x) * TC;
+    const int img = __builtin_amdgcn_readfirstlane(bx / tiles_img), trem = bx - img * tiles_img;   // the divisions run on the VALU
+    const int trow0 = __builtin_amdgcn_readfirstlane(trem / tiles_x);
+    const int h0 = trow0 * TR, w0 = (trem - trow0 * tiles_x) * TC;
     const int rem0 = h0 * a.Wm + w0;                         // origin pixel (the epilogue's 2-D row mapping starts here)
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
     auto uniform_ptr = [](const void *p) {
@@ -1262,9 +1279,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     if (a.trace && lane == 0) {   // record layout of conv_igemm_bf16x3's traced twin; no per-stage wait accounting here
         const unsigned long long tr_end = __builtin_amdgcn_s_memtime(), tr_rt1 = __builtin_amdgcn_s_memrealtime();
         unsigned long long *o = a.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
-        o[0] = tr_t0; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = tr_end; o[4] = 0; o[5] = 0;
-        o[6] = (unsigned long long)(9 * nslices) | ((tr_rt1 - tr_rt0) << 44);
-        o[7] = 0;
+        store_u64x8_settled(o, tr_t0, tr_loop0, tr_loop1, tr_end, 0, 0, (unsigned long long)(9 * nslices) | ((tr_rt1 - tr_rt0) << 44), 0);
     }
 }
 
@@ -1402,8 +1417,7 @@ __global__ __launch_bounds__(256) void unsplit_kernel(float *buf, size_t ngroups
                                 (float)h[3] + (float)l[3]);
         float4 o1 = make_float4((float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6],
                                 (float)h[7] + (float)l[7]);
-        *reinterpret_cast<float4 *>(buf + g * 32 + i * 8) = o0;
-        *reinterpret_cast<float4 *>(buf + g * 32 + i * 8 + 4) = o1;
+        store_2x4_settled(buf + g * 32 + i * 8, o0, o1);
     }
 }
 

@@ -8,8 +8,9 @@ instruction that rewrites one of the store's DATA registers; beside conv_igemm_b
 pass of such a write can be lost.  24 wait states between store and rewrite, or single-dword stores, were clean.
 
 This tool compiles every csrc/*.hip to gfx950 assembly and lists, per kernel, the sites where a VALU instruction writes
-a data register of a global/flat/buffer store of >= 2 dwords within WINDOW wait states of it, inside one basic block
-(an s_nop N counts N + 1, every other instruction 1).  It finds the shape; it cannot tell whether a site ever runs
+a data register of a global/flat/buffer/scratch store of >= 2 dwords within WINDOW wait states of it, along every path the
+code can take from the store (branch targets and fall-throughs are followed; an s_nop N counts N + 1, every other
+instruction 1).  It finds the shape; it cannot tell whether a site ever runs
 beside the conv kernels, nor whether the shape alone suffices (the inline-asm micro-victims with exactly this shape
 stayed clean): a census of exposure, not a verdict."""
 import os
@@ -37,52 +38,65 @@ def vregs(tok):
 
 
 def lint(asm_path):
+    """{kernel: {"stores", "sites", "min"}}.  From every multi-dword store the walk follows the fall-through path, s_branch
+    targets and BOTH sides of conditional branches until WINDOW wait states have passed."""
     out = {}
-    kernel, block = None, []
-
-    def flush():
-        nonlocal block
-        if kernel is None:
-            block = []
-            return
-        for i, (mn, ops) in enumerate(block):
+    kernels, cur = {}, None
+    for line in open(asm_path):
+        if re.match(r"^_Z[\w$.]+:", line) or (re.match(r"^[A-Za-z_][\w$.]*:", line) and not line.startswith(".L")):
+            cur = kernels.setdefault(line.split(":")[0], {"ins": [], "labels": {}})
+            continue
+        if cur is None:
+            continue
+        if line.startswith(".L"):
+            cur["labels"][line.split(":")[0]] = len(cur["ins"])
+            continue
+        m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*(;.*)?$", line)
+        if m and not m.group(1).startswith("."):
+            cur["ins"].append((m.group(1), m.group(2)))
+    for kernel, k in kernels.items():
+        ins, labels = k["ins"], k["labels"]
+        for i, (mn, ops) in enumerate(ins):
             m = STORE.match("\t%s %s" % (mn, ops))
             if not m:
                 continue
             parts = [p.strip() for p in ops.split(",")]
-            # global/flat: vaddr, vdata, saddr|off ; buffer: vdata, vaddr, srsrc ...
+            # global/flat: vaddr, vdata, saddr|off ; buffer: vdata, vaddr, srsrc ... ; scratch: vaddr|off, vdata, ...
             data = vregs(parts[0] if mn.startswith("buffer") else parts[1]) if len(parts) > 1 else set()
             if not data:
                 continue
-            dist = 0
-            for mn2, ops2 in block[i + 1:]:
-                dist += int(ops2.strip() or 0) + 1 if mn2 == "s_nop" else 1
-                if dist > WINDOW:
-                    break
-                if mn2.startswith("v_") and not mn2.startswith(("v_cmp", "v_cmpx", "v_readfirstlane", "v_readlane")):
-                    dst = ops2.split(",")[0]
-                    if vregs(dst) & data:
-                        rec = out.setdefault(kernel, {"sites": 0, "min": 1 << 30, "stores": 0})
-                        rec["sites"] += 1
-                        rec["min"] = min(rec["min"], dist)
+            rec = out.setdefault(kernel, {"sites": 0, "min": 1 << 30, "stores": 0})
+            rec["stores"] += 1
+            # `dead`: the path is only taken with EXEC = 0 (fall-through of s_cbranch_execnz, target of s_cbranch_execz):
+            # VALU instructions write nothing there until something sets EXEC again
+            best, seen, todo = None, set(), [(i + 1, 0, False)]
+            while todo:
+                pc, dist, dead = todo.pop()
+                while pc < len(ins) and (pc, dist, dead) not in seen:
+                    seen.add((pc, dist, dead))
+                    mn2, ops2 = ins[pc]
+                    dist += int(ops2.strip() or 0) + 1 if mn2 == "s_nop" else 1
+                    if dist > WINDOW or mn2 == "s_endpgm":
                         break
-            out.setdefault(kernel, {"sites": 0, "min": 1 << 30, "stores": 0})["stores"] += 1
-        block = []
-
-    for line in open(asm_path):
-        if re.match(r"^_Z[\w$.]+:", line) or re.match(r"^[A-Za-z_][\w$.]*:\s*;? *@?", line) and not line.startswith(".L"):
-            flush()
-            kernel = line.split(":")[0]
-            continue
-        if line.startswith(".L") or re.match(r"^\s+s_(cbranch|branch|endpgm|setpc)", line):
-            if re.match(r"^\s+s_", line):
-                pass
-            flush()
-            continue
-        m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*(;.*)?$", line)
-        if m and not m.group(1).startswith("."):
-            block.append((m.group(1), m.group(2)))
-    flush()
+                    dst = ops2.split(",")[0].strip()
+                    if mn2.startswith("s_") and (dst == "exec" or "saveexec" in mn2):
+                        dead = False
+                    if not dead and mn2.startswith("v_") and not mn2.startswith(("v_cmp", "v_cmpx", "v_readfirstlane", "v_readlane")):
+                        if vregs(dst) & data:
+                            best = dist if best is None else min(best, dist)
+                            break
+                    if mn2 == "s_branch" or mn2.startswith("s_cbranch"):
+                        tgt = labels.get(ops2.strip())
+                        if tgt is not None:
+                            todo.append((tgt, dist, dead or mn2 == "s_cbranch_execz"))
+                        if mn2 == "s_branch":
+                            break
+                        if mn2 == "s_cbranch_execnz":
+                            dead = True
+                    pc += 1
+            if best is not None:
+                rec["sites"] += 1
+                rec["min"] = min(rec["min"], best)
     return out
 
 
