@@ -53,8 +53,8 @@ TRAFFIC_FILE = "r03_traffic.json"
 
 
 # sources of the kernels the timed step launches (the training and inpainting kernels are not among them)
-STEP_SOURCES = ("common.h", "conv.h", "conv.hip", "direct.hip", "generator.hip", "heads.hip", "raster.hip", "sample.h", "settled_store.h",
-                "smpl.hip", "warp.hip")
+STEP_SOURCES = ("common.h", "conv.h", "conv.hip", "direct.hip", "generator.hip", "heads.hip", "raster.hip", "sample.h", "smpl.hip",
+                "warp.hip")
 
 
 def csrc_digest():

@@ -28,7 +28,6 @@
 
 #include "conv.h"
 #include "sample.h"
-#include "settled_store.h"
 
 namespace lwg {
 namespace {
@@ -71,20 +70,16 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + rsel) * TP + col] = acc[i][j][r];
                 // same wave wrote and reads: no barrier needed, only the LDS ordering of one wave
-                float4 v[4];
-                float *dst[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = q * 8 + rrow;
-                    v[q] = *reinterpret_cast<const float4 *>(stage + row * TP + rcol);
+                    const float4 v = *reinterpret_cast<const float4 *>(stage + row * TP + rcol);
                     const int trow = wave_m * 32 * WM + i * 32 + row;
                     const int rem = rem0 + (TC2 > 0 ? (trow / (TC2 > 0 ? TC2 : 1)) * a.Wm + trow % (TC2 > 0 ? TC2 : 1) : trow);
                     const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
                     const size_t opix = ((size_t)img * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
-                    dst[q] = a.y + opix * a.ldy + n0 + wave_n * 32 * WN + j * 32 + rcol;
+                    *reinterpret_cast<float4 *>(a.y + opix * a.ldy + n0 + wave_n * 32 * WN + j * 32 + rcol) = v;
                 }
-                // the tile's four 16-byte stores + 24 wait states as one statement (settled_store.h: DESIGN.md 5.1)
-                store_4x4_settled(dst[0], dst[1], dst[2], dst[3], v[0], v[1], v[2], v[3]);
             }
         smem += NWAVES * 32 * TP;   // statistics scratch behind the staging tiles
     } else {
@@ -148,7 +143,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
             // TC2 == 0: `mtile` counts BMT-row tiles; TC2 > 0: `mtile` is the index of the tile's first 128-row block and
             // the following blocks sit `sub_stride` entries apart
             const size_t pidx = TC2 > 0 ? (size_t)mtile + (size_t)sub * sub_stride : (size_t)mtile * (BMT / BM) + sub;
-            store_x2_settled(a.partials + ((size_t)phase * a.mtiles + pidx) * a.Cout + n0 + ch, make_float2(mean, m2));
+            a.partials[((size_t)phase * a.mtiles + pidx) * a.Cout + n0 + ch] = make_float2(mean, m2);
         }
     }
 }
@@ -955,9 +950,9 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        store_u64x8_settled(o, tr_t0, tr_loop0, tr_loop1, tr_end, tr_wait, tr_bar,
-                            (unsigned long long)tr_stages | (tr_dma << 16) | ((tr_rt1 - tr_rt0) << 44),   // stages < 2^16, dma cycles < 2^28, 100 MHz ticks
-                            ((unsigned long long)xcc << 32) | hwid);
+        o[0] = tr_t0; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = tr_end; o[4] = tr_wait; o[5] = tr_bar;
+        o[6] = (unsigned long long)tr_stages | (tr_dma << 16) | ((tr_rt1 - tr_rt0) << 44);   // stages < 2^16, dma cycles < 2^28, 100 MHz ticks
+        o[7] = ((unsigned long long)xcc << 32) | hwid;
     }
     if (DBG & 32) {   // bench only: keep every MFMA alive without an epilogue
         float keep = 0.f;
@@ -1279,7 +1274,9 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     if (a.trace && lane == 0) {   // record layout of conv_igemm_bf16x3's traced twin; no per-stage wait accounting here
         const unsigned long long tr_end = __builtin_amdgcn_s_memtime(), tr_rt1 = __builtin_amdgcn_s_memrealtime();
         unsigned long long *o = a.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
-        store_u64x8_settled(o, tr_t0, tr_loop0, tr_loop1, tr_end, 0, 0, (unsigned long long)(9 * nslices) | ((tr_rt1 - tr_rt0) << 44), 0);
+        o[0] = tr_t0; o[1] = tr_loop0; o[2] = tr_loop1; o[3] = tr_end; o[4] = 0; o[5] = 0;
+        o[6] = (unsigned long long)(9 * nslices) | ((tr_rt1 - tr_rt0) << 44);
+        o[7] = 0;
     }
 }
 
@@ -1417,7 +1414,8 @@ __global__ __launch_bounds__(256) void unsplit_kernel(float *buf, size_t ngroups
                                 (float)h[3] + (float)l[3]);
         float4 o1 = make_float4((float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6],
                                 (float)h[7] + (float)l[7]);
-        store_2x4_settled(buf + g * 32 + i * 8, o0, o1);
+        *reinterpret_cast<float4 *>(buf + g * 32 + i * 8) = o0;
+        *reinterpret_cast<float4 *>(buf + g * 32 + i * 8 + 4) = o1;
     }
 }
 

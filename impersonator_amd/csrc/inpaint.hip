@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "conv.h"
-#include "settled_store.h"
 
 namespace lwg {
 namespace {
@@ -50,14 +49,14 @@ __global__ __launch_bounds__(256) void gated_apply_kernel(const GatedArgs a)
     y.z = c + 2 < a.Cout ? gated_value(a, px, c + 2) : 0.f;
     y.w = c + 3 < a.Cout ? gated_value(a, px, c + 3) : 0.f;
     if (!a.up) {
-        store_x4_settled(a.dst + (size_t)pix * a.Cdst + c, y);
+        *reinterpret_cast<float4 *>(a.dst + (size_t)pix * a.Cdst + c) = y;
     } else {
         const int yy = pix / a.W, xx = pix - yy * a.W;
         const int W2 = 2 * a.W;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const size_t o = (size_t)(2 * yy + (d >> 1)) * W2 + 2 * xx + (d & 1);
-            store_x4_settled(a.dst + o * a.Cdst + c, y);
+            *reinterpret_cast<float4 *>(a.dst + o * a.Cdst + c) = y;
         }
     }
 }
@@ -74,7 +73,9 @@ __global__ __launch_bounds__(256) void inpaint_input_kernel(const float *__restr
     float v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = img[c * npix + p] * (1.f - m) + (fill ? fill[c * npix + p] : 1.f) * m;
-    store_2x4_settled(out8 + (size_t)p * 8, make_float4(v[0], v[1], v[2], m), make_float4(0.f, 0.f, 0.f, 0.f));
+    float4 *o = reinterpret_cast<float4 *>(out8 + (size_t)p * 8);
+    o[0] = make_float4(v[0], v[1], v[2], m);
+    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // last gated layer of a stage (3 channels, no activation): x = clamp(y,-1,1) (NCHW) and, optionally,

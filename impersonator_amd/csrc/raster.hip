@@ -50,7 +50,6 @@
 // image as their box, i.e. every tile sweeps them over all its pixels, as brute force would.
 #include "common.h"
 #include "sample.h"
-#include "settled_store.h"
 
 namespace lwg {
 namespace {
@@ -410,7 +409,9 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
         (void)bary_depth(v, inv, xi, yi, w);
     }
     o.fim[i] = fn;
-    store_x3_settled(o.wim + i * 3, w[0], w[1], w[2]);   // more work follows: settled_store.h
+    o.wim[i * 3 + 0] = w[0];
+    o.wim[i * 3 + 1] = w[1];
+    o.wim[i * 3 + 2] = w[2];
     if (o.depth) o.depth[i] = zp;
 
     float cnd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
         tx_ = (p[0] * w[0] + p[2] * w[1]) + p[4] * w[2];
         ty_ = (p[1] * w[0] + p[3] * w[1]) + p[5] * w[2];
     }
-    store_x2_settled(reinterpret_cast<float2 *>(o.T + i * 2), make_float2(tx_, ty_));
+    *reinterpret_cast<float2 *>(o.T + i * 2) = make_float2(tx_, ty_);
 
     if (!(o.tsf_img || o.x0)) return;
     float rgb[3] = {0.f, 0.f, 0.f};

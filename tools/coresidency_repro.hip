@@ -13,6 +13,10 @@
 // (back-face test, 3x3 inverse with nine divisions, bounding box) before storing the record.
 //
 //   victim   1 = fused gather -> stores -> arithmetic (the failing shape)
+//            9 = the same with its stores + 24 wait states as one asm statement (a mitigation tried and refuted: it fails too)
+//            60-66 = the minimal victim: one packed-fp32 instruction with / without op_sel (see victim_pk)
+//            15 = 9 with record()'s arithmetic pinned behind the loads' side of the stores (nothing of it ahead of them)
+//            16 = 15 without the wait states; 17 = 15 with compiled stores; 18 = asm stores, arithmetic pinned right behind them
 //            2 = projection as its own kernel, arithmetic kernel reads what it wrote (the shape the product uses now)
 //            3 = fused, the nine stores moved BEHIND the arithmetic
 //            4 = fused as 1 + s_waitcnt vmcnt(0) right after the stores
@@ -152,17 +156,142 @@ __global__ __launch_bounds__(256) void victim_fused(const float *__restrict__ ve
                          "v"(*reinterpret_cast<const double *>(&v[3 * k])), "v"(v[3 * k + 2]) : "memory");
         }
     }
+    // 15-18: WHERE the arithmetic may sit relative to the stores, under control.  PIN = an empty asm that redefines all nine
+    // coordinates: nothing computed from them can be scheduled on the other side of it.
+#define REPRO_PIN asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]))
+    if (MODE == 15 || MODE == 16 || MODE == 17) REPRO_PIN;          // no arithmetic of record() ahead of the stores
+    if (MODE == 9 || MODE == 15) {   // the two 16-byte stores + 24 wait states as one asm statement
+        {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\ts_nop 15\n\ts_nop 7" ::"v"(faces + t * 9),
+                         "v"(f4{v[0], v[1], v[2], v[3]}), "v"(f4{v[4], v[5], v[6], v[7]}) : "memory");
+        }
+        faces[t * 9 + 8] = v[8];
+    }
+    if (MODE == 16 || MODE == 18) {   // the same two 16-byte stores without the wait states
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(faces + t * 9),
+                     "v"(f4{v[0], v[1], v[2], v[3]}), "v"(f4{v[4], v[5], v[6], v[7]}) : "memory");
+        faces[t * 9 + 8] = v[8];
+    }
+    if (MODE == 17) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) faces[t * 9 + k] = v[k];
+    }
+    if (MODE == 18) REPRO_PIN;                                      // all arithmetic of record() behind the stores, right behind
+    // 19 / 20: VALU results written just AHEAD of the stores and read behind them -- the back-face differences, computed
+    // before the stores (pinned there together with the coordinates), carried across, and written out in place of tbox.
+    // 20: 24 wait states between that arithmetic and the stores.
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    if (MODE == 19 || MODE == 20) {
+        REPRO_PIN;
+        d0 = v[3] - v[0]; d1 = v[4] - v[1]; d2 = v[6] - v[0]; d3 = v[7] - v[1];
+        if (MODE == 19)
+            asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]),
+                         "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+        else
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]),
+                         "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16" ::"v"(faces + t * 9),
+                     "v"(f4{v[0], v[1], v[2], v[3]}), "v"(f4{v[4], v[5], v[6], v[7]}) : "memory");
+        faces[t * 9 + 8] = v[8];
+        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]),
+                     "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+    }
+    // 21-24: the same differences from ONE asm statement together with the two 16-byte stores, so that op and adjacency are
+    // exact.  21: two v_pk_add_f32 immediately ahead of the stores; 22: 24 wait states in between; 23: the v_pk_add_f32
+    // immediately behind the stores; 24: four v_sub_f32 immediately ahead (the unpacked control).
+    if (MODE >= 21 && MODE <= 24) {
+        REPRO_PIN;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+        const f2 a = {v[3], v[4]}, b = {v[6], v[7]}, c = {v[0], v[1]};
+        f2 da, db;
+        float *dst = faces + t * 9;
+#define REPRO_ST "global_store_dwordx4 %2, %3, off\n\tglobal_store_dwordx4 %2, %4, off offset:16\n\t"
+#define REPRO_PK "v_pk_add_f32 %0, %5, %7 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %6, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        if (MODE == 21)
+            asm volatile(REPRO_PK REPRO_ST : "=&v"(da), "=&v"(db) : "v"(dst), "v"(lo), "v"(hi), "v"(a), "v"(b), "v"(c) : "memory");
+        if (MODE == 22)
+            asm volatile(REPRO_PK "s_nop 15\n\ts_nop 7\n\t" REPRO_ST : "=&v"(da), "=&v"(db) : "v"(dst), "v"(lo), "v"(hi), "v"(a), "v"(b), "v"(c) : "memory");
+        if (MODE == 23)
+            asm volatile(REPRO_ST REPRO_PK : "=&v"(da), "=&v"(db) : "v"(dst), "v"(lo), "v"(hi), "v"(a), "v"(b), "v"(c) : "memory");
+        if (MODE == 24) {
+            float e0, e1, e2, e3;
+            asm volatile("v_sub_f32 %0, %7, %11\n\tv_sub_f32 %1, %8, %12\n\tv_sub_f32 %2, %9, %11\n\tv_sub_f32 %3, %10, %12\n\t"
+                         "global_store_dwordx4 %4, %5, off\n\tglobal_store_dwordx4 %4, %6, off offset:16"
+                         : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
+                         : "v"(dst), "v"(lo), "v"(hi), "v"(v[3]), "v"(v[4]), "v"(v[6]), "v"(v[7]), "v"(v[0]), "v"(v[1]) : "memory");
+            da = f2{e0, e1}; db = f2{e2, e3};
+        }
+#undef REPRO_ST
+#undef REPRO_PK
+        faces[t * 9 + 8] = v[8];
+        d0 = da.x; d1 = da.y; d2 = db.x; d3 = db.y;
+        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]),
+                     "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+    }
+#undef REPRO_PIN
     if (MODE == 5) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) asm volatile("global_store_dword %0, %1, off" ::"v"(faces + t * 9 + k), "v"(v[k]) : "memory");
     }
     tbox[i] = record(v, is, t, faces_inv, pbox);
+    if (MODE >= 19 && MODE <= 24) {   // the carried differences instead of the tile box: tbox differing alone = they were damaged
+        const unsigned h0 = __float_as_uint(d0), h1 = __float_as_uint(d1), h2 = __float_as_uint(d2), h3 = __float_as_uint(d3);
+        tbox[i] = h0 ^ (h1 << 7 | h1 >> 25) ^ (h2 << 13 | h2 >> 19) ^ (h3 << 21 | h3 >> 11);
+    }
     if (MODE == 3) {
         float u[9];
         project(verts, cam, faces_idx, b, nv, fn, eye_z, u);
 #pragma unroll
         for (int k = 0; k < 9; ++k) faces[t * 9 + k] = u[k];
     }
+}
+
+// victims 60-66: the minimal form.  One packed-fp32 VALU instruction per iteration on lane-dependent operands, its two
+// results hashed into tbox (compared with the same launch on an idle device like every other output).  OP: 0 = v_pk_mul_f32
+// with the half-swap  op_sel:[1,0] op_sel_hi:[0,1]  (low result <- src0.high, high result <- src0.low: what hipcc emits for
+// the back-face differences of the failing victims); 1 = src0.high to both results (op_sel:[1,0], op_sel_hi default);
+// 2 = src0.low to both results (op_sel_hi:[0,1]: the broadcast hipcc uses everywhere); 3 = no modifiers; 4 = v_pk_fma_f32
+// op_sel:[1,0,0]; 5 = v_pk_add_f32 with the swap; 6 = the swap on src1 instead (op_sel:[0,1] op_sel_hi:[1,0]); 7-13: see the code.
+template <int OP>
+__global__ __launch_bounds__(256) void victim_pk(const float *__restrict__ verts, const float *__restrict__ cam,
+                                                 const int *__restrict__ faces_idx, int nv, float eye_z, float *__restrict__ faces,
+                                                 int bs, int nf, int is, float *__restrict__ faces_inv, Box *__restrict__ pbox,
+                                                 unsigned *__restrict__ tbox)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs * nf) return;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int nvals = bs * nv * 3;
+    f2 x = {verts[(2 * i) % nvals], verts[(2 * i + 1) % nvals]};
+    f2 y = {cam[i % (bs * 3)] + 1.5f, 0.75f + (float)(i & 7)};
+    f2 z = {0.5f, -0.25f};
+    unsigned h = 0;
+    for (int it = 0; it < 32; ++it) {
+        f2 r = {0.f, 0.f};
+        if (OP == 0) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+        if (OP == 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(x), "v"(y));
+        if (OP == 2) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+        if (OP == 3) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+        if (OP == 4) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+        if (OP == 5) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+        if (OP == 6) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(y));
+        if (OP == 7) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(y));                       // src1.high to both
+        if (OP == 8) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+        if (OP == 9) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+        if (OP == 10) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(y));
+        if (OP == 11) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(y));                       // D = {x.lo, y.hi}
+        if (OP == 12) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(x), "v"(y));                       // D = {x.hi, y.lo}
+        if (OP == 13) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(y));                    // src1.low to both
+        const unsigned a = __float_as_uint(r.x), b = __float_as_uint(r.y);
+        h = h * 31u + (a ^ (b << 11 | b >> 21));
+        x.x += 0.25f; x.y -= 0.125f;
+    }
+    tbox[i] = h;
 }
 
 // victim 8: the fused shape with the decision turned into DATA.  Stores as victim 1, then the two products of the back-face
@@ -449,7 +578,25 @@ int main(int argc, char **argv)
         for (int k = 0; k < 2; ++k) CHECK(hipStreamCreateWithFlags(&sn[k], hipStreamNonBlocking));
     }
     const int blocks = (int)((nface + 255) / 256);
+    // REPRO_CO=<code object> REPRO_KERNEL=<mangled name>: the victim comes from a separately assembled code object with the
+    // signature of victim_fused -- hand-edited variants of the compiler's assembly (tools/coresidency_asm_variants.py)
+    hipFunction_t co_fn = nullptr;
+    if (getenv("REPRO_CO")) {
+        hipModule_t mod;
+        if (hipModuleLoad(&mod, getenv("REPRO_CO")) != hipSuccess || hipModuleGetFunction(&co_fn, mod, getenv("REPRO_KERNEL")) != hipSuccess) {
+            fprintf(stderr, "cannot load %s / %s\n", getenv("REPRO_CO"), getenv("REPRO_KERNEL"));
+            return 2;
+        }
+    }
     auto run_victim = [&](hipStream_t st) {
+        if (co_fn) {
+            const float *a0 = verts, *a1 = cam; const int *a2 = faces_idx; int a3 = nv; float a4 = eye_z; float *a5 = faces;
+            int a6 = bs, a7 = nf, a8 = is; float *a9 = faces_inv; Box *a10 = pbox; unsigned *a11 = tbox;
+            void *params[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &a8, &a9, &a10, &a11};
+            const int nblocks = (bs * nf + 255) / 256;
+            hipModuleLaunchKernel(co_fn, nblocks, 1, 1, 256, 1, 1, 0, st, params, nullptr);
+            return;
+        }
         CHECK(hipMemsetAsync(faces, 0, nface * 36, st)); CHECK(hipMemsetAsync(faces_inv, 0, nface * 36, st));
         CHECK(hipMemsetAsync(pbox, 0, nface * 8, st)); CHECK(hipMemsetAsync(tbox, 0, nface * 4, st));
         switch (victim) {
@@ -459,6 +606,31 @@ int main(int argc, char **argv)
             case 5: victim_fused<5><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 6: victim_fused<6><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 7: victim_fused<7><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 9: victim_fused<9><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 19: victim_fused<19><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 20: victim_fused<20><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 21: victim_fused<21><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 22: victim_fused<22><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 23: victim_fused<23><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 24: victim_fused<24><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 60: victim_pk<0><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 61: victim_pk<1><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 62: victim_pk<2><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 63: victim_pk<3><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 64: victim_pk<4><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 65: victim_pk<5><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 66: victim_pk<6><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 67: victim_pk<7><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 68: victim_pk<8><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 69: victim_pk<9><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 70: victim_pk<10><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 71: victim_pk<11><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 72: victim_pk<12><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 73: victim_pk<13><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 15: victim_fused<15><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 16: victim_fused<16><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 17: victim_fused<17><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 18: victim_fused<18><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             default:
                 victim_project<<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf);
                 victim_setup<<<blocks, 256, 0, st>>>(faces, bs, nf, is, faces_inv, pbox, tbox);
@@ -543,7 +715,7 @@ int main(int argc, char **argv)
                wrong_c, wrong_flag_only, wrong_sum, lanes_hi, lanes_any);
         return 0;
     }
-    if (victim >= 40) {
+    if (victim >= 40 && (victim < 60 || victim > 73)) {
         const int pk = victim >= 140 ? 1 : 0;
         const int iters = 32, W = (victim - 100 * pk - 20) / 10, S = (victim - 100 * pk - 20) % 10;
         const unsigned n = (unsigned)nface;
@@ -575,7 +747,7 @@ int main(int argc, char **argv)
                bad_launch[0], tot[0], bad_launch[1], tot[1]);
         return 0;
     }
-    if (victim >= 10) {
+    if (victim >= 10 && victim <= 14) {
         const int iters = 32;
         const unsigned n = (unsigned)nface;
         unsigned *out_old;

@@ -24,8 +24,8 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o 
     python $R/bench.py --lanes 1 --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode --no-secondary > $O/stats.log 2>&1
 cd $R
 python tools/summarize_profile.py stats $(find $O/stats -name k_kernel_stats.csv) $O/${TAG}_kernel_stats.md $O/bench.json
-(echo "# tools/lane_stress.py 150 2 8 1 on the final build (settled stores; geometry UNDER the generators: overlap=1, round_depth 1)"; \
- timeout 400 python tools/lane_stress.py 150 2 8 1 2>&1 | tail -3) > $O/lane_stress.log
+(echo "# tools/lane_stress.py 60 2 8 1 on the final build (final build; geometry UNDER the generators: overlap=1, round_depth 1)"; \
+ timeout 400 python tools/lane_stress.py 60 2 8 1 2>&1 | tail -3) > $O/lane_stress.log
 cat $O/lane_stress.log
 python - <<PY
 import json
