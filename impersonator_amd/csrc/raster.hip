@@ -178,10 +178,10 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const float *__restri
     if (i >= bs * nfp) return;
     const int b = i / nfp, fn = i - b * nfp;
     unsigned packed = kTileBoxEmpty;
-    // Every store of this kernel comes LAST, from registers nothing rewrites afterwards, as one asm block per
-    // predicate: the co-residency miscompute of DESIGN.md section 5.1 needs a VALU rewrite of a multi-dword store's data
-    // registers shortly behind the store; tools/store_hazard_lint.py (and tests/test_store_hazard_lint.py) check that the
-    // geometry kernels contain no such site.
+    // All arithmetic first, every store last, one asm block per predicate.  (The order dates from a refuted reading of the
+    // co-residency miscompute of DESIGN.md section 5.1 -- stores followed by arithmetic; the cause is a packed-fp32
+    // instruction form, which this file is built without: impersonator_amd/build.py, tests/test_pk_opsel_lint.py.  The
+    // order is kept because it is the measured, validated one.)
     bool keep = false, has_box = false;
     float inv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     unsigned box_lo = 0, box_hi = 0;
@@ -449,8 +449,7 @@ __global__ __launch_bounds__(kThreads) void raster_tile_kernel(const float *__re
     }
     if (o.x0) {
         // the pixel's eight floats as two 16-byte stores from eight registers that are ready beforehand (left to the
-        // compiler this became dwordx3 + dwordx3 + a zero pair materialised in the first store's data registers three
-        // wait states behind it: the shape of DESIGN.md section 5.1)
+        // compiler this became dwordx3 + dwordx3 + a zero pair materialised in between)
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 lo = {rgb[0], rgb[1], rgb[2], cnd[0]}, hi = {cnd[1], cnd[2], 0.f, 0.f};
         float *dst = o.x0 + i * 8;

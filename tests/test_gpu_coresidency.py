@@ -1,11 +1,15 @@
-"""Blast radius of the co-residency effect of DESIGN.md section 5.1 (kernels that compute wrong values in single quarter-waves
-only while conv_igemm_bf16x3 workgroups share their CUs): the once-per-source path (`personalize`: rasteriser, morph,
+"""Blast radius of the co-residency effect of DESIGN.md section 5.1 (a packed-fp32 instruction form that returns wrong values
+while bf16x3 conv workgroups share its CU; liblwg is checked for it at build-test time, tests/test_pk_opsel_lint.py): the
+once-per-source path (`personalize`: rasteriser, morph,
 InpaintSANet, source encoder) and one training iteration (three-stream generator forward, hand-written backward,
 discriminator update) run on one stream WHILE a second stream streams bf16x3 trunk convolutions, and every result is
 compared bit for bit with the same work on an otherwise idle device.  The grid_sample gradient adds with atomics (as
 torch's does), so the source stream's gradients -- the only tensors downstream of it -- are compared to 1e-5 instead.
 The motion-imitation pipeline itself has its own comparisons (tests/test_gpu_imitator.py::test_lane_pipeline_stress,
 tests/test_gpu_raster.py::test_rasteriser_beside_bf16x3_convolutions)."""
+import os
+import re
+import subprocess
 import threading
 import time
 import types
@@ -146,3 +150,22 @@ def test_training_iteration_beside_bf16x3_convolutions(precision):
         for trial in range(6):
             compare(run(), "trial %d beside %d bf16x3 launches" % (trial, nb.launched))
         assert nb.launched > 100
+
+
+def test_minimal_victim_control_is_clean_and_the_form_is_reported():
+    """tools/coresidency_repro.hip, built with the product's conv.hip as the neighbour (tools/_build/coresidency_repro_real, see
+    the build line in its header; skipped when the binary has not been built): the minimal victim WITHOUT op_sel (63) beside
+    the halo conv kernel must be clean; what the same instruction with op_sel on src1 (66) does on this box is printed, not
+    asserted -- on the MI355X boxes of round 3 it was wrong in 290-300 of 300 launches."""
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_build", "coresidency_repro_real")
+    if not os.path.exists(exe):
+        pytest.skip("tools/_build/coresidency_repro_real not built")
+
+    def differing(victim):
+        out = subprocess.run([exe, "100", str(victim), "300", "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300).stdout
+        m = re.search(r"tbox (\d+); words", out)
+        assert m, out[-2000:]
+        return int(m.group(1))
+
+    assert differing(63) == 0
+    print("victim 66 (v_pk_mul_f32 with op_sel on src1) beside conv3x3_halo_bf16x3: %d of 100 launches differ" % differing(66))

@@ -4,15 +4,16 @@
 //   hipcc ... -DREAL_NEIGHBOUR -DLWG_IGEMM_BENCH tools/coresidency_repro.hip impersonator_amd/csrc/capi.hip -o tools/_build/coresidency_repro_real
 //   coresidency_repro [launches=300] [victim=1] [neighbour=2] [cumask=0]
 //
-// What round 2 saw inside the pipeline: a kernel of the rasteriser computes wrong values in single quarter-waves
-// (16 lanes) ONLY while workgroups of conv_igemm_bf16x3 run on the same device from other streams -- never alone, never
-// beside library GEMMs, never beside the exact-fp32 conv kernel.  Bisecting the neighbour left its ds_read_b128 stream
-// (MFMAs alone: clean).  Bisecting the victim left two code shapes; the more reliable one (297 of 300 launches wrong)
-// is reproduced here: ONE kernel that gathers a face's vertices, projects them, STORES the nine floats (three
-// global_store_dwordx3 per lane) and then runs ~150 VALU instructions of record arithmetic on the same registers
-// (back-face test, 3x3 inverse with nine divisions, bounding box) before storing the record.
+// RESULT (end of round 3; profiles/r03_coresidency.md): a packed-fp32 VALU instruction (v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32) with op_sel set for its SECOND source returns wrong values while its CU is shared with the LDS-read +
+// bf16-MFMA loop of the conv kernels.  Victims 60-73 (victim_pk) are that one instruction in a loop: 66, 67, 68, 70 (op_sel on
+// src1) fail in 300 of 300 launches beside neighbour 300, everything else is clean.  The older victims are the way there and
+// are kept because the write-up cites them: a rasteriser kernel that gathers a face's vertices, projects them, stores the nine
+// floats and runs ~150 VALU instructions of record arithmetic on the same registers failed or not depending on where and how
+// the stores were written -- because that decided whether hipcc used `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` for two
+// differences of the back-face test (tools/coresidency_asm_variants.py edits that one instruction in the assembly).
 //
-//   victim   1 = fused gather -> stores -> arithmetic (the failing shape)
+//   victim   1 = fused gather -> stores -> arithmetic (fails: hipcc emits the op_sel[src1] packed add here)
 //            9 = the same with its stores + 24 wait states as one asm statement (a mitigation tried and refuted: it fails too)
 //            60-66 = the minimal victim: one packed-fp32 instruction with / without op_sel (see victim_pk)
 //            15 = 9 with record()'s arithmetic pinned behind the loads' side of the stores (nothing of it ahead of them)
