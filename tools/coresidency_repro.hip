@@ -288,6 +288,13 @@ __global__ __launch_bounds__(256) void victim_pk(const float *__restrict__ verts
         if (OP == 11) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(y));                       // D = {x.lo, y.hi}
         if (OP == 12) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(x), "v"(y));                       // D = {x.hi, y.lo}
         if (OP == 13) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(y));                    // src1.low to both
+        if (OP == 14) {   // detail: ONE instruction (src1.high to both results), operands and both results written out
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+            tbox[i] = __float_as_uint(r.x);
+            float *o = faces_inv + (size_t)i * 9;
+            o[0] = r.y; o[1] = x.x; o[2] = x.y; o[3] = y.x; o[4] = y.y;
+            return;
+        }
         const unsigned a = __float_as_uint(r.x), b = __float_as_uint(r.y);
         h = h * 31u + (a ^ (b << 11 | b >> 21));
         x.x += 0.25f; x.y -= 0.125f;
@@ -628,6 +635,7 @@ int main(int argc, char **argv)
             case 71: victim_pk<11><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 72: victim_pk<12><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 73: victim_pk<13><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
+            case 74: victim_pk<14><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 15: victim_fused<15><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 16: victim_fused<16><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
             case 17: victim_fused<17><<<blocks, 256, 0, st>>>(verts, cam, faces_idx, nv, eye_z, faces, bs, nf, is, faces_inv, pbox, tbox); break;
@@ -716,7 +724,7 @@ int main(int argc, char **argv)
                wrong_c, wrong_flag_only, wrong_sum, lanes_hi, lanes_any);
         return 0;
     }
-    if (victim >= 40 && (victim < 60 || victim > 73)) {
+    if (victim >= 40 && (victim < 60 || victim > 74)) {
         const int pk = victim >= 140 ? 1 : 0;
         const int iters = 32, W = (victim - 100 * pk - 20) / 10, S = (victim - 100 * pk - 20) % 10;
         const unsigned n = (unsigned)nface;
@@ -800,7 +808,24 @@ int main(int argc, char **argv)
             CHECK(hipMemcpy(gi.data(), faces_inv, nface * 36, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ri.data(), ref_inv, nface * 36, hipMemcpyDeviceToHost));
             CHECK(hipMemcpy(gf.data(), faces, nface * 36, hipMemcpyDeviceToHost));
             CHECK(hipMemcpy(gt.data(), tbox, nface * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(rt.data(), ref_tbox, nface * 4, hipMemcpyDeviceToHost));
-            int shown = 0;
+            if (victim == 74) {   // which lanes, and what the instruction computed instead of x.lo * y.hi / x.hi * y.hi
+                size_t lanes[4] = {0, 0, 0, 0}, nb = 0, lo_as_lolo = 0, lo_as_hilo = 0, lo_zero = 0, hi_bad = 0, hi_as_hilo = 0, hi_as_lolo = 0, other = 0;
+                for (size_t i = 0; i < nface; ++i) {
+                    const float *g = &gi[i * 9];
+                    const float xl = g[1], xh = g[2], yl = g[3], yh = g[4], rx = *(float *)&gt[i], ry = g[0];
+                    const bool bx = rx != xl * yh, by = ry != xh * yh;
+                    if (!bx && !by) continue;
+                    ++nb; ++lanes[(i % 64) / 16];
+                    if (bx) { if (rx == xl * yl) ++lo_as_lolo; else if (rx == xh * yl) ++lo_as_hilo; else if (rx == 0.f) ++lo_zero; else ++other; }
+                    if (by) { ++hi_bad; if (ry == xh * yl) ++hi_as_hilo; else if (ry == xl * yl) ++hi_as_lolo; }
+                    if (nb <= 4) printf("  thread %zu (lane %zu): x = (%g, %g) y = (%g, %g): low result %g (x.lo*y.hi = %g, x.lo*y.lo = %g), high result %g (x.hi*y.hi = %g, x.hi*y.lo = %g)\n",
+                                        i, i % 64, xl, xh, yl, yh, rx, xl * yh, xl * yl, ry, xh * yh, xh * yl);
+                }
+                printf("  detail: %zu wrong threads in this launch; by quarter-wave (lanes 0-15, 16-31, 32-47, 48-63): %zu %zu %zu %zu; low result = x.lo*y.lo "
+                       "(read src1.LOW instead of src1.high) %zu, = x.hi*y.lo %zu, = 0 %zu, something else %zu; high result wrong %zu (= x.hi*y.lo %zu, = x.lo*y.lo %zu)\n",
+                       nb, lanes[0], lanes[1], lanes[2], lanes[3], lo_as_lolo, lo_as_hilo, lo_zero, other, hi_bad, hi_as_hilo, hi_as_lolo);
+            }
+            int shown = victim == 74 ? 6 : 0;
             size_t run_start = 0, nbad = 0;
             for (size_t i = 0; i < nface; ++i) {
                 const bool bad = gt[i] != rt[i] || memcmp(&gi[i * 9], &ri[i * 9], 36) != 0;
