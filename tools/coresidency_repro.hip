@@ -526,6 +526,21 @@ __global__ __launch_bounds__(256) void neighbour_kernel(float *sink, int stages)
     if (keep == 123.456f) sink[0] = keep;
 }
 
+// Neighbours 901-906: workgroups that do NOTHING but hold registers (s_sleep in a loop), to separate "what the neighbour
+// executes" from "where the victim's registers land in the SIMD's register file because of what the neighbour holds".
+#define REPRO_OCCUPIER(name, ...)                                                          \
+    __global__ __launch_bounds__(256) void name(float *sink, int spins)                    \
+    {                                                                                      \
+        for (int i = 0; i < spins; ++i) asm volatile("s_sleep 32" ::: __VA_ARGS__);        \
+        if (spins < 0) sink[0] = 1.f;                                                      \
+    }
+REPRO_OCCUPIER(occupier_v64, "v63")
+REPRO_OCCUPIER(occupier_v128, "v127")
+REPRO_OCCUPIER(occupier_v120_a64, "v119", "a63")      // the four-wave halo kernel's allocation (116 + 64)
+REPRO_OCCUPIER(occupier_v184, "v183")                 // the eight-wave halo kernel's (182, no AGPRs)
+REPRO_OCCUPIER(occupier_v256, "v255")
+REPRO_OCCUPIER(occupier_v192_a64, "v191", "a63")
+
 }  // namespace repro
 
 using namespace repro;
@@ -680,6 +695,14 @@ int main(int argc, char **argv)
     auto run_neighbour = [&](hipStream_t st) {
         if (neigh == 1) neighbour_kernel<false><<<256, 256, 98304, st>>>(sink, 150);
         if (neigh == 2) neighbour_kernel<true><<<256, 256, 98304, st>>>(sink, 150);
+        // register occupiers: 1024 workgroups of four waves, ~250 us each
+        if (neigh == 901) occupier_v64<<<1024, 256, 0, st>>>(sink, 200);
+        if (neigh == 902) occupier_v128<<<1024, 256, 0, st>>>(sink, 200);
+        if (neigh == 903) occupier_v120_a64<<<1024, 256, 0, st>>>(sink, 200);
+        if (neigh == 904) occupier_v184<<<1024, 256, 0, st>>>(sink, 200);
+        if (neigh == 905) occupier_v256<<<1024, 256, 0, st>>>(sink, 200);
+        if (neigh == 906) occupier_v192_a64<<<1024, 256, 0, st>>>(sink, 200);
+        if (neigh >= 901 && neigh <= 906) return;
 #ifdef REAL_NEIGHBOUR
         if (neigh == 3) lwg::launch_conv_igemm_dbg(ca, 128, 200, st);
         if (neigh >= 100 && lwg::launch_conv_igemm_dbg(ca, 128, neigh, st) != 0) { fprintf(stderr, "unknown variant %d\n", neigh); exit(2); }
