@@ -31,6 +31,7 @@
 //   neighbour 0 = none (control), 1 = MFMA stream only, 2 = ds_read_b128 + MFMA stream (stripped conv main loop:
 //            96 KiB of LDS per workgroup = one workgroup per CU, one wave per SIMD, one 16-byte LDS read behind every MFMA),
 //            3 = the product's conv_igemm_bf16x3<128> itself (only when built with -DREAL_NEIGHBOUR)
+//            4 = neighbour 2 with RANDOM bf16 operand data in LDS instead of values next to 1.0
 //   cumask   0 = no masks; 1 = victim stream on CUs 0-127, neighbours on CUs 128-255 (same chip, never the same CU);
 //            2 = victim and neighbours both confined to CUs 0-127 (always share CUs)
 //
@@ -486,11 +487,19 @@ __global__ void compare_words(const unsigned *a, const unsigned *b, size_t n, un
 // 96 KiB of LDS (one workgroup per CU), per "stage" 16 ds_read_b128 of swizzled 128-byte rows, each behind one of 24
 // v_mfma_f32_32x32x16_bf16 on four accumulator tiles.  LDS = 0: the MFMA stream alone.
 template <bool LDS>
-__global__ __launch_bounds__(256) void neighbour_kernel(float *sink, int stages)
+__global__ __launch_bounds__(256) void neighbour_kernel(float *sink, int stages, int random_data = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 24576; i += 256) smem[i] = __uint_as_float(0x3f803f80u + (unsigned)(i * 2654435761u >> 20));
+    for (int i = tid; i < 24576; i += 256) {
+        unsigned w = 0x3f803f80u + (unsigned)(i * 2654435761u >> 20);      // two bf16 values next to 1.0: few bits toggle
+        if (random_data) {   // neighbour 4: two bf16 values with random sign / mantissa and an exponent of 2^-2 .. 2^0: every bit toggles
+            unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            w = (h & 0x807f807fu) | 0x3e803e80u | ((h >> 3) & 0x00800080u);
+        }
+        smem[i] = __uint_as_float(w);
+    }
     __syncthreads();
     f32x16 acc[4];
 #pragma unroll
@@ -510,7 +519,9 @@ __global__ __launch_bounds__(256) void neighbour_kernel(float *sink, int stages)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[q & 7]), __builtin_bit_cast(bf16x8, f[(q + 3) & 7]),
                                                              acc[t], 0, 0, 0);
             if (LDS && q < 16) {
-                const int col = (((q & 7) ^ fsw) * 4);
+                // random_data & 2 (neighbour 6): lanes 32-63 read the NEXT 16-byte chunk, as the product's fragments do (64 distinct
+                // addresses per instruction: twice the LDS bytes of the default, whose upper half re-reads the lower half's)
+                const int col = (random_data & 2) ? ((((2 * (q & 3) + (lane >> 5)) & 7) ^ fsw) * 4) : (((q & 7) ^ fsw) * 4);
                 const float *p = base + ((q & 8) ? b_row : a_row) + ((q & 4) ? 32 * 32 : 0) + col;
                 f[q & 7] = *reinterpret_cast<const float4 *>(p);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -695,6 +706,10 @@ int main(int argc, char **argv)
     auto run_neighbour = [&](hipStream_t st) {
         if (neigh == 1) neighbour_kernel<false><<<256, 256, 98304, st>>>(sink, 150);
         if (neigh == 2) neighbour_kernel<true><<<256, 256, 98304, st>>>(sink, 150);
+        if (neigh == 4) neighbour_kernel<true><<<256, 256, 98304, st>>>(sink, 150, 1);    // the same loop on random operand data
+        if (neigh == 5) neighbour_kernel<false><<<256, 256, 98304, st>>>(sink, 150, 1);   // MFMAs only (operands stay constant)
+        if (neigh == 6) neighbour_kernel<true><<<256, 256, 98304, st>>>(sink, 150, 3);    // random data, 64 distinct 16-byte reads per instruction
+        if (neigh >= 4 && neigh <= 6) return;
         // register occupiers: 1024 workgroups of four waves, ~250 us each
         if (neigh == 901) occupier_v64<<<1024, 256, 0, st>>>(sink, 200);
         if (neigh == 902) occupier_v128<<<1024, 256, 0, st>>>(sink, 200);
