@@ -221,7 +221,7 @@ class Imitator(BaseModel):
     # depth 1 2709, 2 2772, 3 2799, 4 2811 frames/s in one process.  env LWG_ROUND_DEPTH
     round_depth = 4
     # True: the next round's geometry runs underneath this round's generators; False (default): it waits for them.
-    # At round_depth 4 the overlap is worth little (+1.5 %), and it is the configuration in which rasteriser kernels used to
+    # At round_depth 4 the overlap is worth nothing measurable (profiles/r03_bench_overlap_ab.json), and it is the configuration in which rasteriser kernels used to
     # miscompute beside the bf16x3 conv kernels.  The cause is known now -- a packed-fp32 instruction form (DESIGN.md section
     # 5.1) that liblwg's geometry kernels no longer contain and every source is checked for -- but torch's own glue kernels
     # of the geometry stage are outside that check.  Opt in with LWG_OVERLAP_GEOMETRY=1 / the keyword.
@@ -258,7 +258,7 @@ class Imitator(BaseModel):
              1 %).
         By default the geometry of round r+1 waits for the generators of round r (the strictly alternating order);
         `overlap_geometry=True` / LWG_OVERLAP_GEOMETRY=1 lets it run underneath them (worth +2.5 % at round_depth 1,
-        +1.5 % at the default depth 4).  Until the end of round 2 that overlap produced wrong pixels in ~90 % of
+        nothing measurable at the default depth 4).  Until the end of round 2 that overlap produced wrong pixels in ~90 % of
         passes: hipcc had formed a packed-fp32 instruction with op_sel on its second source in the rasteriser's setup
         kernel, a form that miscomputes on a CU shared with the bf16x3 convolution kernels.
         liblwg is checked for that form (tests/test_pk_opsel_lint.py) and the stress runs are clean (profiles/), but
