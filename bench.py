@@ -332,7 +332,8 @@ def main():
     t0 = time.perf_counter()
     out = run_steps(args.warmup, args.steps)
     sharding.barrier(dev)
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else "cpu")
+    rdev = dev if torch.distributed.is_initialized() else "cpu"   # RCCL reduces device tensors
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, rdev)
     assert bool(torch.isfinite(out).all())
 
     def roofline_pass():
@@ -402,6 +403,8 @@ def main():
         return block
 
     roofline = roofline_pass() if not args.no_roofline else None
+    # what carried the barrier / max-over-ranks above (every rank takes part in its one-element all-reduce)
+    rccl = sharding.collective_info(dev) if torch.distributed.is_initialized() else None
 
     fp32_mode = None
     if precision != "fp32" and not args.no_fp32_mode:
@@ -412,7 +415,7 @@ def main():
         t1 = time.perf_counter()
         run_steps(args.warmup, args.steps)
         sharding.barrier(dev)
-        dt32 = sharding.max_over_ranks(time.perf_counter() - t1, dev if world > 1 else "cpu")
+        dt32 = sharding.max_over_ranks(time.perf_counter() - t1, rdev)
         fp32_mode = {"value": round(world * BATCH * args.steps / dt32, 3), "unit": "frames/s",
                      "ms_per_step": round(dt32 / args.steps * 1e3, 4), "dtype": "f32",
                      "note": "same workload, precision='fp32' (v_mfma_f32_32x32x2_f32, bit-exact fmaf chains)"}
@@ -439,6 +442,12 @@ def main():
                                                  "accumulate; 8e-5 L-inf on the image vs fp32, bound 1e-3)"
                                                  if precision == "bf16x3" else " (exact fp32 MFMA)")},
         }
+        if rccl is not None:
+            # N > 1 (or LWG_FORCE_DIST=1 at N = 1): the process group behind the timing barrier -- backend 'nccl' IS RCCL on
+            # ROCm; `ranks` is the communicator's size as the library reports it, `allreduce_of_ones` must equal it
+            line["rccl"] = rccl
+            if rccl["allreduce_of_ones"] != world:
+                line["invalid"] = "the process group's all-reduce of ones returned %r on %d ranks" % (rccl["allreduce_of_ones"], world)
         if fp32_mode is not None:
             line["exact_fp32_mode"] = fp32_mode
         if roofline is not None:
@@ -455,7 +464,7 @@ def main():
         print(json.dumps(line))
         if line.get("invalid"):
             sys.exit(1)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

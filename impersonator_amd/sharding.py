@@ -19,10 +19,18 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", 1)))
 
 
+def forced():
+    """LWG_FORCE_DIST=1: initialise the process group and run every collective also at world_size 1 -- how the RCCL
+    code path (communicator creation bound to `device_id`, barrier, all-reduce of CUDA tensors, object gather) is
+    executed on a box with ONE GPU (tests/test_gpu_rccl.py); RCCL wants a GPU per rank, so two ranks cannot share it."""
+    return os.environ.get("LWG_FORCE_DIST", "0") not in ("0", "", "false", "False")
+
+
 def init_process_group(backend=None):
-    """Initialises torch.distributed when launched under torchrun; returns (rank, local_rank, world)."""
+    """Initialises torch.distributed when launched under torchrun (or at world 1 under LWG_FORCE_DIST=1); returns
+    (rank, local_rank, world)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -75,7 +83,7 @@ def sum_over_ranks(value, device="cpu"):
 def gather_in_frame_order(local_items, num_frames, batch, rank, world):
     """local_items: this rank's per-frame outputs in the order of shard_blocks().  Returns the full
     frame-ordered list on rank 0 (None elsewhere)."""
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized() or (world == 1 and not forced()):
         return list(local_items)
     gathered = [None] * world if rank == 0 else None
     dist.gather_object(list(local_items), gathered, dst=0)
@@ -114,7 +122,25 @@ def average_gradients(flat_grads):
     """Data-parallel training: averages a flat gradient tensor over the ranks in place (all-reduce SUM
     then divide) -- RCCL over xGMI for CUDA tensors, gloo on CPU.  No-op without an initialised multi-rank group.  The
     reference does this implicitly through nn.DataParallel (models/impersonator_trainer.py:196-214)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced()):
         dist.all_reduce(flat_grads)
         flat_grads.div_(dist.get_world_size())
     return flat_grads
+
+
+def collective_info(device=None):
+    """What carries the collectives of this process group, for the bench line's `rccl` block: backend name, the number
+    of ranks the communicator spans, the RCCL version torch was built against, and a one-element SUM all-reduce on
+    `device` that must come back equal to the number of ranks (proof that the communicator really connects them)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    info = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+    if info["backend"] == "nccl":
+        v = torch.cuda.nccl.version()
+        info["version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        info["library"] = "RCCL (torch.distributed backend 'nccl' on ROCm %s)" % getattr(torch.version, "hip", None)
+    dev = device if device is not None else ("cuda" if info["backend"] == "nccl" else "cpu")
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(one)
+    info["allreduce_of_ones"] = float(one.item())
+    return info

@@ -43,6 +43,8 @@ def _smpl_of(path):
 def main():
     opt = TestOptions().parse()
     rank, local_rank, world = sharding.init_process_group()
+    if local_rank >= torch.cuda.device_count() and os.environ.get("LWG_DIST_BACKEND") == "gloo":
+        local_rank %= torch.cuda.device_count()   # test hook: N gloo ranks sharing the visible GPU(s) (RCCL wants one each)
     torch.cuda.set_device(local_rank)
     if opt.synthetic:
         imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(
@@ -68,10 +70,13 @@ def main():
     if rank == 0 and opt.output_dir:
         out_dir = util.mkdir(opt.output_dir)
         for t, img in enumerate(outs):
-            name = os.path.split(tgt_paths[t])[-1] if tgt_paths else '%.8d.jpg' % t
+            # the reference names its outputs after the target files (run_imitator.py:232, 'pred_%.8d.jpg' in
+            # inference_by_smpls); the synthetic sequence has no files and is written losslessly, so that what lands on
+            # disk IS the uint8 truncation of utils/cv_utils.py:31-33 (hazard H11) and can be compared as such
+            name = os.path.split(tgt_paths[t])[-1] if tgt_paths else '%.8d.png' % t
             cv_utils.save_cv2_img(img, os.path.join(out_dir, 'pred_' + name), normalize=True)
         print('wrote %d frames to %s' % (len(outs), out_dir))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

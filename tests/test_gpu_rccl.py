@@ -1,0 +1,57 @@
+"""RCCL executed from this repository's multi-rank code on the one visible GPU (the reference's equivalent is
+nn.DataParallel, models/impersonator_trainer.py:196-214).  RCCL wants a GPU per rank, so the process group is forced at
+world_size 1 (LWG_FORCE_DIST=1, impersonator_amd/sharding.py::forced): backend "nccl", communicator bound to the device at
+init, then the calls bench.py / run_imitator.py / the trainer make.  The two-rank semantics of the same calls are covered
+on gloo (tests/test_gpu_multirank.py, tests/test_gpu_sharding.py, tests/test_sharding.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(args, timeout=900):
+    env = dict(os.environ, LWG_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    env.pop("LWG_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
+                       text=True)
+    assert p.returncode == 0, "%s failed (%d)\n%s\n%s" % (args[0], p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_collectives_on_one_rank():
+    """init_process_group(nccl, device_id), barrier, max/sum over ranks on device tensors, the frame-ordered object gather,
+    and average_gradients on the trainer's real G (390 MB) and D (29.9 MB) gradient buffers -- through RCCL."""
+    out = _run(["tools/rccl_smoke.py"])
+    print("rccl:", json.dumps(out))
+    r = out["rccl"]
+    assert r["backend"] == "nccl" and r["ranks"] == 1 and r["allreduce_of_ones"] == 1.0
+    assert r["version"] and r["version"][0].isdigit()
+    ag = out["average_gradients"]
+    assert ag["G"]["bytes"] > 3.8e8 and 2.7e7 < ag["D"]["bytes"] < 3.1e7
+    assert ag["G"]["max_abs_err"] <= 1e-6 and ag["D"]["max_abs_err"] <= 1e-6 and ag["G"]["ms"] > 0
+
+
+def test_bench_line_carries_the_rccl_block():
+    """bench.py with a process group (the driver's N > 1 launch; here forced at N = 1) reports what carried its barrier:
+    backend nccl, the communicator's rank count, the RCCL version, and an all-reduce of ones equal to the rank count."""
+    line = _run(["bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-fp32-mode", "--no-secondary",
+                 "--no-roofline"])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "invalid" not in line
+    r = line["rccl"]
+    assert r["backend"] == "nccl" and r["ranks"] == 1 and r["allreduce_of_ones"] == 1.0 and r["version"]

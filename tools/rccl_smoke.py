@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""RCCL itself, executed from this repository's own multi-rank code, on however many GPUs are visible.
+
+    LWG_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=P python tools/rccl_smoke.py
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/rccl_smoke.py
+
+gpurun offers one GPU and RCCL wants a GPU per rank, so the tests run this at world_size 1 with LWG_FORCE_DIST=1
+(`sharding.forced()`): backend "nccl" (= RCCL on ROCm), communicator bound to the rank's device at init
+(`init_process_group(device_id=...)`), and then exactly the calls `bench.py`, `run_imitator.py` and the trainer make --
+`sharding.barrier`, `max_over_ranks` / `sum_over_ranks` on a device tensor, `gather_in_frame_order` (object gather) and
+`average_gradients` on the trainer's real flat gradient buffers (generator 390 MB, discriminator 29.9 MB).  A
+single-rank all-reduce is a copy-through inside RCCL, but everything around it -- bootstrap over the rendezvous, the
+HIP streams/events ProcessGroupNCCL puts around a collective, dmabuf IPC initialisation (HSA_ENABLE_IPC_MODE_LEGACY=0),
+the kernels RCCL launches -- is what a first N-GPU run would otherwise meet for the first time.  Rank 0 prints one
+JSON line."""
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from impersonator_amd import sharding  # noqa: E402
+
+
+def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rank, local_rank, world = sharding.init_process_group(backend=os.environ.get("LWG_DIST_BACKEND", "nccl"))
+    import torch.distributed as dist
+    assert dist.is_initialized(), "no process group: launch under torchrun or with LWG_FORCE_DIST=1"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    out = {"world": world, "device": torch.cuda.get_device_name(dev)}
+    out["rccl"] = sharding.collective_info(dev)
+    assert out["rccl"]["ranks"] == world and out["rccl"]["allreduce_of_ones"] == world
+
+    sharding.barrier(dev)
+    assert sharding.max_over_ranks(1.5 + rank, dev) == 1.5 + (world - 1)
+    assert sharding.sum_over_ranks(2.0, dev) == 2.0 * world
+
+    # frame-ordered gather of per-frame outputs (what run_imitator.py collects on rank 0)
+    frames, batch = 8 * world + 3, 4
+    mine = [("f%d" % t, rank) for s, e in sharding.shard_blocks(frames, batch, rank, world) for t in range(s, e)]
+    got = sharding.gather_in_frame_order(mine, frames, batch, rank, world)
+    if rank == 0:
+        assert [g[0] for g in got] == ["f%d" % t for t in range(frames)]
+
+    # the training path's one collective, on the trainer's real flat gradient buffers
+    from impersonator_amd.models.impersonator_trainer import Impersonator
+    size = int(os.environ.get("LWG_RCCL_SMOKE_SIZE", 64))
+    m = Impersonator(types.SimpleNamespace(image_size=size, batch_size=1, map_name='uv_seg', norm_type='instance', repeat_num=6,
+                                           is_train=True, conv_precision="bf16x3"))
+    tr = m._generator_trainer()
+    g_grad, d_grad = tr.flat_g, m._D.flat_buffers()[1]
+    times = {}
+    for name, buf in (("G", g_grad), ("D", d_grad)):
+        n = buf.numel()
+        pattern = torch.arange(n, device=dev, dtype=torch.float32).remainder_(1021.0).mul_(1.0 / 1021.0)
+        buf.copy_(pattern * (rank + 1))
+        sharding.average_gradients(buf)      # warm-up call: communicator's first large collective
+        expect = pattern * ((world + 1) / 2.0)
+        err = float((buf - expect).abs().max())
+        assert err <= 1e-6, (name, err)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            sharding.average_gradients(buf)
+        torch.cuda.synchronize(dev)
+        times[name] = {"bytes": n * 4, "ms": round((time.perf_counter() - t0) / reps * 1e3, 4), "max_abs_err": err}
+    out["average_gradients"] = times
+    sharding.barrier(dev)
+    if rank == 0:
+        print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
