@@ -94,7 +94,7 @@ def cpu_baseline(seed=0, batches=2):
     """Times the CPU oracle (kind 'port': oracle/torch_ref.py + oracle/raster_ref.c, see their headers) on the same
     workload: one warm-up + `batches` batches of 8 frames, all host cores."""
     from oracle import torch_ref
-    from impersonator_amd.networks.batch_smpl import HumanModelRecovery, synthetic_smpl_params
+    from impersonator_amd.networks.batch_smpl import SMPL, synthetic_smpl_params
     from impersonator_amd.networks.generator import ImpersonatorGenerator
     from impersonator_amd.utils import synthetic
 
@@ -106,14 +106,18 @@ def cpu_baseline(seed=0, batches=2):
     G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6)
     shapes = [(k, tuple(v.shape)) for k, v in G.state_dict().items()]
     sd = torch_ref.state_dict_from_numpy(synthetic.random_state_dict(shapes, seed=seed, affine="identity"))
-    hmr = HumanModelRecovery(smpl_params=synthetic_smpl_params(seed))
+    # the oracle's SMPL (== the reference's SMPL.forward, tests/test_oracle_vs_reference.py) on float64 tensors, rounded to fp32:
+    # the correctly rounded vertices, which is also what the device's default `compensated` SMPL mode produces -- so the
+    # frames computed here double as the theta -> image parity vectors.  (SMPL is 0.02 of 105.6 GFLOP per frame: its dtype
+    # does not show in the timing.)
+    sm = torch_ref.smpl_tensors(SMPL(params=synthetic_smpl_params(seed)), torch.float64)
     src_smpl = torch.from_numpy(demo.synthetic_smpls(1, seed + 1))
     src_smpl[:, 3:75] = 0
     src_img = torch.from_numpy(synthetic.smooth_image(seed + 11))
     bg_img = torch.from_numpy(synthetic.smooth_image(seed + 12))
     smpls = torch.from_numpy(demo.synthetic_smpls(1024, seed))
     with torch.no_grad():
-        si = hmr.get_details(src_smpl)
+        si = torch_ref.get_details(sm, src_smpl)
         sf2v, sfim, _ = torch_ref.render_fim_wim(si["cam"], si["verts"], faces_t)
         p2v = torch_ref.source_p2verts(sf2v)
         scond = torch_ref.encode_fim(sfim, map_fn)
@@ -124,7 +128,7 @@ def cpu_baseline(seed=0, batches=2):
             chunk = smpls[b * BATCH:(b + 1) * BATCH]
             cam = si["cam"].expand(BATCH, -1).clone()
             cam[:, 1:] += chunk[:, 1:3] - smpls[0:1, 1:3]
-            info = hmr.get_details(torch.cat([cam, chunk[:, 3:75], si["shape"].expand(BATCH, -1)], 1))
+            info = torch_ref.get_details(sm, torch.cat([cam, chunk[:, 3:75], si["shape"].expand(BATCH, -1)], 1))
             fr = torch_ref.transfer_frame(src_img, p2v, info["cam"], info["verts"], faces_t, map_fn)
             return fr["fim"], torch_ref.imitator_forward(sd, enc, res, bg_img, fr["tsf_inputs"], fr["T"])[0]
 
@@ -150,7 +154,7 @@ def cpu_baseline(seed=0, batches=2):
             "port_vs_reference": "calibration where /root/reference exists (8-core build container, 5 batches each): the "
                                  "port runs at 0.90x the speed of the reference's own modules (median; per-batch spread "
                                  "0.76-1.06x) with bit-identical outputs -- profiles/r02_port_vs_reference.md"}
-    return line, {"fim": torch.cat([k[0] for k in kept]), "pred": torch.cat([k[1] for k in kept]), "first_batch": 1}
+    return line, {"fim": torch.cat([k[0] for k in kept]), "pred": torch.cat([k[1] for k in kept]), "first_batch": 1, "src_fim": sfim}
 
 
 def parity_block(imitator, src_img, bg_img, smpls, lanes, theta_chain):
@@ -183,17 +187,23 @@ def parity_block(imitator, src_img, bg_img, smpls, lanes, theta_chain):
     frames_agree = agree.flatten(1).all(1)
     linf = float((pred - ref).abs().max())
     fim_mismatch = int((fim != fr["fim"]).sum()) + int((si["fim"].cpu() != src["fim"]).sum())
-    return {"ok": bool(linf <= 1e-3 and fim_mismatch == 0),
+    smpl_mode = imitator.hmr.smpl.precision
+    chain_fim = int((~agree).sum()) + int((si["fim"].cpu() != theta_chain["src_fim"]).sum())
+    chain_ok = (chain_fim == 0 and float(d_chain.max()) <= 1e-3) if smpl_mode == "compensated" else True
+    return {"ok": bool(linf <= 1e-3 and fim_mismatch == 0 and chain_ok),
             "frames": int(pred.shape[0]), "linf": round(linf, 7), "fim_mismatch": fim_mismatch,
             "T_linf": round(float((torch.cat(Ts) - fr["T"]).abs().max()), 9),
             "bound": 1e-3, "oracle": "same_vertices: oracle/torch_ref.py + raster_ref.c restarted from the device's posed "
                                      "vertices; pipeline = the timed one (%d lanes)" % lanes,
-            "theta_chain": {"fim_mismatch_pixels": int((~agree).sum()),
+            "theta_chain": {"ok": bool(chain_ok), "smpl_precision": smpl_mode, "fim_mismatch_pixels": chain_fim,
                             "frames_with_identical_fim": int(frames_agree.sum()),
                             "linf_on_those_frames": (round(float(d_chain[frames_agree].max()), 7)
                                                      if bool(frames_agree.any()) else None),
                             "linf_all": round(float(d_chain.max()), 7),
-                            "note": "oracle's own CPU SMPL from the same theta (vertices differ by ~1e-6)"}}
+                            "note": "oracle's own SMPL from the same theta in fp64, rounded (= the reference's SMPL.forward on float64 "
+                                    "tensors); device SMPL in its `compensated` mode (fp64 intermediates, one rounding): part of `ok`.  "
+                                    "Against ONE fp32 evaluation there is no 1e-3 answer: the reference's own SMPL moves the image by "
+                                    "1.2e-3..3e-3 with the thread count / frames per call (profiles/r04_theta_chain_reference_self.md)"}}
 
 
 def conv_roofline(generator, run, steps=1):

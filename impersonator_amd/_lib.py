@@ -42,6 +42,7 @@ _PROTOS = {
     "lwg_smpl_project_joints": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "lwg_smpl_workspace_bytes": (_sz, [_i]),
     "lwg_smpl_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lwg_smpl_forward_f64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lwg_pack_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lwg_unpack_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lwg_generator_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _i, _i]),

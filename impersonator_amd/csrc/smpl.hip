@@ -23,58 +23,81 @@ constexpr int NJ = 24;        // SMPL joints
 constexpr int NPF = 207;      // pose feature length = 23 * 9
 static_assert(NPF % 23 == 0, "the pose-blend loop walks 23 terms at a time");
 
-// workspace: pose feature (bs, 207) then A (bs, 24, 12)
+// The working type R of the three kernels: float = the reference's own arithmetic (fp32 tensors, networks/batch_smpl.py), every
+// multiply-add one rounding; double = the "compensated" mode (lwg_smpl_forward_f64): the same expressions on the same fp32
+// model tensors evaluated in fp64 and rounded to fp32 once at the end -- the correctly rounded value of the function the
+// reference's code defines, which any fp32 evaluation (the reference's included) misses by its own ~1e-6 of summation
+// noise.  That noise matters downstream: the rasteriser's barycentric weights amplify a 1e-6 vertex difference to 1e-3 in
+// the flow.  Cost: nothing measurable (the kernels are latency-bound, 0.02 GFLOP per frame).
+template <typename R> struct mathx;
+template <> struct mathx<float> {
+    static __device__ float sqrt_(float x) { return sqrtf(x); }
+    static __device__ float cos_(float x) { return cosf(x); }
+    static __device__ float sin_(float x) { return sinf(x); }
+    static __device__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+};
+template <> struct mathx<double> {
+    static __device__ double sqrt_(double x) { return sqrt(x); }
+    static __device__ double cos_(double x) { return cos(x); }
+    static __device__ double sin_(double x) { return sin(x); }
+    static __device__ double fma_(double a, double b, double c) { return fma(a, b, c); }
+};
+
+// workspace: pose feature (bs, 207) then A (bs, 24, 12), both of type R
+template <typename R, typename JT>
 __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__ theta, int nb,
-                                                       const float *__restrict__ J_template,
-                                                       const float *__restrict__ J_shapedirs,
-                                                       const int *__restrict__ parents, float *__restrict__ pf,
-                                                       float *__restrict__ A_out, float *__restrict__ Rs_out)
+                                                       const JT *__restrict__ J_template,
+                                                       const JT *__restrict__ J_shapedirs,
+                                                       const int *__restrict__ parents, R *__restrict__ pf,
+                                                       R *__restrict__ A_out, float *__restrict__ Rs_out)
 {
-    __shared__ float R[NJ][9];
-    __shared__ float J[NJ][3];
-    __shared__ float G[NJ][12];   // world transforms, row-major 3x4
+    using M = mathx<R>;
+    __shared__ R Rm[NJ][9];
+    __shared__ R J[NJ][3];
+    __shared__ R G[NJ][12];   // world transforms, row-major 3x4
     const int b = blockIdx.x, l = threadIdx.x;
     const float *th = theta + (size_t)b * (3 + 72 + nb);
     const float *pose = th + 3, *beta = th + 75;
 
     if (l < NJ) {
         // batch_smpl.py:86-100: angle = ||r + 1e-8||, axis = r / angle
-        const float rx = pose[3 * l], ry = pose[3 * l + 1], rz = pose[3 * l + 2];
-        const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
-        const float angle = sqrtf(ax * ax + ay * ay + az * az);
-        const float x = rx / angle, y = ry / angle, z = rz / angle;
-        const float c = cosf(angle), s = sinf(angle), t = 1.f - c;
-        float m[9];
+        const R rx = pose[3 * l], ry = pose[3 * l + 1], rz = pose[3 * l + 2];
+        const R eps = (R)1e-8f;
+        const R ax = rx + eps, ay = ry + eps, az = rz + eps;
+        const R angle = M::sqrt_(ax * ax + ay * ay + az * az);
+        const R x = rx / angle, y = ry / angle, z = rz / angle;
+        const R c = M::cos_(angle), s = M::sin_(angle), t = (R)1 - c;
+        R m[9];
         m[0] = c + t * x * x;     m[1] = t * x * y - s * z; m[2] = t * x * z + s * y;
         m[3] = t * y * x + s * z; m[4] = c + t * y * y;     m[5] = t * y * z - s * x;
         m[6] = t * z * x - s * y; m[7] = t * z * y + s * x; m[8] = c + t * z * z;
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
-            R[l][e] = m[e];
-            if (Rs_out) Rs_out[((size_t)b * NJ + l) * 9 + e] = m[e];
-            if (l >= 1) pf[(size_t)b * NPF + (l - 1) * 9 + e] = m[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+            Rm[l][e] = m[e];
+            if (Rs_out) Rs_out[((size_t)b * NJ + l) * 9 + e] = (float)m[e];
+            if (l >= 1) pf[(size_t)b * NPF + (l - 1) * 9 + e] = m[e] - ((e == 0 || e == 4 || e == 8) ? (R)1 : (R)0);
         }
     }
     for (int i = l; i < NJ * 3; i += 64) {
-        float v = J_template[i];
-        for (int k = 0; k < nb; ++k) v += beta[k] * J_shapedirs[k * NJ * 3 + i];
+        R v = J_template[i];
+        for (int k = 0; k < nb; ++k) v += (R)beta[k] * (R)J_shapedirs[k * NJ * 3 + i];
         J[i / 3][i % 3] = v;
     }
     __syncthreads();
 
     // kinematic chain (batch_smpl.py:189-197): G_i = G_parent * [R_i | J_i - J_parent]; 12 lanes, one per element
     const int r = l >> 2, cidx = l & 3;
-    if (l < 12) G[0][l] = cidx < 3 ? R[0][r * 3 + cidx] : J[0][r];
+    if (l < 12) G[0][l] = cidx < 3 ? Rm[0][r * 3 + cidx] : J[0][r];
     __syncthreads();
     for (int i = 1; i < NJ; ++i) {
         const int p = parents[i];
         if (l < 12) {
-            float v;
+            R v;
             if (cidx < 3) {
-                v = G[p][r * 4 + 0] * R[i][0 * 3 + cidx] + G[p][r * 4 + 1] * R[i][1 * 3 + cidx] +
-                    G[p][r * 4 + 2] * R[i][2 * 3 + cidx];
+                v = G[p][r * 4 + 0] * Rm[i][0 * 3 + cidx] + G[p][r * 4 + 1] * Rm[i][1 * 3 + cidx] +
+                    G[p][r * 4 + 2] * Rm[i][2 * 3 + cidx];
             } else {
-                const float dx = J[i][0] - J[p][0], dy = J[i][1] - J[p][1], dz = J[i][2] - J[p][2];
+                const R dx = J[i][0] - J[p][0], dy = J[i][1] - J[p][1], dz = J[i][2] - J[p][2];
                 v = G[p][r * 4 + 0] * dx + G[p][r * 4 + 1] * dy + G[p][r * 4 + 2] * dz + G[p][r * 4 + 3];
             }
             G[i][l] = v;
@@ -84,7 +107,7 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__
     // relative transforms (batch_smpl.py:206-216): A = G - [0 | G_rot * J]
     for (int i = l; i < NJ * 12; i += 64) {
         const int j = i / 12, e = i % 12, rr = e >> 2, cc = e & 3;
-        float v = G[j][e];
+        R v = G[j][e];
         if (cc == 3) v -= G[j][rr * 4 + 0] * J[j][0] + G[j][rr * 4 + 1] * J[j][1] + G[j][rr * 4 + 2] * J[j][2];
         A_out[((size_t)b * NJ + j) * 12 + e] = v;
     }
@@ -100,44 +123,46 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__
 // operation sequence: results do not depend on the batch size or on the frame's position (tested bit for bit).
 constexpr int VB = 64;          // vertices per workgroup (192 lanes)
 constexpr int VF = 4;           // frames per lane
+template <typename R>
 __global__ __launch_bounds__(3 * VB) void smpl_verts_kernel(const float *__restrict__ theta, int nb, int nv, int bs,
                                                             const float *__restrict__ v_template,
                                                             const float *__restrict__ shapedirs,
                                                             const float *__restrict__ posedirs,
                                                             const float *__restrict__ weights,
-                                                            const float *__restrict__ pf, const float *__restrict__ A,
+                                                            const R *__restrict__ pf, const R *__restrict__ A,
                                                             float *__restrict__ verts)
 {
-    __shared__ float s_pf[VF][NPF];
-    __shared__ float s_A[VF][NJ * 12];
-    __shared__ float s_beta[VF][16];
-    __shared__ float s_p[VF][3 * VB];
+    using M = mathx<R>;
+    __shared__ R s_pf[VF][NPF];
+    __shared__ R s_A[VF][NJ * 12];
+    __shared__ R s_beta[VF][16];
+    __shared__ R s_p[VF][3 * VB];
     const int b0 = blockIdx.y * VF, tid = threadIdx.x;
     for (int i = tid; i < VF * NPF; i += 3 * VB) {
         const int f = i / NPF, k = i - f * NPF;
-        s_pf[f][k] = b0 + f < bs ? pf[(size_t)(b0 + f) * NPF + k] : 0.f;
+        s_pf[f][k] = b0 + f < bs ? pf[(size_t)(b0 + f) * NPF + k] : (R)0;
     }
     for (int i = tid; i < VF * NJ * 12; i += 3 * VB) {
         const int f = i / (NJ * 12), k = i - f * NJ * 12;
-        s_A[f][k] = b0 + f < bs ? A[(size_t)(b0 + f) * NJ * 12 + k] : 0.f;
+        s_A[f][k] = b0 + f < bs ? A[(size_t)(b0 + f) * NJ * 12 + k] : (R)0;
     }
     if (tid < VF * 16) {
         const int f = tid >> 4, k = tid & 15;
-        s_beta[f][k] = (b0 + f < bs && k < nb) ? theta[(size_t)(b0 + f) * (75 + nb) + 75 + k] : 0.f;
+        s_beta[f][k] = (b0 + f < bs && k < nb) ? (R)theta[(size_t)(b0 + f) * (75 + nb) + 75 + k] : (R)0;
     }
     __syncthreads();
     const size_t row = (size_t)nv * 3;
     const int e = blockIdx.x * 3 * VB + tid;
     const bool ok = e < nv * 3;
-    float p[VF];
+    R p[VF];
     if (ok) {
-        const float vt = v_template[e];
+        const R vt = v_template[e];
 #pragma unroll
         for (int f = 0; f < VF; ++f) p[f] = vt;
         for (int k = 0; k < nb; ++k) {
-            const float sd = shapedirs[k * row + e];
+            const R sd = shapedirs[k * row + e];
 #pragma unroll
-            for (int f = 0; f < VF; ++f) p[f] = fmaf(s_beta[f][k], sd, p[f]);
+            for (int f = 0; f < VF; ++f) p[f] = M::fma_(s_beta[f][k], sd, p[f]);
         }
         // 207 = 9 x 23: 23 independent loads in flight per lane (the kernel runs at ~3 waves per CU: latency-bound)
         for (int k0 = 0; k0 < NPF; k0 += 23) {
@@ -147,7 +172,7 @@ __global__ __launch_bounds__(3 * VB) void smpl_verts_kernel(const float *__restr
 #pragma unroll
             for (int j = 0; j < 23; ++j)
 #pragma unroll
-                for (int f = 0; f < VF; ++f) p[f] = fmaf(s_pf[f][k0 + j], pd[j], p[f]);
+                for (int f = 0; f < VF; ++f) p[f] = M::fma_(s_pf[f][k0 + j], (R)pd[j], p[f]);
         }
 #pragma unroll
         for (int f = 0; f < VF; ++f) s_p[f][tid] = p[f];
@@ -155,37 +180,38 @@ __global__ __launch_bounds__(3 * VB) void smpl_verts_kernel(const float *__restr
     __syncthreads();
     if (!ok) return;
     const int v = e / 3, c = e - v * 3, vl = (tid / 3) * 3;
-    float T[VF][4];
+    R T[VF][4];
 #pragma unroll
     for (int f = 0; f < VF; ++f)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) T[f][q] = 0.f;
+        for (int q = 0; q < 4; ++q) T[f][q] = (R)0;
     const float *w = weights + (size_t)v * NJ;
 #pragma unroll 4
     for (int j = 0; j < NJ; ++j) {
-        const float wj = w[j];
+        const R wj = w[j];
 #pragma unroll
         for (int f = 0; f < VF; ++f)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) T[f][q] = fmaf(wj, s_A[f][j * 12 + c * 4 + q], T[f][q]);
+            for (int q = 0; q < 4; ++q) T[f][q] = M::fma_(wj, s_A[f][j * 12 + c * 4 + q], T[f][q]);
     }
 #pragma unroll
     for (int f = 0; f < VF; ++f)
         if (b0 + f < bs)
             verts[((size_t)(b0 + f) * nv + v) * 3 + c] =
-                fmaf(T[f][2], s_p[f][vl + 2], fmaf(T[f][1], s_p[f][vl + 1], T[f][0] * s_p[f][vl])) + T[f][3];
+                (float)(M::fma_(T[f][2], s_p[f][vl + 2], M::fma_(T[f][1], s_p[f][vl + 1], T[f][0] * s_p[f][vl])) + T[f][3]);
 }
 
 // grid (n_out_joints, bs): joints[b][j][:] = sum_v verts[b][v][:] * joint_regressor[v][j]
+template <typename R>
 __global__ __launch_bounds__(256) void smpl_joints_kernel(const float *__restrict__ verts,
                                                           const float *__restrict__ jreg, int nv, int nj,
                                                           float *__restrict__ joints)
 {
-    __shared__ float red[3][4];
+    __shared__ R red[3][4];
     const int j = blockIdx.x, b = blockIdx.y;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    R a0 = 0, a1 = 0, a2 = 0;
     for (int v = threadIdx.x; v < nv; v += 256) {
-        const float w = jreg[(size_t)v * nj + j];
+        const R w = jreg[(size_t)v * nj + j];
         const float *p = verts + ((size_t)b * nv + v) * 3;
         a0 += w * p[0];
         a1 += w * p[1];
@@ -205,7 +231,7 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(const float *__restric
     __syncthreads();
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;
-        joints[((size_t)b * nj + j) * 3 + c] = red[c][0] + red[c][1] + red[c][2] + red[c][3];
+        joints[((size_t)b * nj + j) * 3 + c] = (float)(red[c][0] + red[c][1] + red[c][2] + red[c][3]);
     }
 }
 
@@ -274,13 +300,16 @@ int lwg_smpl_project_joints(const float *j3d, const float *cam, int bs, int num_
     return LWG_OK;
 }
 
-size_t lwg_smpl_workspace_bytes(int bs) { return bs > 0 ? (size_t)bs * (NPF + NJ * 12) * sizeof(float) : 0; }
+size_t lwg_smpl_workspace_bytes(int bs) { return bs > 0 ? (size_t)bs * (NPF + NJ * 12) * sizeof(double) : 0; }
 
-int lwg_smpl_forward(const float *theta, int bs, int num_betas, int nv, int num_out_joints, const float *v_template,
-                     const float *shapedirs, const float *posedirs, const float *J_template,
-                     const float *J_shapedirs, const int32_t *parents, const float *weights,
-                     const float *joint_regressor, float *verts, float *joints, float *Rs, void *workspace,
-                     size_t workspace_bytes, lwg_stream_t stream)
+}  // extern "C"
+
+namespace {
+template <typename R, typename JT>
+int smpl_forward_impl(const float *theta, int bs, int num_betas, int nv, int num_out_joints, const float *v_template,
+                      const float *shapedirs, const float *posedirs, const JT *J_template, const JT *J_shapedirs,
+                      const int32_t *parents, const float *weights, const float *joint_regressor, float *verts, float *joints,
+                      float *Rs, void *workspace, size_t workspace_bytes, lwg_stream_t stream)
 {
     LWG_REQUIRE(theta && v_template && shapedirs && posedirs && J_template && J_shapedirs && parents && weights && verts,
                 "smpl_forward: NULL argument");
@@ -290,18 +319,43 @@ int lwg_smpl_forward(const float *theta, int bs, int num_betas, int nv, int num_
     if (!workspace || workspace_bytes < lwg_smpl_workspace_bytes(bs))
         LWG_FAIL(LWG_ERR_WORKSPACE, "smpl_forward: workspace needs %zu bytes", lwg_smpl_workspace_bytes(bs));
     hipStream_t st = as_stream(stream);
-    float *pf = static_cast<float *>(workspace);
-    float *A = pf + (size_t)bs * NPF;
-    smpl_pose_kernel<<<bs, 64, 0, st>>>(theta, num_betas, J_template, J_shapedirs, parents, pf, A, Rs);
+    R *pf = static_cast<R *>(workspace);
+    R *A = pf + (size_t)bs * NPF;
+    smpl_pose_kernel<R, JT><<<bs, 64, 0, st>>>(theta, num_betas, J_template, J_shapedirs, parents, pf, A, Rs);
     LWG_LAUNCH_CHECK("smpl_pose_kernel");
-    smpl_verts_kernel<<<dim3(ceil_div((long)nv * 3, 3 * VB), ceil_div(bs, VF)), 3 * VB, 0, st>>>(
+    smpl_verts_kernel<R><<<dim3(ceil_div((long)nv * 3, 3 * VB), ceil_div(bs, VF)), 3 * VB, 0, st>>>(
         theta, num_betas, nv, bs, v_template, shapedirs, posedirs, weights, pf, A, verts);
     LWG_LAUNCH_CHECK("smpl_verts_kernel");
     if (joints) {
-        smpl_joints_kernel<<<dim3(num_out_joints, bs), 256, 0, st>>>(verts, joint_regressor, nv, num_out_joints, joints);
+        smpl_joints_kernel<R><<<dim3(num_out_joints, bs), 256, 0, st>>>(verts, joint_regressor, nv, num_out_joints, joints);
         LWG_LAUNCH_CHECK("smpl_joints_kernel");
     }
     return LWG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int lwg_smpl_forward(const float *theta, int bs, int num_betas, int nv, int num_out_joints, const float *v_template,
+                     const float *shapedirs, const float *posedirs, const float *J_template,
+                     const float *J_shapedirs, const int32_t *parents, const float *weights,
+                     const float *joint_regressor, float *verts, float *joints, float *Rs, void *workspace,
+                     size_t workspace_bytes, lwg_stream_t stream)
+{
+    return smpl_forward_impl<float, float>(theta, bs, num_betas, nv, num_out_joints, v_template, shapedirs, posedirs, J_template,
+                                           J_shapedirs, parents, weights, joint_regressor, verts, joints, Rs, workspace,
+                                           workspace_bytes, stream);
+}
+
+int lwg_smpl_forward_f64(const float *theta, int bs, int num_betas, int nv, int num_out_joints, const float *v_template,
+                         const float *shapedirs, const float *posedirs, const double *J_template,
+                         const double *J_shapedirs, const int32_t *parents, const float *weights,
+                         const float *joint_regressor, float *verts, float *joints, float *Rs, void *workspace,
+                         size_t workspace_bytes, lwg_stream_t stream)
+{
+    return smpl_forward_impl<double, double>(theta, bs, num_betas, nv, num_out_joints, v_template, shapedirs, posedirs, J_template,
+                                             J_shapedirs, parents, weights, joint_regressor, verts, joints, Rs, workspace,
+                                             workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -84,6 +84,13 @@ def batch_orth_proj_idrot(X, camera):
 
 
 class SMPL(nn.Module):
+    # arithmetic of the device path: "fp32" = the reference's own (fp32 tensors, one rounding per multiply-add);
+    # "compensated" = every intermediate in fp64, ONE rounding to fp32 at the end (smpl.hip, lwg_smpl_forward_f64).  The
+    # compensated vertices are the correctly rounded values of the function the reference's code defines; an fp32 evaluation
+    # -- this one or the reference's -- sits ~1e-6 away from them by summation order alone, and the rasteriser amplifies
+    # that to 1e-3 in the flow field.  Same speed (latency-bound kernels).  env LWG_SMPL_PRECISION.
+    precision = "compensated"
+
     def __init__(self, pkl_path=None, rotate=False, params=None):
         super().__init__()
         if rotate:
@@ -117,6 +124,13 @@ class SMPL(nn.Module):
         self.register_buffer('J_template', f32(jreg @ vt))                         # (24, 3)
         self.register_buffer('J_shapedirs', f32(np.einsum('jv,vck->kjc', jreg, sdirs).reshape(self.num_betas, -1)))
         self.register_buffer('parents_t', torch.from_numpy(self.parents.astype(np.int32)))
+        # "compensated" mode (lwg_smpl_forward_f64): the same folding, in fp64, of the fp32 tensors the model actually holds
+        jreg32 = self.J_regressor.double().numpy().T                               # (24, nv), the fp32 values
+        self.register_buffer('J_template_d', torch.from_numpy(jreg32 @ self.v_template.double().numpy()).contiguous())
+        sd32 = self.shapedirs.double().numpy().reshape(self.num_betas, -1, 3)      # (nb, nv, 3)
+        self.register_buffer('J_shapedirs_d', torch.from_numpy(
+            np.einsum('jv,kvc->kjc', jreg32, sd32).reshape(self.num_betas, -1)).contiguous())
+        self.precision = os.environ.get("LWG_SMPL_PRECISION", self.precision)
         self._ws = None
 
     def forward(self, beta, theta, get_skin=False):
@@ -148,9 +162,13 @@ class SMPL(nn.Module):
         need = lib.lwg_smpl_workspace_bytes(n)
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        _lib.check(lib.lwg_smpl_forward(
+        if self.precision not in ("fp32", "compensated"):
+            raise ValueError("SMPL.precision must be 'fp32' or 'compensated', not %r" % (self.precision,))
+        f64 = self.precision == "compensated"
+        _lib.check((lib.lwg_smpl_forward_f64 if f64 else lib.lwg_smpl_forward)(
             _lib.ptr(th), n, self.num_betas, nv, joints.shape[1], _lib.ptr(self.v_template), _lib.ptr(self.shapedirs),
-            _lib.ptr(self.posedirs), _lib.ptr(self.J_template), _lib.ptr(self.J_shapedirs), _lib.ptr(self.parents_t),
+            _lib.ptr(self.posedirs), _lib.ptr(self.J_template_d if f64 else self.J_template),
+            _lib.ptr(self.J_shapedirs_d if f64 else self.J_shapedirs), _lib.ptr(self.parents_t),
             _lib.ptr(self.weights), _lib.ptr(self.joint_regressor), _lib.ptr(verts), _lib.ptr(joints), _lib.ptr(Rs),
             _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()))
         return verts, joints, Rs

@@ -128,6 +128,16 @@ LWG_API int lwg_smpl_forward(const float *theta, int bs, int num_betas, int nv, 
                              const float *J_template, const float *J_shapedirs, const int32_t *parents,
                              const float *weights, const float *joint_regressor, float *verts, float *joints,
                              float *Rs, void *workspace, size_t workspace_bytes, lwg_stream_t stream);
+/* The same function with every intermediate in fp64 and ONE rounding to fp32 at the end ("compensated" mode of
+ * networks/batch_smpl.py:285-375): the fp32 model tensors are read as they are, J_template / J_shapedirs are the fp64
+ * products of the fp32 regressor with the fp32 template / shape directions.  The result is the correctly rounded value of
+ * the function the reference's code defines; any fp32 evaluation of it (the reference's own included) differs from that by
+ * its ~1e-6 of summation noise, which the rasteriser downstream amplifies. */
+LWG_API int lwg_smpl_forward_f64(const float *theta, int bs, int num_betas, int nv, int num_out_joints,
+                                 const float *v_template, const float *shapedirs, const float *posedirs,
+                                 const double *J_template, const double *J_shapedirs, const int32_t *parents,
+                                 const float *weights, const float *joint_regressor, float *verts, float *joints,
+                                 float *Rs, void *workspace, size_t workspace_bytes, lwg_stream_t stream);
 
 /* NCHW (n,C,H,W) -> NHWC with the channel count padded to cpad (zeros), and back (first C channels). */
 LWG_API int lwg_pack_nhwc(const float *x_nchw, int n, int C, int H, int W, int cpad, float *out_nhwc,

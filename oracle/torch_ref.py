@@ -646,3 +646,138 @@ def generator_train_steps(gsd, dsd, batches, opt=None, align_corners=False):
         optim.step()
         hist.append({k: float(v.detach()) for k, v in terms.items()})
     return hist, first, {k: v.detach().clone() for k, v in params.items()}
+
+
+# --------------------------------------------------------------------------- Imitator host methods (a1, a11, H9, H10)
+def swap_smpl(src_cam, src_shape, tgt_smpl, first_cam, cam_strategy="smooth"):
+    """Imitator.swap_smpl (models/imitator.py:216-234) for one frame (1,85): the camera policy."""
+    tgt_cam, pose = tgt_smpl[:, 0:3].contiguous(), tgt_smpl[:, 3:75].contiguous()
+    if cam_strategy == "smooth":
+        cam = src_cam.clone()
+        cam[:, 1:] += tgt_cam[:, 1:] - first_cam[:, 1:]
+    elif cam_strategy == "source":
+        cam = src_cam
+    else:
+        cam = tgt_cam
+    return torch.cat([cam, pose, src_shape], dim=1)
+
+
+def get_vis_f2pts(f2pts, fims):
+    """SMPLRenderer.get_vis_f2pts (utils/nmr.py:506-546, --only_vis, hazard H10): faces that are not among
+    `fim.unique()[1:]` become -2 (the first unique value is dropped unconditionally: it is -1 whenever a
+    background pixel exists)."""
+    out = torch.zeros_like(f2pts) - 2.0
+    for i in range(f2pts.shape[0]):
+        ids = fims[i].unique()[1:].long()
+        out[i, ids] = f2pts[i, ids]
+    return out
+
+
+def imitator_personalize(sd, img, src_info, faces_idx, map_fn, only_vis=False, bg_sd=None, bg_ks=13, ft_ks=3, image_size=256):
+    """Imitator.personalize (models/imitator.py:82-155) after `hmr.get_details` (src_info: cam, verts, shape, ...):
+    bg_sd None = --bg_model ORIGINAL (the generator's BGNet on the eroded-mask image, :126-132), else the InpaintSANet
+    state dict (:124-125).  Returns the reference's src_info entries (feats as enc/res)."""
+    f2v, fim, wim = render_fim_wim(src_info["cam"], src_info["verts"], faces_idx, image_size)
+    cond = encode_fim(fim, map_fn)
+    p2v = source_p2verts(f2v)            # H9: the reference negates y through a view of f2verts
+    f2v = f2v.clone()
+    f2v[:, :, :, 1] *= -1
+    if only_vis:
+        p2v = get_vis_f2pts(p2v, fim)
+    bg_mask = morph(cond[:, -1:], bg_ks, "erode")
+    if bg_sd is not None:
+        bg = inpaint_forward(bg_sd, img, 1 - bg_mask)[1]
+    else:
+        bg = bgnet_forward(sd, torch.cat([img * bg_mask, bg_mask], dim=1))
+    ft = 1 - morph(cond[:, -1:], ft_ks, "erode")
+    enc, res = encode_src(sd, torch.cat([img * ft, cond], 1))
+    out = dict(src_info)
+    out.update(fim=fim, wim=wim, cond=cond, f2verts=f2v, p2verts=p2v, img=img, bg=bg, enc=enc, res=res)
+    return out
+
+
+def imitator_inference_by_smpls(sd, src, get_details, tgt_smpls, faces_idx, map_fn, cam_strategy="smooth", front_map_fn=None,
+                                image_size=256, align_corners=False):
+    """Imitator.inference_by_smpls (models/imitator.py:191-214): per frame t, transfer_params_by_smpl (:236-268; first_cam
+    is set from the frame at t == 0 under 'smooth') then forward (:326-336) with the optional warp_front (:338-342,
+    front_map_fn given = --front_warp).  `src` = imitator_personalize(...).  Returns a list of per-frame dicts."""
+    first_cam, frames = None, []
+    for t in range(tgt_smpls.shape[0]):
+        tgt = tgt_smpls[t:t + 1]
+        if t == 0 and cam_strategy == "smooth":
+            first_cam = tgt[:, 0:3].clone()
+        info = get_details(swap_smpl(src["cam"], src["shape"], tgt, first_cam, cam_strategy))
+        fr = transfer_frame(src["img"], src["p2verts"], info["cam"], info["verts"], faces_idx, map_fn, image_size, align_corners)
+        pred, _, mask = imitator_forward(sd, src["enc"], src["res"], src["bg"], fr["tsf_inputs"], fr["T"], align_corners)
+        if front_map_fn is not None:
+            front = encode_fim(fr["fim"], front_map_fn)
+            pred = (1 - front) * pred + fr["tsf_img"] * front * (1 - mask)
+        info = dict(info)
+        info.update(fim=fr["fim"], wim=fr["wim"], cond=fr["cond"], tsf_img=fr["tsf_img"], T=fr["T"], preds=pred,
+                    first_cam=None if first_cam is None else first_cam.clone())
+        frames.append(info)
+    return frames
+
+
+# --------------------------------------------------------------------------- SMPL (a2), any float dtype
+def smpl_tensors(model, dtype=torch.float32):
+    """The fp32 tensors an SMPL module holds (the reference's buffer names, networks/batch_smpl.py:242-283), cast to `dtype`."""
+    names = ("v_template", "shapedirs", "J_regressor", "posedirs", "weights", "joint_regressor")
+    out = {n: getattr(model, n).detach().cpu().to(dtype) for n in names}
+    out["parents"] = np.asarray(model.parents)
+    return out
+
+
+def smpl_forward(sm, beta, theta):
+    """SMPL.forward (networks/batch_smpl.py:285-375; batch_rodrigues :64-101, batch_global_rigid_transformation :129-218
+    with rotate_base=False) in the dtype of `sm`'s tensors.  float32 = the reference's arithmetic; float64 on the same fp32
+    model values, rounded to fp32 afterwards, = the correctly rounded value of the function that code defines (what the
+    device's "compensated" SMPL mode computes).  -> (verts, joints, Rs)"""
+    dt = sm["v_template"].dtype
+    beta, theta = beta.to(dt), theta.to(dt)
+    n, nv = beta.shape[0], sm["v_template"].shape[0]
+    v_shaped = torch.matmul(beta, sm["shapedirs"]).view(-1, nv, 3) + sm["v_template"]
+    J = torch.stack([torch.matmul(v_shaped[:, :, k], sm["J_regressor"]) for k in range(3)], dim=2)
+    r3 = theta.reshape(-1, 3)
+    angle = torch.norm(r3 + 1e-8, p=2, dim=1, keepdim=True)
+    r = torch.div(r3, angle).unsqueeze(-1)
+    angle = angle.unsqueeze(-1)
+    cos, sin = torch.cos(angle), torch.sin(angle)
+    outer = torch.matmul(r, r.permute(0, 2, 1))
+    eyes = torch.eye(3, dtype=dt).unsqueeze(0).repeat(r3.shape[0], 1, 1)
+    rx, ry, rz = r[:, 0, 0], r[:, 1, 0], r[:, 2, 0]
+    zero = torch.zeros_like(rx)
+    skew = torch.stack([zero, -rz, ry, rz, zero, -rx, -ry, rx, zero], dim=1).view(-1, 3, 3)   # batch_skew, :19-60
+    Rs = (cos * eyes + (1 - cos) * outer + sin * skew).view(-1, 24, 3, 3)
+    pose_feature = (Rs[:, 1:] - torch.eye(3, dtype=dt)).view(-1, 207)
+    v_posed = torch.matmul(pose_feature, sm["posedirs"]).view(-1, nv, 3) + v_shaped
+
+    Js = J.unsqueeze(-1)
+
+    def make_A(R, t):
+        return torch.cat([F.pad(R, [0, 0, 0, 1, 0, 0]), torch.cat([t, torch.ones(n, 1, 1, dtype=dt)], dim=1)], dim=2)
+
+    results = [make_A(Rs[:, 0], Js[:, 0])]
+    for i in range(1, 24):
+        p = int(sm["parents"][i])
+        results.append(torch.matmul(results[p], make_A(Rs[:, i], Js[:, i] - Js[:, p])))
+    results = torch.stack(results, dim=1)
+    Js_w0 = torch.cat([Js, torch.zeros(n, 24, 1, 1, dtype=dt)], dim=2)
+    A = results - F.pad(torch.matmul(results, Js_w0), [3, 0, 0, 0, 0, 0, 0, 0])
+
+    W = sm["weights"].repeat(n, 1).view(n, -1, 24)
+    T = torch.matmul(W, A.view(n, 24, 16)).view(n, -1, 4, 4)
+    v_homo = torch.matmul(T, torch.cat([v_posed, torch.ones(n, nv, 1, dtype=dt)], dim=2).unsqueeze(-1))
+    verts = v_homo[:, :, :3, 0]
+    joints = torch.stack([torch.matmul(verts[:, :, k], sm["joint_regressor"]) for k in range(3)], dim=2)
+    return verts, joints, Rs
+
+
+def get_details(sm, theta):
+    """HumanModelRecovery.get_details (networks/hmr.py:302-330): fp32 dictionary whatever dtype `sm` computes in (the SMPL
+    stage's results are rounded to fp32 once, then the keypoint projection of batch_smpl.py:221-234 runs in fp32)."""
+    theta = theta.float()
+    cam, pose, shape = theta[:, 0:3].contiguous(), theta[:, 3:75].contiguous(), theta[:, 75:].contiguous()
+    verts, j3d, _ = smpl_forward(sm, shape, pose)
+    verts, j3d = verts.float(), j3d.float()
+    return dict(theta=theta, cam=cam, pose=pose, shape=shape, verts=verts, j3d=j3d, j2d=cam[:, None, 0:1] * (j3d[:, :, :2] + cam[:, None, 1:]))

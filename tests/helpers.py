@@ -140,3 +140,39 @@ def task_scene():
                 cam_b=synthetic.cams(1, seed=101), verts_b=synthetic.motion_verts(rest, 200)[None].copy(),
                 img_b=synthetic.smooth_image(77),
                 views=[((0.0, 0.6, 0.0), (0.0, 0.0, 0.0), False), ((0.2, -1.1, 0.1), (0.02, 0.0, 0.0), True)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tests/golden/imitator_golden.npz: the reference's own Imitator methods run unbound (make_golden.py::make_imitator)
+IMITATOR_VARIANTS = {
+    # name: image size, --only_vis, --bg_model (ORIGINAL = the generator's BGNet, else InpaintSANet), --front_warp, --cam_strategy
+    "main": dict(size=256, only_vis=False, bg_model="ORIGINAL", front_warp=False, cam_strategy="smooth"),
+    "vis_inpaint_front_source": dict(size=128, only_vis=True, bg_model="deepfillv2", front_warp=True, cam_strategy="source"),
+    "vis_bgnet_front_copy": dict(size=128, only_vis=True, bg_model="ORIGINAL", front_warp=True, cam_strategy="copy"),
+    "inpaint_smooth": dict(size=128, only_vis=False, bg_model="deepfillv2", front_warp=False, cam_strategy="smooth"),
+}
+
+
+def imitator_scene(size):
+    """Inputs of imitator_golden.npz (numpy) at one image size: synthetic SMPL model + mesh tables, one source (rest pose,
+    own camera and betas), four target SMPL vectors far apart in the synthetic motion, seeded images."""
+    from impersonator_amd import demo
+    from impersonator_amd.networks.batch_smpl import synthetic_smpl_params
+    rest, faces = synthetic.body_mesh()
+    src_smpl = demo.synthetic_smpls(1, seed=1)[0]
+    src_smpl[3:75] = 0.0
+    return dict(rest=rest, faces=faces, map_fn=synthetic.uv_seg_map_fn(rest, faces), front_map_fn=synthetic.front_map_fn(rest, faces),
+                smpl_params=synthetic_smpl_params(0), src_smpl=src_smpl, tgt_smpls=demo.synthetic_smpls(64, seed=0)[::16].copy(),
+                src_img=synthetic.smooth_image(11, (1, 3, size, size)), size=size)
+
+
+def inpaintor_state_dict(seed=1):
+    """Seeded InpaintSANet(c_dim=4) weights (numpy), keyed like the reference's state_dict."""
+    from impersonator_amd.networks.inpaintor import InpaintSANet
+    shapes = [(k, tuple(v.shape)) for k, v in InpaintSANet(c_dim=4).state_dict().items()]
+    return synthetic.random_inpaintor_state_dict(shapes, seed)
+
+
+def tensor_stat(x):
+    x = torch.as_tensor(x).double()
+    return np.array([x.mean().item(), x.abs().mean().item(), (x * x).mean().item()])

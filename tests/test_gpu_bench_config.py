@@ -78,46 +78,61 @@ def test_batch8_bench_workload_matches_oracle(bench_imitator, precision):
     print("bench workload, %s: L-inf over 32 frames = %.3g" % (precision, float(err.max())))
 
 
-def test_theta_to_image_chain_with_the_oracles_own_smpl(bench_imitator):
+@pytest.mark.parametrize("smpl_precision", ["compensated", "fp32"])
+def test_theta_to_image_chain_with_the_oracles_own_smpl(bench_imitator, smpl_precision):
     """The other parity tests restart the oracle from the device's posed vertices.  Here the oracle runs its OWN SMPL
-    (the reference's tensor-op formulation on the CPU, pinned in tests/test_host_logic.py) from the same theta, so the
-    whole chain theta -> image is compared.  The two SMPL evaluations agree to ~1e-6; the reference's barycentric
-    formula w = face_inv * (xi, yi, 1) (rasterize_cuda_kernel.cu:139-141) amplifies that by |face_inv| ~ 1e3..1e4, so
-    the flow and the image legitimately move by more than the 1e-3 same-input bound, and a pixel centre within 1e-6 of
-    a face edge may change owner.  Stated bounds: at most 2 face-index pixels per frame differ; on the frames whose
-    face-index maps agree entirely the image stays within 1e-2."""
-    from impersonator_amd.networks.batch_smpl import HumanModelRecovery, synthetic_smpl_params
+    (oracle/torch_ref.py::smpl_forward == the reference's SMPL.forward, tests/test_oracle_vs_reference.py) from the same
+    theta, so the whole chain theta -> image is compared -- the north star's "identical SMPL inputs".
+
+    `compensated` (the default): device SMPL with fp64 intermediates and one rounding, against the oracle's fp64 SMPL rounded
+    to fp32 -- both are the correctly rounded vertices, so the face-index maps must be IDENTICAL and every frame within the
+    1e-3 bound.  `fp32`: two fp32 evaluations in different summation orders agree to ~1e-7..1e-6 only, which the
+    barycentric weights w = face_inv * (xi, yi, 1) (rasterize_cuda_kernel.cu:139-141, |face_inv| ~ 1e3..1e4) amplify; the
+    reference does that to itself (profiles/r04_theta_chain_reference_self.md: its own SMPL with 1 thread vs 8, or 1 frame
+    per call vs 8: up to 2 face-index pixels and 2.7e-3 on the image).  Bounds there = twice the measured values."""
+    from impersonator_amd.networks.batch_smpl import SMPL, synthetic_smpl_params
     imitator, src_img, bg_img, smpls = bench_imitator
     imitator.generator.precision = "bf16x3"
+    before = imitator.hmr.smpl.precision
     n = 16
-    chunks = [(smpls[s:s + BATCH], 8 + s) for s in range(0, n, BATCH)]
-    got_pred, got_fim = [], []
-    for chunk, t in chunks:
-        x = imitator.transfer_params_by_smpl(chunk, "smooth", t=t)
-        got_fim.append(imitator.tsf_info["fim"].cpu())
-        got_pred.append(imitator.forward(x, imitator.tsf_info["T"]).cpu())
-    got_pred, got_fim = torch.cat(got_pred), torch.cat(got_fim)
+    try:
+        imitator.hmr.smpl.precision = smpl_precision
+        src_smpl_np = demo.synthetic_smpls(1, seed=1)[0]
+        src_smpl_np[3:75] = 0
+        imitator.personalize(src_img, src_smpl=src_smpl_np, bg_img=bg_img)     # the source's vertices in the same arithmetic
+        chunks = [(smpls[s:s + BATCH], 8 + s) for s in range(0, n, BATCH)]
+        got_pred, got_fim = [], []
+        for chunk, t in chunks:
+            x = imitator.transfer_params_by_smpl(chunk, "smooth", t=t)
+            got_fim.append(imitator.tsf_info["fim"].cpu())
+            got_pred.append(imitator.forward(x, imitator.tsf_info["T"]).cpu())
+        got_pred, got_fim = torch.cat(got_pred), torch.cat(got_fim)
+        src_fim = imitator.src_info["fim"].cpu()
+    finally:
+        imitator.hmr.smpl.precision = before
+        imitator.personalize(src_img, src_smpl=src_smpl_np, bg_img=bg_img)
 
-    hmr = HumanModelRecovery(smpl_params=synthetic_smpl_params(0))          # CPU tensors -> the tensor-op formulation
+    sm = torch_ref.smpl_tensors(SMPL(params=synthetic_smpl_params(0)), torch.float64 if smpl_precision == "compensated" else torch.float32)
     sd = {k: v.detach().cpu() for k, v in imitator.generator.state_dict().items()}
     faces_t, map_fn = imitator.render.faces.cpu(), imitator.render.map_fn.cpu()
     src_t, bg_t = torch.from_numpy(src_img)[None], torch.from_numpy(bg_img)[None]
     all_smpls = torch.from_numpy(demo.synthetic_smpls(1024, seed=0))
-    src_smpl = torch.from_numpy(demo.synthetic_smpls(1, seed=1))
-    src_smpl[:, 3:75] = 0
     with torch.no_grad():
-        si = hmr.get_details(src_smpl)
+        si = torch_ref.get_details(sm, torch.from_numpy(src_smpl_np)[None])
         src = torch_ref.personalize(sd, src_t, si["cam"], si["verts"], faces_t, map_fn, ft_ks=imitator._opt.ft_ks)
         chunk = all_smpls[8:8 + n]
-        cam = si["cam"].expand(n, -1).clone()
-        cam[:, 1:] += chunk[:, 1:3] - all_smpls[0:1, 1:3]
-        info = hmr.get_details(torch.cat([cam, chunk[:, 3:75], si["shape"].expand(n, -1)], 1))
+        theta = torch.cat([torch_ref.swap_smpl(si["cam"], si["shape"], chunk[i:i + 1], all_smpls[0:1, 0:3], "smooth") for i in range(n)])
+        info = torch_ref.get_details(sm, theta)
         fr, ref = torch_ref.imitator_frames(sd, src, src_t, bg_t, info["cam"], info["verts"], faces_t, map_fn)
     mism = (got_fim != fr["fim"]).flatten(1).sum(1)
-    assert int(mism.max()) <= 2 and int(mism.sum()) <= n, "face-index pixels differing per frame: %s" % mism.tolist()
-    agree = mism == 0
-    assert int(agree.sum()) >= n // 2
     err = (got_pred - ref).abs().flatten(1).max(1).values
-    assert float(err[agree].max()) <= 1e-2, "theta chain, frames with identical face-index maps: L-inf %g" % float(err[agree].max())
-    print("theta chain: %d face-index pixels differ over %d frames; L-inf on the %d agreeing frames %.3g, all frames %.3g"
-          % (int(mism.sum()), n, int(agree.sum()), float(err[agree].max()), float(err.max())))
+    agree = mism == 0
+    print("theta chain, %s SMPL: %d face-index pixels differ over %d frames (source: %d); L-inf on the %d agreeing frames %.3g, all frames %.3g"
+          % (smpl_precision, int(mism.sum()), n, int((src_fim != src["fim"]).sum()), int(agree.sum()), float(err[agree].max()), float(err.max())))
+    if smpl_precision == "compensated":
+        assert torch.equal(src_fim, src["fim"]) and int(mism.sum()) == 0, "face-index pixels differing per frame: %s" % mism.tolist()
+        assert float(err.max()) <= 1e-3, "theta chain, compensated SMPL: L-inf %g" % float(err.max())
+    else:
+        assert int(mism.max()) <= 2 and int(mism.sum()) <= 8, "face-index pixels differing per frame: %s" % mism.tolist()
+        assert int(agree.sum()) >= n // 2
+        assert float(err[agree].max()) <= 6.5e-3, "theta chain, fp32 SMPL, frames with identical face-index maps: L-inf %g" % float(err[agree].max())

@@ -36,19 +36,33 @@ def test_morph_matches_reference_restatement():
 
 
 def test_swap_smpl_camera_policies():
-    # models/imitator.py:216-234
+    """Imitator.swap_smpl against the reference's own method (models/imitator.py:216-234): run unbound where /root/reference
+    exists, and against the SMPL vectors that method produced inside the reference's inference_by_smpls
+    (tests/golden/imitator_golden.npz, make_golden.py::make_imitator) everywhere."""
     from impersonator_amd.models.imitator import Imitator
-    self = types.SimpleNamespace(first_cam=torch.tensor([[1.0, 0.1, 0.2]]))
+    from oracle import reference_loader
+    from tests import helpers
+    tgt = torch.from_numpy(demo.synthetic_smpls(4, 0))
     src_cam = torch.tensor([[0.9, 0.0, 0.05]])
     shape = torch.arange(10).float()[None]
-    tgt = torch.from_numpy(demo.synthetic_smpls(4, 0))
-    out = Imitator.swap_smpl(self, src_cam, shape, tgt, "smooth")
-    assert out.shape == (4, 85)
-    assert torch.allclose(out[:, 0], src_cam[:, 0].expand(4))
-    assert torch.allclose(out[:, 1:3], src_cam[:, 1:] + tgt[:, 1:3] - self.first_cam[:, 1:])
-    assert torch.equal(out[:, 3:75], tgt[:, 3:75]) and torch.equal(out[:, 75:], shape.expand(4, -1))
-    assert torch.equal(Imitator.swap_smpl(self, src_cam, shape, tgt, "source")[:, :3], src_cam.expand(4, -1))
-    assert torch.equal(Imitator.swap_smpl(self, src_cam, shape, tgt, "copy")[:, :3], tgt[:, :3])
+    if reference_loader.available():
+        ref = reference_loader.load().imitator.Imitator
+        for strategy in ("smooth", "source", "copy"):
+            me = types.SimpleNamespace(first_cam=torch.tensor([[1.0, 0.1, 0.2]]))
+            # the reference takes one frame per call (its loop, imitator.py:166,196); this build's method takes a batch
+            want = torch.cat([ref.swap_smpl(me, src_cam, shape, tgt[i:i + 1], strategy) for i in range(4)])
+            assert torch.equal(Imitator.swap_smpl(me, src_cam, shape, tgt, strategy), want), strategy
+    g = helpers.golden("imitator_golden.npz")
+    for name, v in helpers.IMITATOR_VARIANTS.items():
+        k = name + "/"
+        sc = helpers.imitator_scene(64)        # the SMPL vectors do not depend on the image size
+        src = torch.from_numpy(g[k + "src_theta"])
+        fc = g[k + "first_cam"][-1]
+        me = types.SimpleNamespace(first_cam=None if np.isnan(fc).all() else torch.from_numpy(fc)[None])
+        out = Imitator.swap_smpl(me, src[:, :3], src[:, 75:], torch.from_numpy(sc["tgt_smpls"]), v["cam_strategy"])
+        assert np.array_equal(out.numpy(), g[k + "theta"]), name
+        if v["cam_strategy"] == "smooth":
+            assert np.array_equal(fc, sc["tgt_smpls"][0, :3])      # first_cam = the frame at t == 0 (imitator.py:243-244)
 
 
 def test_options_keep_reference_flag_names():

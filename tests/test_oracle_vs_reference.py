@@ -313,3 +313,30 @@ def test_body_recovery_flow_restatement_matches_reference(ref):
             continue
         assert a.shape == b.shape and a.dtype == b.dtype, i
         assert torch.equal(a, b), "output %d differs by %g" % (i, float((a.float() - b.float()).abs().max()))
+
+
+def test_smpl_restatement_matches_reference_in_fp32_and_fp64(ref):
+    """oracle/torch_ref.py::smpl_forward / get_details == the reference's SMPL.forward (networks/batch_smpl.py:285-375) and
+    HumanModelRecovery.get_details (networks/hmr.py:302-330) BIT FOR BIT, in fp32 (the reference's arithmetic) and with the
+    reference's own code running on float64 tensors (the `compensated` mode's oracle)."""
+    import types
+    from impersonator_amd import demo
+    from impersonator_amd.networks.batch_smpl import SMPL, synthetic_smpl_params
+    m = SMPL(params=synthetic_smpl_params(0))
+    th = torch.from_numpy(demo.synthetic_smpls(6, 0))
+    th[0, 3:75] = 0
+    for dt in (torch.float32, torch.float64):
+        stub = types.SimpleNamespace(shapedirs=m.shapedirs.to(dt), v_template=m.v_template.to(dt), size=m.size,
+                                     J_regressor=m.J_regressor.to(dt), posedirs=m.posedirs.to(dt), parents=m.parents,
+                                     weights=m.weights.to(dt), joint_regressor=m.joint_regressor.to(dt), rotate=False)
+        rv, rj, rR = ref.batch_smpl.SMPL.forward(stub, th[:, 75:].contiguous().to(dt), th[:, 3:75].contiguous().to(dt), get_skin=True)
+        sm = torch_ref.smpl_tensors(m, dt)
+        ov, oj, oR = torch_ref.smpl_forward(sm, th[:, 75:], th[:, 3:75])
+        assert rv.dtype == dt and torch.equal(rv, ov) and torch.equal(rj, oj) and torch.equal(rR, oR), dt
+    hmr = types.SimpleNamespace(smpl=lambda beta, theta, get_skin=False: ref.batch_smpl.SMPL.forward(stub32, beta, theta, get_skin=get_skin))
+    stub32 = types.SimpleNamespace(shapedirs=m.shapedirs, v_template=m.v_template, size=m.size, J_regressor=m.J_regressor,
+                                   posedirs=m.posedirs, parents=m.parents, weights=m.weights, joint_regressor=m.joint_regressor, rotate=False)
+    want = ref.networks.HumanModelRecovery.get_details(hmr, th)
+    got = torch_ref.get_details(torch_ref.smpl_tensors(m), th)
+    for k in ("theta", "cam", "pose", "shape", "verts", "j2d", "j3d"):
+        assert torch.equal(want[k], got[k]), k
