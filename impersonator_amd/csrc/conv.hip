@@ -1576,6 +1576,7 @@ static unsigned long long *trace_block(const ConvArgs &a, int gx, int gy, int wa
 int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant)
 {
     ConvArgs a = a_in;   // (the halo launches attach a trace block)
+    a.trace = nullptr;   // only this function hands out trace blocks (lwg_conv_trace); never a caller's uninitialised field
     if (a.Cout % bn != 0 || (bn != 64 && bn != 128))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cout=%d not a multiple of the %d-channel tile", a.Cout, bn);
     if (!a.general && ((a.Hm * a.Wm) % BM != 0 || a.mtiles * BM != a.N * a.Hm * a.Wm))
@@ -1588,6 +1589,11 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
     for (int p = 0; p < a.nphase; ++p)
         if (a.ph[p].Kpad % BK != 0 || a.ph[p].Kpad < a.ph[p].ntaps * a.Cin)
             LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: bad padded K=%d for %d taps x %d channels", a.ph[p].Kpad, a.ph[p].ntaps, a.Cin);
+    if (a.precision == 1 && a.tap_inner)
+        for (int p = 0; p < a.nphase; ++p)
+            if (a.ph[p].Kpad != a.ph[p].ntaps * a.Cin)   // the taps-innermost walk addresses weight column tap*Cin + ci: no K padding
+                LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: taps-innermost walk needs K=%d == %d taps x %d channels", a.ph[p].Kpad,
+                         a.ph[p].ntaps, a.Cin);
     const dim3 grid(a.mtiles, a.Cout / bn, a.fuse_phases ? 1 : a.nphase);
     const size_t lds = (size_t)2 * (BM + bn) * LDK * sizeof(float);
     // the 128-channel tile needs 72 KiB of LDS: above the 64 KiB default, well inside gfx950's 160 KiB per CU
@@ -1749,7 +1755,8 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
         // 256 x 128 tiles on eight waves (two per SIMD) where every CU still gets one: the two 128-row halves share the
         // weight stage and a workgroup's prologue / epilogue are paid once per 256 rows -- the stride-2 encoders
         static const char *tall_ring_env = getenv("LWG_RING_TALL");   // "0": 128-row tiles only (A/B switch)
-        if (bn == 128 && !a.fuse_phases && a.nphase == 1 && (a.mtiles & 1) == 0 && !g_trace.buf &&
+        // (a tile's rows are img * Hm*Wm + rem without a wrap: a 256-row tile must not straddle two images)
+        if (bn == 128 && !a.fuse_phases && a.nphase == 1 && (a.mtiles & 1) == 0 && (a.Hm * a.Wm) % 256 == 0 && !g_trace.buf &&
             (long)(a.mtiles / 2) * (a.Cout / 128) >= device_cu_count() && !(tall_ring_env && tall_ring_env[0] == '0')) {
             static DeviceOnce opt_tall;
             const size_t lds_t = (size_t)3 * (256 + 128) * BK * sizeof(float);
@@ -1906,7 +1913,7 @@ int launch_conv_igemm_dbg(const ConvArgs &a, int bn, int dbg, hipStream_t st)
         case 812: if (bn == 128) launch_w_dbg<128, 1, 2, 0>(a, st); else launch_w_dbg<64, 1, 1, 0>(a, st); break;
         case 831: if (bn == 128) launch_w_dbg<128, 2, 1, 1>(a, st); else launch_w_dbg<64, 1, 1, 1>(a, st); break;   // no DMA
         case 856: {   // 256x64 tile (bn 64 only)
-            if (bn != 64 || (a.mtiles & 1)) return LWG_ERR_INVALID_ARG;
+            if (bn != 64 || (a.mtiles & 1) || (a.Hm * a.Wm) % 256 != 0) return LWG_ERR_INVALID_ARG;
             const dim3 grid(a.mtiles / 2, a.Cout / 64, a.nphase);
             const size_t lds = (size_t)3 * (256 + 64) * BK * sizeof(float);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_bf16x3<64, 2, 2, 3, 0, 256>),

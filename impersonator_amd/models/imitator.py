@@ -278,7 +278,12 @@ class Imitator(BaseModel):
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
+        # launch sequences of `fuse` batches: size every lane's scratch for that before the first one is enqueued
+        want = max(1, int(self._opt.batch_size)) * (1 if self._opt.front_warp else fuse)
+        self.generator.reserve(want)
         lane_list = self._lanes(nl)
+        for _, g in lane_list[1:]:
+            g.reserve(want)
         side.wait_stream(main)          # the personalised source (and the caller's smpl tensors) are main-stream work
         for st, _ in lane_list:
             st.wait_stream(main)

@@ -217,6 +217,14 @@ class HumanModelRecovery(nn.Module):
         tgt = tgt_smpl.float().contiguous()
         n, nb = tgt.shape[0], tgt.shape[1] - 75
         dev = tgt.device
+        # the kernel reads src_cam[0..2], first_cam[0..2] and src_shape[0..nb-1] through raw pointers: ONE source row each, on
+        # the targets' device (Imitator.swap_smpl would broadcast or raise; here a wrong shape would read out of bounds)
+        for name, t, width in (("src_cam", src_cam, 3), ("src_shape", src_shape, nb), ("first_cam", first_cam, 3)):
+            if t is None:
+                continue
+            if tuple(t.shape) != (1, width) or t.device != dev:
+                raise ValueError("get_details_swapped: %s must be a (1, %d) tensor on %s, got %s on %s"
+                                 % (name, width, dev, tuple(t.shape), t.device))
         theta = torch.empty((n, 75 + nb), device=dev, dtype=torch.float32)
         cam = torch.empty((n, 3), device=dev, dtype=torch.float32)
         pose = torch.empty((n, 72), device=dev, dtype=torch.float32)

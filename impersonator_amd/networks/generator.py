@@ -193,6 +193,14 @@ class ImpersonatorGenerator(NetworkBase):
             self._uploaded_version = ver
         return self._handle
 
+    def reserve(self, bs):
+        """Sizes the device scratch for launch sequences of up to `bs` frames ahead of time (extension): growing inside a
+        running pipeline would destroy and re-create the handle -- a device synchronisation and a weight upload -- in the
+        middle of it (Imitator.predict_batches fuses consecutive batches into one launch sequence)."""
+        if bs > self.max_batch:
+            self.release()
+            self.max_batch = int(bs)
+
     def replica(self):
         """A second engine over the *same* parameters (extension): own device handle, so own scratch and own copy of
         the re-laid-out weights.  Imitator.predict_batches runs consecutive batches on two of them, each on its own HIP

@@ -55,6 +55,27 @@ def test_conv_bf16x3_route(case):
                            ops.conv2d_forward(xg, wg, b, stride, pad, transposed))
 
 
+@pytest.mark.parametrize("k,stride", [(1, 1), (3, 2)])
+def test_ring_kernel_with_an_odd_number_of_tiles_per_image(k, stride):
+    """conv_igemm_bf16x3's 256-row tiles (eight waves) are only taken when an image's output grid is whole 256-row tiles: a
+    12 x 32 output map is three 128-pixel tiles, and with an even batch big enough to give every CU a tall tile (44 images x 3
+    tiles x 4 channel tiles) a 256-row tile would straddle two images -- zero-padded taps and InstanceNorm statistics of the
+    wrong image.  Against float64 torch."""
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(77)
+    N, cin, cout, Ho, Wo = 44, 32, 512, 12, 32
+    H, W = (Ho, Wo) if stride == 1 else (2 * Ho, 2 * Wo)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.05
+    y = F.conv2d(x.double(), w.double(), None, stride=stride, padding=k // 2)
+    assert tuple(y.shape[2:]) == (Ho, Wo)
+    xg, wg = x.permute(0, 2, 3, 1).contiguous().cuda(), w.cuda().contiguous()
+    y16 = ops.conv2d_forward(xg, wg, None, stride, k // 2, False, precision="bf16x3")
+    assert not torch.equal(y16, ops.conv2d_forward(xg, wg, None, stride, k // 2, False)), "the bf16x3 route did not run"
+    per_image = (y16.cpu().permute(0, 3, 1, 2).double() - y).flatten(1).norm(dim=1) / y.flatten(1).norm(dim=1)
+    assert float(per_image.max()) < 3e-5, "image %d: %g" % (int(per_image.argmax()), float(per_image.max()))
+
+
 @pytest.mark.parametrize("H,W", [(4, 32), (12, 96), (8, 64), (36, 160)])
 @pytest.mark.parametrize("cin,cout,N", [(32, 64, 2), (64, 128, 5), (128, 64, 1), (64, 256, 9)])
 @pytest.mark.parametrize("transposed", [False, True])
