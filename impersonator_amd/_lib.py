@@ -43,6 +43,11 @@ _PROTOS = {
     "lwg_smpl_workspace_bytes": (_sz, [_i]),
     "lwg_smpl_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lwg_smpl_forward_f64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lwg_morph": (_i, [_vp, _i, _i, _i, _c.c_long, _i, _i, _i, _vp, _vp]),
+    "lwg_mask_compose": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lwg_source_p2verts": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lwg_vis_f2pts_workspace_bytes": (_sz, [_i, _i]),
+    "lwg_vis_f2pts": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "lwg_pack_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lwg_unpack_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lwg_generator_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _i, _i]),

@@ -27,6 +27,7 @@ SOURCES = [
     ("raster.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("warp.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("smpl.hip", ["-fno-slp-vectorize"]),
+    ("personalize.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("conv.hip", []),
     ("direct.hip", []),
     ("heads.hip", []),

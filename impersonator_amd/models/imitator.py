@@ -116,29 +116,32 @@ class Imitator(BaseModel):
         src_info['wim'] = src_wim
         src_info['cond'], _ = self.render.encode_fim(src_info['cam'], src_info['verts'], fim=src_fim, transpose=True)
         src_info['f2verts'] = src_f2verts
-        # hazard H9 (imitator.py:105-107): p2verts is a VIEW of f2verts and the y flip mutates f2verts too
+        # hazard H9 (imitator.py:105-107): p2verts is a VIEW of f2verts and the y flip mutates f2verts too -- one liblwg launch
+        # negates y in place and returns the contiguous (nf,3,2) copy the fused per-frame kernel reads
+        p2verts_c = self.render.source_p2verts(src_f2verts)
         src_info['p2verts'] = src_f2verts[:, :, :, 0:2]
-        src_info['p2verts'][:, :, :, 1] *= -1
         if opt.only_vis:
-            src_info['p2verts'] = self.render.get_vis_f2pts(src_info['p2verts'], src_fim)
+            src_info['p2verts'] = p2verts_c = self.render.get_vis_f2pts(p2verts_c, src_fim)
         src_info['img'] = img
         src_info['image'] = ori_img
 
-        bg_mask = util.morph(src_info['cond'][:, -1:, :, :], ks=opt.bg_ks, mode='erode')
-        body_mask = 1 - bg_mask
+        # masks and network inputs of imitator.py:116-135 as liblwg launches (lwg_morph, lwg_mask_compose): bg is 1, ft is 0
+        bg_cond = src_info['cond'][:, -1:, :, :]
         if bg_img is not None:
             src_info['bg'] = torch.as_tensor(bg_img, dtype=torch.float32).cuda().reshape(1, 3, opt.image_size, opt.image_size)
         elif getattr(opt, 'bg_model', 'ORIGINAL') != 'ORIGINAL' or self.bgnet is not self.generator.bg_model:
+            body_mask = util.morph(bg_cond, ks=opt.bg_ks, mode='erode', complement=True)   # 1 - bg_mask
             src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)          # imitator.py:124-125
         else:
             # imitator.py:126-132: BGNet on the masked image + mask
-            src_info['bg'] = self.bgnet(torch.cat([img * bg_mask, bg_mask], dim=1))
+            bg_mask = util.morph(bg_cond, ks=opt.bg_ks, mode='erode')
+            src_info['bg'] = self.bgnet(self.render.mask_compose(img, bg_mask, bg_mask))
 
-        ft_mask = 1 - util.morph(src_info['cond'][:, -1:, :, :], ks=opt.ft_ks, mode='erode')
-        src_inputs = torch.cat([img * ft_mask, src_info['cond']], dim=1)
+        # ft_mask = 1 - erode(bg, ft_ks); src_inputs = cat([img * ft_mask, cond])
+        ft_erode = util.morph(bg_cond, ks=opt.ft_ks, mode='erode')
+        src_inputs = self.render.mask_compose(img, ft_erode, src_info['cond'], invert=True)
         src_info['feats'] = self.generator.encode_src(src_inputs)
-        # contiguous copy of the (nf,3,2) source face vertices for the fused per-frame kernel
-        src_info['p2verts_c'] = src_info['p2verts'].contiguous()
+        src_info['p2verts_c'] = p2verts_c
         self.src_info = src_info
 
         if visualizer is not None:

@@ -205,7 +205,8 @@ class HumanModelRecovery(nn.Module):
         raise NotImplementedError("the HMR image regressor (networks/hmr.py:200-300) is not part of the "
                                   "Imitator.forward() path; pass src_smpl / tgt_smpls")
 
-    STRATEGIES = {'smooth': 1, 'source': 2}   # anything else: the target's own camera (models/imitator.py:216-234)
+    # anything else: the target's own camera (models/imitator.py:216-234); 'as_is': theta = the given vector (get_details only)
+    STRATEGIES = {'smooth': 1, 'source': 2, 'as_is': 0}
 
     @torch.no_grad()
     def get_details_swapped(self, tgt_smpl, src_cam, src_shape, first_cam, cam_strategy='smooth'):
@@ -232,7 +233,8 @@ class HumanModelRecovery(nn.Module):
         strategy = self.STRATEGIES.get(cam_strategy, 3)
         sc = src_cam.float().contiguous() if strategy in (1, 2) else None
         fc = first_cam.float().contiguous() if strategy == 1 else None
-        _lib.check(lib.lwg_smpl_swap(_lib.ptr(tgt), n, nb, strategy, _lib.ptr(sc), _lib.ptr(src_shape.float().contiguous()), _lib.ptr(fc),
+        ss = src_shape.float().contiguous() if strategy != 0 else None
+        _lib.check(lib.lwg_smpl_swap(_lib.ptr(tgt), n, nb, strategy, _lib.ptr(sc), _lib.ptr(ss), _lib.ptr(fc),
                                      _lib.ptr(theta), _lib.ptr(cam), _lib.ptr(pose), _lib.ptr(shape), _lib.stream_ptr()))
         verts, j3d, _ = self.smpl.forward_theta(theta)
         j2d = torch.empty((n, j3d.shape[1], 2), device=dev, dtype=torch.float32)
@@ -240,6 +242,9 @@ class HumanModelRecovery(nn.Module):
         return {'theta': theta, 'cam': cam, 'pose': pose, 'shape': shape, 'verts': verts, 'j2d': j2d, 'j3d': j3d}
 
     def get_details(self, theta):
+        if theta.is_cuda:
+            # the slicing and the keypoint projection as liblwg launches too (same values as the tensor expressions below)
+            return self.get_details_swapped(theta, None, None, None, 'as_is')
         cam = theta[:, 0:3].contiguous()
         pose = theta[:, 3:75].contiguous()
         shape = theta[:, 75:].contiguous()

@@ -273,8 +273,9 @@ class ImpersonatorGenerator(NetworkBase):
         n = src_inputs.shape[0]
         h = self._ensure_handle(n)
         x = src_inputs.float().contiguous()
-        feats = [torch.empty((n, c, s, s), device=x.device, dtype=torch.float32).contiguous(
-            memory_format=torch.channels_last) for c, s in self._feature_shapes()]
+        # allocated channels_last outright (an NCHW empty tensor converted afterwards would cost a copy kernel each)
+        feats = [torch.empty((n, c, s, s), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+                 for c, s in self._feature_shapes()]
         _lib.check(_lib.load().lwg_generator_encode_src_n(h, _lib.ptr(x), n, _lib.ptr_array(feats), _lib.stream_ptr()))
         return feats[:N_DOWN + 1], feats[N_DOWN + 1:]
 

@@ -196,8 +196,22 @@ class SMPLRenderer(nn.Module):
     @staticmethod
     @torch.no_grad()
     def get_vis_f2pts(f2pts, fims):
-        """utils/nmr.py:506-546 (--only_vis, hazard H10): faces not in fim.unique()[1:] become -2.
-        Once per source, index bookkeeping only: plain torch indexing on the device."""
+        """utils/nmr.py:506-546 (--only_vis, hazard H10): faces not in fim.unique()[1:] become -2 -- i.e. the sorted unique
+        values minus the SMALLEST one present (the background's -1 whenever a background pixel exists).  CUDA tensors: two
+        liblwg launches (lwg_vis_f2pts: flag the values present, select); CPU tensors: the reference's indexing."""
+        if f2pts.is_cuda:
+            batched = f2pts.dim() == 4
+            pts = (f2pts if batched else f2pts[None]).float().contiguous()
+            fim = (fims if batched else fims[None]).to(torch.int32).contiguous()
+            bs, nf = pts.shape[:2]
+            per_face = pts[0, 0].numel()
+            lib = _lib.load()
+            ws = torch.empty(lib.lwg_vis_f2pts_workspace_bytes(bs, nf), dtype=torch.uint8, device=pts.device)
+            out = torch.empty_like(pts)
+            _lib.check(lib.lwg_vis_f2pts(_lib.ptr(pts), bs, nf, per_face, _lib.ptr(fim), fim.shape[1], fim.shape[2], _lib.ptr(out),
+                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+            return out if batched else out[0]
+
         def vis(orig, fim):
             out = torch.zeros_like(orig) - 2.0
             ids = fim.unique()[1:].long()
@@ -206,6 +220,29 @@ class SMPLRenderer(nn.Module):
         if f2pts.dim() == 4:
             return torch.stack([vis(f2pts[i], fims[i]) for i in range(f2pts.shape[0])], dim=0)
         return vis(f2pts, fims)
+
+    @torch.no_grad()
+    def source_p2verts(self, f2verts):
+        """models/imitator.py:105-107 (hazard H9) as one launch: negates y of `f2verts` (bs,nf,3,3) IN PLACE -- the reference
+        does it through the `p2verts = f2verts[..., 0:2]` view -- and returns the contiguous (bs,nf,3,2) copy of that view
+        which the per-frame flow kernel reads."""
+        f2verts = self._cuda(f2verts)
+        bs, nf = f2verts.shape[:2]
+        p2 = torch.empty((bs, nf, 3, 2), device=f2verts.device, dtype=torch.float32)
+        _lib.check(_lib.load().lwg_source_p2verts(_lib.ptr(f2verts), bs, nf, _lib.ptr(p2), _lib.stream_ptr()))
+        return p2
+
+    @torch.no_grad()
+    def mask_compose(self, img, mask, tail, invert=False):
+        """torch.cat([img * (1 - mask if invert else mask), tail], dim=1) in one launch (models/imitator.py:127-128,135):
+        img (n,3,H,W), mask (n,1,H,W), tail (n,ct,H,W)."""
+        img, mask, tail = self._cuda(img), self._cuda(mask), self._cuda(tail)
+        n, _, h, w = img.shape
+        ct = tail.shape[1]
+        out = torch.empty((n, 3 + ct, h, w), device=img.device, dtype=torch.float32)
+        _lib.check(_lib.load().lwg_mask_compose(_lib.ptr(img), _lib.ptr(mask), int(bool(invert)), _lib.ptr(tail), ct, n, h, w,
+                                                _lib.ptr(out), _lib.stream_ptr()))
+        return out
 
     # ------------------------------------------------------------------ fused per-frame path
     @torch.no_grad()

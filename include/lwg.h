@@ -139,6 +139,28 @@ LWG_API int lwg_smpl_forward_f64(const float *theta, int bs, int num_betas, int 
                                  const float *weights, const float *joint_regressor, float *verts, float *joints,
                                  float *Rs, void *workspace, size_t workspace_bytes, lwg_stream_t stream);
 
+/* ---- Once-per-source glue of Imitator.personalize (models/imitator.py:82-155), so that `personalize` launches no
+ * framework kernel.
+ * morph: utils/util.py:73-89 -- erode (mode 0: pad with 1, count == ks*ks) / dilate (mode 1: pad with 0, count >= 1) of a
+ *   mask with a ks x ks box (ks odd, <= 31); mask (n,1,H,W) fp32 whose images sit batch_stride floats apart (a channel slice of
+ *   an NCHW tensor qualifies), out (n,1,H,W) dense.  Exact for {0,1} masks (integer counts).  complement != 0 writes
+ *   1 - result (body_mask = 1 - bg_mask, ft_mask = 1 - erode: imitator.py:117,134).
+ * mask_compose: torch.cat([img * m, tail], dim=1) with m = mask or 1 - mask (invert): img (n,3,H,W), mask (n,1,H,W), tail
+ *   (n,tail_channels,H,W) -> out (n,3+tail_channels,H,W) (imitator.py:127-128,135).
+ * source_p2verts: hazard H9 (imitator.py:105-107): negates y of f2verts (bs,nf,3,3) IN PLACE (the reference does it through
+ *   the p2verts view) and writes the contiguous p2verts (bs,nf,3,2) = f2verts[..., 0:2].
+ * vis_f2pts: SMPLRenderer.get_vis_f2pts (utils/nmr.py:506-546, --only_vis, hazard H10): out = f2pts (bs,nf,per_face floats per
+ *   face) where the face id is among fim.unique()[1:] -- the sorted unique values minus the SMALLEST one present, whatever it
+ *   is -- and -2 elsewhere. */
+LWG_API int lwg_morph(const float *mask, int n, int H, int W, long batch_stride, int ks, int mode, int complement, float *out,
+                      lwg_stream_t stream);
+LWG_API int lwg_mask_compose(const float *img, const float *mask, int invert, const float *tail, int tail_channels, int n,
+                             int H, int W, float *out, lwg_stream_t stream);
+LWG_API int lwg_source_p2verts(float *f2verts, int bs, int nf, float *p2verts, lwg_stream_t stream);
+LWG_API size_t lwg_vis_f2pts_workspace_bytes(int bs, int nf);
+LWG_API int lwg_vis_f2pts(const float *f2pts, int bs, int nf, int per_face, const int32_t *fim, int H, int W, float *out,
+                          void *workspace, size_t workspace_bytes, lwg_stream_t stream);
+
 /* NCHW (n,C,H,W) -> NHWC with the channel count padded to cpad (zeros), and back (first C channels). */
 LWG_API int lwg_pack_nhwc(const float *x_nchw, int n, int C, int H, int W, int cpad, float *out_nhwc,
                           lwg_stream_t stream);
