@@ -1,6 +1,6 @@
 """Turns rocprofv3 CSV output into the small tracked summaries under profiles/ (development aid).
 
-    python tools/summarize_profile.py stats  <kernel_stats.csv> <out.md> [bench.json]
+    python tools/summarize_profile.py stats  <kernel_stats.csv> <out.md> [bench.json] [--cmd "<the traced command line>"]
     python tools/summarize_profile.py pmc    <counter_collection.csv> <kernel_trace.csv> <out.md>
 """
 import collections
@@ -15,14 +15,15 @@ def short(name):
     return m.group(1) if m else name[:70]
 
 
-def stats(path, out, bench=None):
+def stats(path, out, bench=None, cmd=None):
     rows = list(csv.DictReader(open(path)))
     with open(out, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --lanes 1 --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-mode\n"
-                "# (--lanes 1: one generator at a time, so a kernel's duration is its own -- the default two lanes overlap the\n"
-                "#  kernels of two batches, which is what the bench line below gains from; bench.py's roofline pass times its\n"
-                "#  kernels on one lane for the same reason.  __amd_rocclr_copyBuffer rows are the one-time weight uploads of\n"
-                "#  the setup, outside the timed steps)\n\n")
+        # the header carries the command line that was actually traced (round 3's fp32 summary carried the bf16 run's)
+        f.write("# %s\n" % (cmd or "rocprofv3 --kernel-trace --stats -- (command line not recorded)"))
+        f.write("# (--lanes 1, where given: one generator at a time, so a kernel's duration is its own -- the default two lanes overlap\n"
+                "#  the kernels of two batches, which is what the bench line gains from; bench.py's roofline pass times its kernels\n"
+                "#  on one lane for the same reason.  __amd_rocclr_copyBuffer rows are the one-time weight uploads of the setup,\n"
+                "#  outside the timed steps)\n\n")
         if bench:
             f.write("bench.py line of the same code (un-profiled run):\n\n```json\n%s\n```\n\n" % open(bench).read().strip())
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
@@ -104,6 +105,11 @@ if __name__ == "__main__":
     if sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
     elif sys.argv[1] == "stats":
-        stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+        argv, cmd = list(sys.argv), None
+        if "--cmd" in argv:
+            i = argv.index("--cmd")
+            cmd = argv[i + 1]
+            del argv[i:i + 2]
+        stats(argv[2], argv[3], argv[4] if len(argv) > 4 else None, cmd)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
