@@ -218,17 +218,12 @@ class Imitator(BaseModel):
         return (1 - front_mask) * preds + self.tsf_info['tsf_img'] * front_mask * (1 - mask)
 
     # ------------------------------------------------------------------ stream pipeline over batches
-    lanes = 2   # generator engines (and HIP streams) predict_batches deals consecutive batches to; env LWG_LANES
+    lanes = 2   # generator engines (and HIP streams) predict_batches deals consecutive batches to: 1 or 2; env LWG_LANES
+    MAX_LANES = 2   # a third lane measured -3 % (profiles/r03_bench_lanes3.json) and is not offered
     # batches per lane and round: the geometry of lanes * round_depth batches is one launch sequence (the kernels are
     # latency-bound at these sizes) and the lanes drain once per round; tools/depth_bench.py at batch 8, two lanes:
     # depth 1 2709, 2 2772, 3 2799, 4 2811 frames/s in one process.  env LWG_ROUND_DEPTH
     round_depth = 4
-    # True: the next round's geometry runs underneath this round's generators; False (default): it waits for them.
-    # At round_depth 4 the overlap is worth nothing measurable (profiles/r03_bench_overlap_ab.json), and it is the configuration in which rasteriser kernels used to
-    # miscompute beside the bf16x3 conv kernels.  The cause is known now -- a packed-fp32 instruction form (DESIGN.md section
-    # 5.1) that liblwg's geometry kernels no longer contain and every source is checked for -- but torch's own glue kernels
-    # of the geometry stage are outside that check.  Opt in with LWG_OVERLAP_GEOMETRY=1 / the keyword.
-    overlap_geometry = False
     # consecutive batches of a round that run as ONE generator launch sequence (see predict_batches); env LWG_FUSE.
     # Two batches of 8 = 16 frames give the trunk convolutions 256 tiles of 8 x 32 pixels (eight waves sharing a weight
     # stage): conv kernels 0.42 -> 0.48 of the matrix-pipe peak, +2.5..4.5 % frames/s (profiles/r03_conv_experiments.md).
@@ -250,33 +245,24 @@ class Imitator(BaseModel):
         return have[:n]
 
     @torch.no_grad()
-    def predict_batches(self, batches, cam_strategy='smooth', lanes=None, overlap_geometry=None):
+    def predict_batches(self, batches, cam_strategy='smooth', lanes=None):
         """Yields (t, preds) for every (tgt_smpls_chunk, t) of `batches`, in order.  Frames are independent once the
         source is personalised, so consecutive batches are processed in rounds of `lanes * round_depth`:
           1. the geometry of the round's batches (swap_smpl, SMPL, projection, rasteriser, flow, image warp -- a dozen
-             small, latency-bound kernels) runs as ONE launch sequence over all the round's frames on a side stream;
+             small, latency-bound kernels) runs as ONE launch sequence over all the round's frames on a side stream,
+             after the generators of the previous round;
           2. their generators then run side by side, each on its own stream and engine (scratch): a layer is
              conv -> finalize -> apply, every launch waiting for the one before, and the idle tails and launch gaps
-             of one chain are filled by the other's kernels (+15 % frames/s at batch 8 with two lanes; a third adds
-             1 %).
-        By default the geometry of round r+1 waits for the generators of round r (the strictly alternating order);
-        `overlap_geometry=True` / LWG_OVERLAP_GEOMETRY=1 lets it run underneath them (worth +2.5 % at round_depth 1,
-        nothing measurable at the default depth 4).  Until the end of round 2 that overlap produced wrong pixels in ~90 % of
-        passes: hipcc had formed a packed-fp32 instruction with op_sel on its second source in the rasteriser's setup
-        kernel, a form that miscomputes on a CU shared with the bf16x3 convolution kernels.
-        liblwg is checked for that form (tests/test_pk_opsel_lint.py) and the stress runs are clean (profiles/), but
-        torch's own glue kernels in the geometry stage are not covered, so the overlap is opt-in.  Events order every hand-over; round r+1 is enqueued before
-        round r is yielded, so a consumer that synchronises on a result (device->host copy) does not drain the
-        pipeline.  Same results as transfer_params_by_smpl + forward per batch."""
+             of one chain are filled by the other's kernels (+10-15 % frames/s at batch 8 with two lanes).
+        Events order every hand-over; round r+1 is enqueued before round r is yielded, so a consumer that synchronises on
+        a result (device->host copy) does not drain the pipeline.  Same results as transfer_params_by_smpl + forward per
+        batch, bit for bit.  (Rounds 2-3 also offered running round r+1's geometry UNDERNEATH round r's generators; at
+        round_depth 4 it measured no gain -- profiles/r03_bench_overlap_ab.json -- and was removed in round 4.  What made it
+        dangerous is in DESIGN_HISTORY.md: a packed-fp32 instruction form that miscomputes beside the bf16x3 conv kernels.)"""
         import os
-        nl = max(1, int(lanes if lanes is not None else os.environ.get("LWG_LANES", self.lanes)))
+        nl = min(self.MAX_LANES, max(1, int(lanes if lanes is not None else os.environ.get("LWG_LANES", self.lanes))))
         depth = max(1, int(os.environ.get("LWG_ROUND_DEPTH", self.round_depth)))
         fuse = max(1, int(os.environ.get("LWG_FUSE", self.fuse)))
-        if overlap_geometry is None:
-            env = os.environ.get("LWG_OVERLAP_GEOMETRY")
-            overlap = self.overlap_geometry if env is None else env not in ("0", "", "false", "False")
-        else:
-            overlap = bool(overlap_geometry)
         main = torch.cuda.current_stream()
         if getattr(self, '_side_stream', None) is None:
             self._side_stream = torch.cuda.Stream()
@@ -292,13 +278,12 @@ class Imitator(BaseModel):
             st.wait_stream(main)
 
         def enqueue_round(items, prev_done):
-            """geometry of `items` on the side stream (after the generators of the previous round), then one generator
+            """geometry of `items` on the side stream, after the generators of the previous round, then one generator
             per lane; returns [(t, preds, info, done_event)]"""
             prepared = []
             with torch.cuda.stream(side):
-                if not overlap:
-                    for ev in prev_done:
-                        side.wait_event(ev)
+                for ev in prev_done:
+                    side.wait_event(ev)
                 sizes = [int(chunk.shape[0]) if chunk.dim() > 1 else 1 for chunk, _ in items]
                 if len(items) > 1 and all(t != 0 for _, t in items[1:]) and all(torch.is_tensor(c) for c, _ in items):
                     # one launch sequence for the whole round (the kernels are latency-bound at these sizes), then

@@ -22,4 +22,5 @@ imitator.bgnet = net.cuda()
 for _ in range(3):
     imitator.personalize(src_img, src_smpl=src_smpl)
 torch.cuda.synchronize()
-print("personalized; background range %.3f..%.3f" % (float(imitator.src_info["bg"].min()), float(imitator.src_info["bg"].max())))
+bg = imitator.src_info["bg"].cpu().numpy()          # (a device-side min / max would put ATen reduce kernels into the trace)
+print("personalized; background range %.3f..%.3f" % (bg.min(), bg.max()))

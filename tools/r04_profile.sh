@@ -11,9 +11,9 @@ T0=$(date +%s)
 timeout 900 python $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"
 python $R/bench.py --lanes 1 --no-cpu-baseline --no-roofline --no-fp32-mode --no-secondary > $O/bench_lanes1.json 2>/dev/null
 
-BF="python $R/bench.py --lanes 1 --steps 16 --warmup 4 --no-cpu-baseline --no-fp32-mode --no-secondary"
+BF="python $R/bench.py --lanes 1 --steps 16 --warmup 4 --settle-ms 0 --no-cpu-baseline --no-fp32-mode --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- $BF > $O/stats.log 2>&1
-FP="python $R/bench.py --lanes 1 --steps 8 --warmup 2 --precision fp32 --no-cpu-baseline --no-secondary"
+FP="python $R/bench.py --lanes 1 --steps 8 --warmup 2 --settle-ms 0 --precision fp32 --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32_stats -o k -- $FP > $O/fp32_stats.log 2>&1
 PM="python $R/bench.py --lanes 1 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32-mode --no-secondary"
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
@@ -46,4 +46,4 @@ print("parity", json.dumps(d.get("parity"))[:900])
 print("cpu", json.dumps(d.get("cpu_baseline"))[:300])
 print("secondary", json.dumps(d.get("secondary"))[:1500])
 PY
-sed -n 1,40p $O/${TAG}_roofline.md | cut -c1-220; grep -A12 "By kernel" $O/${TAG}_fp32_roofline.md | cut -c1-200; tail -8 $O/${TAG}_pmc_mfma.md; grep -c "at::native" $O/${TAG}_personalize_kernel_stats.md
+sed -n 1,40p $O/${TAG}_roofline.md | cut -c1-220; grep -A12 "By kernel" $O/${TAG}_fp32_roofline.md | cut -c1-200; tail -8 $O/${TAG}_pmc_mfma.md; echo "ATen kernels in the personalize trace: $(grep -c "at::native" $O/${TAG}_personalize_kernel_stats.md)"
