@@ -63,6 +63,13 @@ struct ConvArgs {
     // (partials must be null), mtiles = ceil(M / 128).
     int natural_order;              // 1: keep the natural tile order (default 0: XCD bands, see conv_igemm_bf16x3)
     int tap_inner;                  // bf16x3 kernel: 1 = walk the reduction (32-channel slice, tap) with the taps innermost
+    // Fused InstanceNorm-apply of the INPUT (conv3x3_halo_bf16x3 only; conv_raw_input_supported() says whether a launch takes
+    // it): channels >= raw_from of x hold the producer's RAW fp32 conv output instead of a split-bf16 activation, and the
+    // kernel normalises them itself after the halo lands in LDS -- relu(x * scale + shift) with the producer's
+    // (scale, shift) = in_ss[image * in_ss_ld + (channel - raw_from)], then the hi/lo split -- the same operations, bit for
+    // bit, that apply_kernel would have written to memory and this kernel read back.  raw_in = 0: off.
+    int raw_in, raw_from;
+    const float2 *in_ss; int in_ss_ld;
     unsigned long long *trace;      // measurement builds only (LWG_CONV_TRACE): per-wave cycle accounting, see conv_igemm_bf16x3
     int general;
     const float *bias;
@@ -78,6 +85,8 @@ enum { kIgemmReg64 = 0, kIgemmReg128 = 1, kIgemmSmallCin = 2, kIgemmDma64 = 3, k
        kIgemmBf16x3_128 = 6, kDirectStemBf16x3 = 7, kHaloBf16x3_128 = 8, kHaloBf16x3_64 = 9, kIgemmVariants = 10 };
 extern const char *const kIgemmVariantNames[kIgemmVariants];
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant = nullptr);
+// true when launch_conv_igemm(a, bn) would run a kernel that honours a.raw_in (the halo-resident 3x3 / transposed kernels)
+bool conv_raw_input_supported(const ConvArgs &a, int bn);
 
 // The 7x7 stem (Cin 6 in an NHWC8 fp32 tensor -> 64 channels) as an LDS-resident direct convolution on the bf16x3
 // path (direct.hip).  `w` is the filter bank packed by stem_pack_weights; output and partials as launch_conv_igemm.

@@ -994,9 +994,17 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
 //   * halo pieces (1 KiB = 8 pixels each, NHW per wave and slice, the last ones may repeat a chunk so that every wave
 //     issues the same number) ride behind the MFMAs of taps 0..6, ahead of the stage's weight pieces; counted
 //     s_waitcnt: the pieces younger than the next stage's weights are known per tap at compile time.
-template <int NHW, int B_CH, int Q, int QB, int NS>
+//   * RAW (ConvArgs::raw_in): channel slices >= raw_from arrive as the producer's raw fp32 conv output and are normalised,
+//     ReLU'd and split IN the halo slot by the wave that fetched them (every wave converts the chunks it loaded itself, so no
+//     extra barrier: the stage barrier that publishes the halo publishes the converted halo).  The halo pieces are then
+//     issued in taps 0..4 instead of 0..6; a piece issued in tap t has landed behind the counted wait of tap t+2, and its
+//     chunk is converted under the MFMAs of tap t+3 -- the last one in tap 7, ahead of the barrier in tap 8 after which the
+//     next slice's first fragments are read.  Chunks that two waves would fetch (so that all waves issue the same number
+//     of pieces) go to a dummy chunk for one of them: a late duplicate must not overwrite a converted chunk.
+template <int NHW, int B_CH, int Q, int QB, int NS, int HT = 7>
 struct HaloSched {
-    static constexpr int nh(int t) { return t < 7 ? NHW / 7 + (t < NHW % 7 ? 1 : 0) : 0; }   // halo pieces issued in tap t's stage
+    static constexpr int nh(int t) { return t < HT ? NHW / HT + (t < NHW % HT ? 1 : 0) : 0; }   // halo pieces issued in tap t's stage
+    static constexpr int tap_of(int k) { int t = 0; while (hstart(t + 1) <= k) ++t; return t; }    // tap in which piece k is issued
     static constexpr int hstart(int t) { int n = 0; for (int u = 0; u < t; ++u) n += nh(u); return n; }
     static constexpr int lps(int t) { return nh(t) + B_CH; }
     static constexpr int pos(int t, int p) { return (p + 1) * Q / lps(t) - 1; }              // piece p rides behind this MFMA
@@ -1023,7 +1031,7 @@ struct HaloCT {
     static constexpr int dx(int t) { return (t == 2 || t == 6 || t == 8) ? 1 : 0; }
 };
 
-template <int BN, int WM, int WN, int NS, int TC, int BMT = BM, int CT = 0>
+template <int BN, int WM, int WN, int NS, int TC, int BMT = BM, int CT = 0, bool RAW = false>
 __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void conv3x3_halo_bf16x3(const ConvArgs a)
 {
     constexpr int NPH = CT ? 4 : 1, PADL = CT ? 0 : 1;   // accumulator sets; halo rows / columns above and left of the tile
@@ -1037,8 +1045,13 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     static_assert(B_CH >= 1, "a weight chunk per wave");
     constexpr int TILES = WM * WN, Q = 6 * TILES, QB = Q * 3 / 4, NL = 2 * (WM + WN);
     constexpr int RPM = (NL + (Q - QB) - 1) / (Q - QB);
-    using S = HaloSched<NHW, B_CH, Q, QB, NS>;
-    static_assert(S::hstart(9) == NHW && Q >= NHW / 7 + 1 + B_CH, "halo pieces fit taps 0..6, one piece per MFMA at most");
+    constexpr int HT = RAW ? 5 : 7;                // taps in whose stages the halo pieces of the next slice are issued
+    using S = HaloSched<NHW, B_CH, Q, QB, NS, HT>;
+    static_assert(S::hstart(9) == NHW && Q >= NHW / HT + 1 + B_CH, "halo pieces fit their taps, one piece per MFMA at most");
+    static_assert(!RAW || (NW % 2 == 0 && S::tap_of(NHW - 1) + 3 <= 7), "RAW: chunk parity per wave, conversions end by tap 7");
+    // RAW: one dummy chunk behind the ring (duplicate pieces land there), then the raw channels' (scale, shift) of this image
+    constexpr int DUMMY = BOFF + NS * BSTAGE;      // float offset
+    constexpr int SSOFF = DUMMY + 8 * BK;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1084,6 +1097,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     // ---- halo chunks of this wave: chunk c = (wave + NW j) mod NCH covers halo pixels 8c .. 8c+7; lane -> (pixel 8c + lane>>3,
     //      16-byte slot lane&7), fetched from the swizzled source slot.  The byte offsets do not depend on the slice.
     unsigned hoff[NHW];
+    unsigned inside = 0;   // RAW: bit j = this lane's pixel of piece j is inside the image (padding stays zero: nothing to normalise)
 #pragma unroll
     for (int j = 0; j < NHW; ++j) {
         int c = wave + NW * j;
@@ -1093,6 +1107,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         const int gh = h0 - PADL + hr, gw = w0 - PADL + hc;
         const bool ok = p < HP && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
         hoff[j] = ok ? (unsigned)(((gh * a.W + gw) * a.ldx + (ls ^ ((p >> 1) & 7)) * 4) * 4) : zoff_b;
+        if (RAW && ok && wave + NW * j < NCH) inside |= 1u << j;   // (a duplicate piece goes to the dummy chunk and is nobody's to convert)
     }
     unsigned wvoff[NPH][B_CH];   // lane offsets into the phase's [Cout][ntaps * Cin] matrix
 #pragma unroll
@@ -1112,9 +1127,55 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     // halo piece j of channel slice `sl` into halo slot hs
     auto halo_piece = [&](int j, int sl, int hs) {
         int c = wave + NW * j;
-        if (c >= NCH) c -= NCH;
-        dma16(hoff[j], x_base + __builtin_amdgcn_readfirstlane((unsigned)sl * (BK * 4u)),
-              __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((hs * HALO + c * 8 * BK) * 4)));
+        unsigned dst = (unsigned)((hs * HALO + c * 8 * BK) * 4);
+        if (c >= NCH) {
+            c -= NCH;
+            dst = RAW ? (unsigned)(DUMMY * 4) : (unsigned)((hs * HALO + c * 8 * BK) * 4);
+        }
+        dma16(hoff[j], x_base + __builtin_amdgcn_readfirstlane((unsigned)sl * (BK * 4u)), __builtin_amdgcn_readfirstlane(lds_base + dst));
+    };
+    // RAW: piece j of slice `sl` (landed in halo slot hs) from raw fp32 to the normalised split-bf16 form, in place.  Lane
+    // (lr, ls) holds the 16 bytes it fetched: raw channels 4g .. 4g+3 of the slice, g = ls ^ swz (the fetch swizzled the SOURCE
+    // slot); as a split run those four values are 8 bytes of hi in 16-byte slot g/2 and 8 of lo in slot 4 + g/2, both
+    // stored at their swizzled positions.  One ds_read_b128 per lane, then the writes: the wave reads its whole chunk before
+    // it writes any of it (LDS operations of one wave execute in order).
+    [[maybe_unused]] float4 ssa = {0.f, 0.f, 0.f, 0.f}, ssb = {0.f, 0.f, 0.f, 0.f};   // (scale, shift) of this lane's four channels
+    [[maybe_unused]] auto load_ss = [&](int sl) {
+        // chunk c = wave + NW j and NW is even: every chunk of this wave has the parity of `wave`, so swz and g are per-lane constants
+        const int g = ls ^ ((((wave & 1) << 2) + (lr >> 1)) & 7);
+        const float *q = smem + SSOFF + (sl * BK - a.raw_from + 4 * g) * 2;
+        ssa = *reinterpret_cast<const float4 *>(q);
+        ssb = *reinterpret_cast<const float4 *>(q + 4);
+    };
+    // per-lane constants of the conversion (see load_ss): byte offsets inside a chunk row of the slot read and of the two slots written
+    [[maybe_unused]] const int cv_swz = (((wave & 1) << 2) + (lr >> 1)) & 7, cv_g = ls ^ cv_swz;
+    [[maybe_unused]] const int cv_rd = lr * 128 + ls * 16;
+    [[maybe_unused]] const int cv_hi = lr * 128 + (((cv_g >> 1) ^ cv_swz) << 4) + ((cv_g & 1) << 3);
+    [[maybe_unused]] const int cv_lo = lr * 128 + (((4 + (cv_g >> 1)) ^ cv_swz) << 4) + ((cv_g & 1) << 3);
+    [[maybe_unused]] const int cv_dummy = DUMMY * 4 + lane * 16;     // where the writes of lanes with nothing to convert go
+    struct Conv { float4 v, y; bf16x4_t h, l; };
+    [[maybe_unused]] Conv cv[2];
+    // step 0: read the raw 16 bytes; 1: normalise + ReLU; 2: hi terms; 3: lo terms; 4: write.  `live` = the lane's pixel is inside
+    // the image and the slice is a raw one (else the results go to the dummy chunk: no branch in the MFMA stream)
+    [[maybe_unused]] auto convert_step = [&](int j, Conv &c, int hs, int step, bool live) {
+        char *chunk = reinterpret_cast<char *>(smem) + (hs * HALO + (wave + NW * j) * 8 * BK) * 4;
+        if (step == 0) {
+            c.v = *reinterpret_cast<const float4 *>(chunk + cv_rd);
+        } else if (step == 1) {
+            c.y.x = fmaxf(fmaf(c.v.x, ssa.x, ssa.y), 0.f);
+            c.y.y = fmaxf(fmaf(c.v.y, ssa.z, ssa.w), 0.f);
+            c.y.z = fmaxf(fmaf(c.v.z, ssb.x, ssb.y), 0.f);
+            c.y.w = fmaxf(fmaf(c.v.w, ssb.z, ssb.w), 0.f);
+        } else if (step == 2) {
+            c.h[0] = (__bf16)c.y.x; c.h[1] = (__bf16)c.y.y; c.h[2] = (__bf16)c.y.z; c.h[3] = (__bf16)c.y.w;
+        } else if (step == 3) {
+            c.l[0] = (__bf16)(c.y.x - (float)c.h[0]); c.l[1] = (__bf16)(c.y.y - (float)c.h[1]);
+            c.l[2] = (__bf16)(c.y.z - (float)c.h[2]); c.l[3] = (__bf16)(c.y.w - (float)c.h[3]);
+        } else {
+            char *base = reinterpret_cast<char *>(smem);
+            *reinterpret_cast<bf16x4_t *>(live ? chunk + cv_hi : base + cv_dummy) = c.h;
+            *reinterpret_cast<bf16x4_t *>(live ? chunk + cv_lo : base + cv_dummy + 8) = c.l;
+        }
     };
     // weight piece jb of reduction stage (tap it, slice is) into ring slot `slot`
     auto weight_piece = [&](int jb, int it, int is, int slot) {
@@ -1178,6 +1239,13 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         const int sl_halo = sl + 1 < nslices ? sl + 1 : 0;    // the last slice fetches a halo nobody reads
         Frags f1, nx;
         int nxt_a[WM];
+        // RAW: the chunks of slice sl+1 whose piece was issued three taps ago have landed (counted wait of tap T-1): normalise them
+        // under this tap's MFMAs, ahead of its barrier
+        [[maybe_unused]] const bool raw_next = RAW && sl + 1 < nslices && (sl + 1) * BK >= a.raw_from;
+        [[maybe_unused]] const unsigned live_bits = raw_next ? inside : 0u;
+        if constexpr (RAW) {
+            if (T == S::tap_of(0) + 3) load_ss(sl + 1 < nslices ? sl + 1 : 0);
+        }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int kb = q / (3 * TILES), r = q % (3 * TILES);
@@ -1211,6 +1279,30 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
             }
+            if constexpr (RAW) {
+                // the conversion of the pieces issued three taps ago, five steps per piece, one step behind each of the MFMAs ahead
+                // of the barrier (four steps where the stage has fewer than ten MFMAs there: the 64-channel tile)
+                constexpr int NCONV = T >= 3 ? S::nh(T - 3) : 0, K0 = T >= 3 ? S::hstart(T - 3) : 0;
+                constexpr int ST = QB >= 10 ? 5 : 4;
+                static_assert(NCONV <= 2 && NCONV * ST <= QB, "conversion steps fit ahead of the barrier");
+                if (q < NCONV * ST) {
+                    const int u = q / ST, step = q % ST;
+                    const bool live = (live_bits >> (K0 + u)) & 1u;
+                    if (ST == 5) {
+                        convert_step(K0 + u, cv[u], hs ^ 1, step, live);
+                    } else {   // 0: read, 1: normalise + hi, 2: lo, 3: write
+                        if (step == 0) convert_step(K0 + u, cv[u], hs ^ 1, 0, live);
+                        if (step == 1) { convert_step(K0 + u, cv[u], hs ^ 1, 1, live); convert_step(K0 + u, cv[u], hs ^ 1, 2, live); }
+                        if (step == 2) convert_step(K0 + u, cv[u], hs ^ 1, 3, live);
+                        if (step == 3) convert_step(K0 + u, cv[u], hs ^ 1, 4, live);
+                    }
+                    const bool rd = step == 0, wr = step == ST - 1;
+                    if (q >= NL) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else if (wr) { __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2, 0); }
+                    else __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                }
+            }
             if (ISSUE) {
 #pragma unroll
                 for (int p = 0; p < S::lps(T); ++p)
@@ -1228,6 +1320,14 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     };
 
     // ---- prologue: halo of slice 0, weights of stages 0 .. NS-2 (taps 0 .. NS-2 of slice 0); the first stage landed
+    if constexpr (RAW) {
+        // this image's (scale, shift) of the raw channels into LDS: plain loads, drained before the first DMA is issued (the
+        // main loop counts its outstanding memory operations)
+        const float2 *ss = a.in_ss + (size_t)img * a.in_ss_ld;
+        const int nraw = a.Cin - a.raw_from;
+        for (int i2 = tid; i2 < nraw; i2 += NW * 64) reinterpret_cast<float2 *>(smem + SSOFF)[i2] = ss[i2];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 #pragma unroll
     for (int j = 0; j < NHW; ++j) halo_piece(j, 0, 0);
 #pragma unroll
@@ -1235,6 +1335,19 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
 #pragma unroll
         for (int jb = 0; jb < B_CH; ++jb) weight_piece(jb, st, 0, st);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * B_CH) : "memory");
+    if constexpr (RAW) {
+        if (a.raw_from == 0) {                 // slice 0 is raw: convert it before anyone reads it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // the (scale, shift) table is complete
+            asm volatile("" ::: "memory");
+            load_ss(0);
+#pragma unroll
+            for (int j = 0; j < NHW; ++j)
+#pragma unroll
+                for (int step = 0; step < 5; ++step) convert_step(j, cv[0], 0, step, (inside >> j) & 1u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -1573,6 +1686,29 @@ static unsigned long long *trace_block(const ConvArgs &a, int gx, int gy, int wa
     return p;
 }
 
+// the shapes conv3x3_halo_bf16x3 takes (3x3 / stride 1 / pad 1, or the four phases of ConvTranspose2d(k3, s2, p1, op1))
+static bool halo3x3_shape(const ConvArgs &a)
+{
+    const ConvPhase &p0 = a.ph[0];
+    return a.nphase == 1 && p0.KH == 3 && p0.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.os == 1 && a.H == a.Hm &&
+           a.W == a.Wm && p0.Kpad == 9 * a.Cin && a.Wm % 32 == 0 && a.Hm % 4 == 0;
+}
+static bool haloCT_shape(const ConvArgs &a)
+{
+    return a.nphase == 4 && a.os == 2 && a.stride == 1 && a.pad == 0 && a.dil == 1 && a.H == a.Hm && a.W == a.Wm && a.Wm % 32 == 0 &&
+           a.Hm % 4 == 0 && a.Cout % 64 == 0 && a.ph[0].KH == 1 && a.ph[0].KW == 1 && a.ph[1].KH == 1 && a.ph[1].KW == 2 &&
+           a.ph[2].KH == 2 && a.ph[2].KW == 1 && a.ph[3].KH == 2 && a.ph[3].KW == 2 && a.ph[0].Kpad == a.Cin &&
+           a.ph[1].Kpad == 2 * a.Cin && a.ph[2].Kpad == 2 * a.Cin && a.ph[3].Kpad == 4 * a.Cin;
+}
+bool conv_raw_input_supported(const ConvArgs &a, int bn)
+{
+    static const char *halo_env = getenv("LWG_HALO"), *fused_env = getenv("LWG_FUSED_APPLY");   // A/B switches ("0": off)
+    if ((halo_env && halo_env[0] == '0') || (fused_env && fused_env[0] == '0')) return false;
+    if (a.precision != 1 || a.general || !a.w_split || (a.ldx & 31) || (a.Cin & 31) || a.Cin < 32 || (bn != 64 && bn != 128)) return false;
+    if (a.raw_from < 0 || (a.raw_from & 31) || a.raw_from >= a.Cin || a.Cin - a.raw_from > 512) return false;
+    return halo3x3_shape(a) || haloCT_shape(a);
+}
+
 int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant)
 {
     ConvArgs a = a_in;   // (the halo launches attach a trace block)
@@ -1594,6 +1730,8 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
             if (a.ph[p].Kpad != a.ph[p].ntaps * a.Cin)   // the taps-innermost walk addresses weight column tap*Cin + ci: no K padding
                 LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: taps-innermost walk needs K=%d == %d taps x %d channels", a.ph[p].Kpad,
                          a.ph[p].ntaps, a.Cin);
+    if (a.raw_in && (!a.in_ss || !conv_raw_input_supported(a, bn)))
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: raw (un-normalised) input is only taken by the halo-resident bf16x3 kernels");
     const dim3 grid(a.mtiles, a.Cout / bn, a.fuse_phases ? 1 : a.nphase);
     const size_t lds = (size_t)2 * (BM + bn) * LDK * sizeof(float);
     // the 128-channel tile needs 72 KiB of LDS: above the 64 KiB default, well inside gfx950's 160 KiB per CU
@@ -1663,17 +1801,16 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
             if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the bf16x3 path");
         // 3x3 / stride 1 / pad 1 with whole 128-pixel row blocks: the halo-resident kernel (conv3x3_halo_bf16x3)
         static const char *halo_env = getenv("LWG_HALO");   // "0": the DMA-ring kernel everywhere (A/B switch)
-        const ConvPhase &p0 = a.ph[0];
-        if (!(halo_env && halo_env[0] == '0') && a.nphase == 1 && p0.KH == 3 && p0.KW == 3 && a.stride == 1 && a.pad == 1 &&
-            a.dil == 1 && a.os == 1 && a.H == a.Hm && a.W == a.Wm && p0.Kpad == 9 * a.Cin &&
-            a.Wm % 32 == 0 && a.Hm % 4 == 0) {
+        if (!(halo_env && halo_env[0] == '0') && halo3x3_shape(a)) {
             const int tc = 32;
-            static DeviceOnce halo_opt[4];
+            static DeviceOnce halo_opt[8];
+            const size_t raw_bytes = a.raw_in ? (size_t)8 * BK * sizeof(float) + (size_t)(a.Cin - a.raw_from) * sizeof(float2) : 0;
             auto run = [&](auto kern, int ns, int bmt, DeviceOnce &once) -> int {
                 const int hp = (bmt / tc + 2) * (tc + 2), nch = (hp + 7) / 8;
-                const size_t bytes = ((size_t)2 * nch * 8 * BK + (size_t)ns * bn * BK) * sizeof(float);
-                if (!once.done()) {
-                    LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+                const size_t base = ((size_t)2 * nch * 8 * BK + (size_t)ns * bn * BK) * sizeof(float), bytes = base + raw_bytes;
+                if (!once.done()) {   // the raw-input variants size their (scale, shift) table per launch: opt in for up to 512 channels
+                    const size_t most = base + (a.raw_in ? (size_t)8 * BK * sizeof(float) + 512 * sizeof(float2) : 0);
+                    LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most));
                     once.mark();
                 }
                 const dim3 g(grid.x / (bmt / BM), grid.y, 1);
@@ -1688,7 +1825,11 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
             // (the 64-channel tile on eight waves of 32 x 64 -- one 110 KiB workgroup instead of two of 76 -- measured slower:
             // 380 -> 348 TFLOP/s on skipper.2, gpurun_out/r03o)
             int rc;
-            if (tall) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 256>, 4, 256, halo_opt[2]);
+            if (a.raw_in) {   // the input's InstanceNorm + ReLU + split folded into the halo (see HaloSched)
+                if (tall) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 256, 0, true>, 4, 256, halo_opt[6]);
+                else if (bn == 128) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 128, 0, true>, 4, 128, halo_opt[4]);
+                else rc = run(&conv3x3_halo_bf16x3<64, 1, 2, 3, 32, 128, 0, true>, 3, 128, halo_opt[5]);
+            } else if (tall) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 256>, 4, 256, halo_opt[2]);
             else if (bn == 128) rc = run(&conv3x3_halo_bf16x3<128, 2, 2, 4, 32>, 4, 128, halo_opt[0]);
             else rc = run(&conv3x3_halo_bf16x3<64, 1, 2, 3, 32>, 3, 128, halo_opt[1]);   // 52 + 24 KiB: two workgroups per CU
             if (rc != LWG_OK) return rc;
@@ -1697,19 +1838,30 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
             return LWG_OK;
         }
         // ConvTranspose2d(k3, s2, p1, op1) given as its four phases: one launch of the halo kernel (CT = 1)
-        if (!(halo_env && halo_env[0] == '0') && a.nphase == 4 && a.os == 2 && a.stride == 1 && a.pad == 0 && a.dil == 1 &&
-            a.H == a.Hm && a.W == a.Wm && a.Wm % 32 == 0 && a.Hm % 4 == 0 && a.Cout % 64 == 0 &&
-            a.ph[0].KH == 1 && a.ph[0].KW == 1 && a.ph[1].KH == 1 && a.ph[1].KW == 2 && a.ph[2].KH == 2 && a.ph[2].KW == 1 &&
-            a.ph[3].KH == 2 && a.ph[3].KW == 2 && a.ph[0].Kpad == a.Cin && a.ph[1].Kpad == 2 * a.Cin && a.ph[2].Kpad == 2 * a.Cin &&
-            a.ph[3].Kpad == 4 * a.Cin) {
+        if (!(halo_env && halo_env[0] == '0') && haloCT_shape(a)) {
             const bool wide = a.Cout % 128 == 0 && (long)a.mtiles * (a.Cout / 128) >= device_cu_count();
             const int cbn = wide ? 128 : 64, ns = wide ? 4 : 3;
             const int nch = ((4 + 1) * (32 + 1) + 7) / 8;
-            const size_t bytes = ((size_t)2 * nch * 8 * BK + (size_t)ns * cbn * BK) * sizeof(float);
+            const size_t bytes = ((size_t)2 * nch * 8 * BK + (size_t)ns * cbn * BK) * sizeof(float) +
+                                 (a.raw_in ? (size_t)8 * BK * sizeof(float) + (size_t)(a.Cin - a.raw_from) * sizeof(float2) : 0);
             const dim3 g(a.mtiles, a.Cout / cbn, 1);
             a.trace = trace_block(a, g.x, g.y, 4, -(int)(9 * a.Cin / BK));   // negative stage count marks a transposed conv
-            static DeviceOnce ct_opt[2];
-            if (wide) {
+            static DeviceOnce ct_opt[4];
+            if (a.raw_in && wide) {
+                auto kern = &conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 128, 1, true>;
+                if (!ct_opt[2].done()) {
+                    LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    ct_opt[2].mark();
+                }
+                kern<<<g, 256, bytes, st>>>(a);
+            } else if (a.raw_in) {
+                auto kern = &conv3x3_halo_bf16x3<64, 1, 2, 3, 32, 128, 1, true>;
+                if (!ct_opt[3].done()) {
+                    LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    ct_opt[3].mark();
+                }
+                kern<<<g, 256, bytes, st>>>(a);
+            } else if (wide) {
                 auto kern = &conv3x3_halo_bf16x3<128, 2, 2, 4, 32, 128, 1>;
                 if (!ct_opt[0].done()) {
                     LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

@@ -354,11 +354,13 @@ const float *zero_tail_of(const lwg_generator *g, const float *x)
     return nullptr;
 }
 
-// one normalised conv layer: conv -> statistics -> (caller applies)
-int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, int H, int W, float *raw,
-             hipStream_t st)
+// launch arguments of one conv layer: `raw` / `ld_raw` = where the raw (pre-norm) output goes and its pixel stride (0: dense);
+// raw_from >= 0: the input's channels from there on are the PRODUCER's raw output, normalised by the conv itself with the
+// (scale, shift) currently in g->ss (ConvArgs::raw_in)
+int conv_args(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, int H, int W, float *raw, int ld_raw, int raw_from,
+              ConvArgs &a, int &bn)
 {
-    ConvArgs a = {};
+    a = ConvArgs{};
     a.x = x;
     a.ldx = ldx;
     a.N = N;
@@ -379,8 +381,14 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
         if (!a.zeros) LWG_FAIL(LWG_ERR_STATE, "bf16x3 conv input is not one of the handle's activation buffers");
     }
     a.y = raw;
-    a.ldy = L.cout;
+    a.ldy = ld_raw > 0 ? ld_raw : L.cout;
     a.Cout = L.cout;
+    if (raw_from >= 0) {
+        a.raw_in = 1;
+        a.raw_from = raw_from;
+        a.in_ss = g->ss;
+        a.in_ss_ld = L.cin_pad - raw_from;
+    }
     a.nphase = L.nphase;
     a.dil = 1;
     for (int p = 0; p < L.nphase; ++p) a.ph[p] = L.ph[p];
@@ -397,7 +405,7 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     // tiles), else 64 for more, smaller tiles (small batches).  Transposed convs: 64-channel tiles with the four
     // phases walked inside the workgroup (equal work per workgroup).
     const long tiles128 = (long)a.mtiles * (L.cout / 128) * L.nphase;
-    int bn = (L.cout % 128 == 0 && tiles128 >= 256) ? 128 : 64;
+    bn = (L.cout % 128 == 0 && tiles128 >= 256) ? 128 : 64;
     if (L.transposed) {
         if (a.precision == 1 && L.cout % 128 == 0) {
             // bf16x3: the 128-channel tile is ~1.4x faster than the 64-channel one; phases become separate workgroups,
@@ -408,6 +416,29 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
             bn = 64;
             a.fuse_phases = 1;
         }
+    }
+    return LWG_OK;
+}
+
+// would layer L, reading `x`, take raw input channels from `raw_from` on?  (the halo-resident bf16x3 kernels do)
+bool takes_raw_input(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, int H, int W, int raw_from)
+{
+    if (!g->split || !L.w_split) return false;
+    ConvArgs a;
+    int bn = 0;
+    if (conv_args(g, L, x, ldx, N, H, W, g->raw, 0, raw_from, a, bn) != LWG_OK) return false;
+    return conv_raw_input_supported(a, bn);
+}
+
+// one normalised conv layer: conv -> statistics -> (caller applies, or the consumer does: see conv_args)
+int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, int H, int W, float *raw, hipStream_t st,
+             int ld_raw = 0, int raw_from = -1)
+{
+    ConvArgs a;
+    int bn = 0;
+    {
+        const int rc0 = conv_args(g, L, x, ldx, N, H, W, raw, ld_raw, raw_from, a, bn);
+        if (rc0 != LWG_OK) return rc0;
     }
 
     hipEvent_t e1 = nullptr;
@@ -505,10 +536,16 @@ int run_resblock(lwg_generator *g, const StreamNet &s, int i, const float *xin, 
                  const Warp *warps, int nwarp, int align, hipStream_t st)
 {
     const int h = g->is >> kNDown, C = g->cd << kNDown;
-    int rc = run_conv(g, s.res[2 * i], xin, C, N, h, h, g->raw, st);
-    if (rc != LWG_OK) return rc;
-    if ((rc = run_apply(g, N, h, h, C, true, g->trunk[2], C, nullptr, 0, nullptr, 0, align, st)) != LWG_OK) return rc;
-    if ((rc = run_conv(g, s.res[2 * i + 1], g->trunk[2], C, N, h, h, g->raw, st)) != LWG_OK) return rc;
+    int rc;
+    if (takes_raw_input(g, s.res[2 * i + 1], g->trunk[2], C, N, h, h, 0)) {
+        // the first conv's InstanceNorm + ReLU is applied by the second conv as it loads its halo: no pass over memory in between
+        if ((rc = run_conv(g, s.res[2 * i], xin, C, N, h, h, g->trunk[2], st, C)) != LWG_OK) return rc;
+        if ((rc = run_conv(g, s.res[2 * i + 1], g->trunk[2], C, N, h, h, g->raw, st, 0, 0)) != LWG_OK) return rc;
+    } else {
+        if ((rc = run_conv(g, s.res[2 * i], xin, C, N, h, h, g->raw, st)) != LWG_OK) return rc;
+        if ((rc = run_apply(g, N, h, h, C, true, g->trunk[2], C, nullptr, 0, nullptr, 0, align, st)) != LWG_OK) return rc;
+        if ((rc = run_conv(g, s.res[2 * i + 1], g->trunk[2], C, N, h, h, g->raw, st)) != LWG_OK) return rc;
+    }
     return run_apply(g, N, h, h, C, false, xout, C, xin, C, warps, nwarp, align, st);
 }
 
@@ -568,16 +605,31 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
     g->trunk_out = cur;
     const float *d = g->trunk[cur];
     int dC = cd << kNDown, dH = is >> kNDown;
+    bool d_raw = false;   // d holds the previous skipper's RAW output (its InstanceNorm + ReLU pending in g->ss)
     for (int i = 0; i < kNDown; ++i) {
         const int lvl = kNDown - 1 - i, oC = dC / 2, oH = dH * 2;
-        if ((rc = run_conv(g, s.dec[i], d, dC, bs, dH, dH, g->raw, st)) != LWG_OK) return rc;
-        if ((rc = run_apply(g, bs, oH, oH, oC, true, g->cat[lvl] + oC, 2 * oC, nullptr, 0, nullptr, 0, align, st)) != LWG_OK)
+        const bool last = i + 1 == kNDown;
+        // Where the consumer is the halo-resident bf16x3 kernel, a layer's InstanceNorm + ReLU is applied by that consumer as it
+        // loads its halo (ConvArgs::raw_in): the producer writes its raw output straight into the consumer's input buffer and
+        // no apply pass runs in between.  Transposed conv -> second half of cat[level]:
+        const bool skip_takes_raw = takes_raw_input(g, s.skip[i], g->cat[lvl], 2 * oC, bs, oH, oH, oC);
+        if ((rc = run_conv(g, s.dec[i], d, dC, bs, dH, dH, skip_takes_raw ? g->cat[lvl] + oC : g->raw, st, skip_takes_raw ? 2 * oC : 0,
+                           d_raw ? 0 : -1)) != LWG_OK)
             return rc;
-        if ((rc = run_conv(g, s.skip[i], g->cat[lvl], 2 * oC, bs, oH, oH, g->raw, st)) != LWG_OK) return rc;
-        if (i + 1 < kNDown) {
-            if ((rc = run_apply(g, bs, oH, oH, oC, true, g->sk[i], oC, nullptr, 0, nullptr, 0, align, st)) != LWG_OK)
+        if (!skip_takes_raw &&
+            (rc = run_apply(g, bs, oH, oH, oC, true, g->cat[lvl] + oC, 2 * oC, nullptr, 0, nullptr, 0, align, st)) != LWG_OK)
+            return rc;
+        // skipper conv over the whole cat buffer -> the next level's input (the last one's raw output feeds the heads)
+        const bool next_takes_raw = !last && takes_raw_input(g, s.dec[i + 1], g->sk[i], oC, bs, oH, oH, 0);
+        if ((rc = run_conv(g, s.skip[i], g->cat[lvl], 2 * oC, bs, oH, oH, next_takes_raw ? g->sk[i] : g->raw, st, 0,
+                           skip_takes_raw ? oC : -1)) != LWG_OK)
+            return rc;
+        if (!last) {
+            if (!next_takes_raw &&
+                (rc = run_apply(g, bs, oH, oH, oC, true, g->sk[i], oC, nullptr, 0, nullptr, 0, align, st)) != LWG_OK)
                 return rc;
             d = g->sk[i];
+            d_raw = next_takes_raw;
         }
         dC = oC;
         dH = oH;
