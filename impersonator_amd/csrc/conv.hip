@@ -1005,6 +1005,35 @@ template <int NHW, int B_CH, int Q, int QB, int NS, int HT = 7>
 struct HaloSched {
     static constexpr int nh(int t) { return t < HT ? NHW / HT + (t < NHW % HT ? 1 : 0) : 0; }   // halo pieces issued in tap t's stage
     static constexpr int tap_of(int k) { int t = 0; while (hstart(t + 1) <= k) ++t; return t; }    // tap in which piece k is issued
+    // MFMA slots ahead of the barrier that carry no DMA piece (RAW: where the conversion micro-steps ride)
+    static constexpr bool dma_at(int t, int q) { for (int p = 0; p < lps(t); ++p) if (pos(t, p) == q) return true; return false; }
+    static constexpr int nfree(int t, int q0) { int n = 0; for (int q = q0; q < QB; ++q) n += dma_at(t, q) ? 0 : 1; return n; }
+    // RAW: which of a piece's eight conversion micro-steps [first, last) ride in free slot `slot` (piece 0 or 1 of the stage).  The
+    // read (step 0) goes first and its first use two slots later: an in-order wave that waits for an LDS read does not issue
+    // MFMAs either.
+    static constexpr int conv_first(int nconv, int nslot, int slot, int piece) { return conv_range(nconv, nslot, slot, piece) / 16; }
+    static constexpr int conv_last(int nconv, int nslot, int slot, int piece) { return conv_range(nconv, nslot, slot, piece) % 16; }
+    static constexpr int conv_range(int nconv, int nslot, int slot, int piece) {   // first * 16 + last (no tables: everything folds)
+        if (nconv == 1) {
+            if (piece != 0) return 0;
+            if (nslot >= 7)   // {0} - - {1,2} {3,4} {5,6} {7}
+                return slot == 0 ? 0 * 16 + 1 : slot == 3 ? 1 * 16 + 3 : slot == 4 ? 3 * 16 + 5 : slot == 5 ? 5 * 16 + 7 : slot == 6 ? 7 * 16 + 8 : 0;
+            return slot == 0 ? 0 * 16 + 1 : slot == 2 ? 1 * 16 + 4 : slot == 3 ? 4 * 16 + 6 : slot == 4 ? 6 * 16 + 8 : 0;   // {0} - {1,2,3} {4,5} {6,7}
+        }
+        if (nslot >= 8) {     // A{0} B{0} A{1,2} B{1,2} A{3,4} B{3,4} A{5,6,7} B{5,6,7}
+            if (slot >= 8 || (slot & 1) != piece) return 0;
+            return (slot >> 1) == 0 ? 0 * 16 + 1 : (slot >> 1) == 1 ? 1 * 16 + 3 : (slot >> 1) == 2 ? 3 * 16 + 5 : 5 * 16 + 8;
+        }
+        if (slot == 0) return 0 * 16 + 1;   // A{0} B{0} | - | A{1,2,3} B{1,2,3} A{4..7} B{4..7}
+        if (slot < 2 || slot >= 6 || (slot & 1) != piece) return 0;
+        return slot < 4 ? 1 * 16 + 4 : 4 * 16 + 8;
+    }
+    static constexpr int free_index(int t, int q0, int q) {
+        if (q < q0 || q >= QB || dma_at(t, q)) return -1;
+        int n = 0;
+        for (int u = q0; u < q; ++u) n += dma_at(t, u) ? 0 : 1;
+        return n;
+    }
     static constexpr int hstart(int t) { int n = 0; for (int u = 0; u < t; ++u) n += nh(u); return n; }
     static constexpr int lps(int t) { return nh(t) + B_CH; }
     static constexpr int pos(int t, int p) { return (p + 1) * Q / lps(t) - 1; }              // piece p rides behind this MFMA
@@ -1045,10 +1074,10 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     static_assert(B_CH >= 1, "a weight chunk per wave");
     constexpr int TILES = WM * WN, Q = 6 * TILES, QB = Q * 3 / 4, NL = 2 * (WM + WN);
     constexpr int RPM = (NL + (Q - QB) - 1) / (Q - QB);
-    constexpr int HT = RAW ? 5 : 7;                // taps in whose stages the halo pieces of the next slice are issued
+    constexpr int HT = RAW ? 6 : 7;                // taps in whose stages the halo pieces of the next slice are issued
     using S = HaloSched<NHW, B_CH, Q, QB, NS, HT>;
     static_assert(S::hstart(9) == NHW && Q >= NHW / HT + 1 + B_CH, "halo pieces fit their taps, one piece per MFMA at most");
-    static_assert(!RAW || (NW % 2 == 0 && S::tap_of(NHW - 1) + 3 <= 7), "RAW: chunk parity per wave, conversions end by tap 7");
+    static_assert(!RAW || (NW % 2 == 0 && S::tap_of(NHW - 1) + 3 <= 8), "RAW: chunk parity per wave, conversions end ahead of the barrier of tap 8");
     // RAW: one dummy chunk behind the ring (duplicate pieces land there), then the raw channels' (scale, shift) of this image
     constexpr int DUMMY = BOFF + NS * BSTAGE;      // float offset
     constexpr int SSOFF = DUMMY + 8 * BK;
@@ -1153,28 +1182,36 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
     [[maybe_unused]] const int cv_hi = lr * 128 + (((cv_g >> 1) ^ cv_swz) << 4) + ((cv_g & 1) << 3);
     [[maybe_unused]] const int cv_lo = lr * 128 + (((4 + (cv_g >> 1)) ^ cv_swz) << 4) + ((cv_g & 1) << 3);
     [[maybe_unused]] const int cv_dummy = DUMMY * 4 + lane * 16;     // where the writes of lanes with nothing to convert go
-    struct Conv { float4 v, y; bf16x4_t h, l; };
-    [[maybe_unused]] Conv cv[2];
-    // step 0: read the raw 16 bytes; 1: normalise + ReLU; 2: hi terms; 3: lo terms; 4: write.  `live` = the lane's pixel is inside
-    // the image and the slice is a raw one (else the results go to the dummy chunk: no branch in the MFMA stream)
+    struct Conv { float4 v, y, hf; bf16x4_t h, l; int ahi, alo; };
+    [[maybe_unused]] Conv cvA, cvB;   // (two named objects, not an array: an index the front end cannot fold sends an array to scratch)
+    // Eight micro-steps per piece, a few instructions each, so that they can ride one by one behind consecutive MFMAs:
+    // 0 read the raw 16 bytes; 1, 2 normalise + ReLU; 3 hi terms; 4 hi terms back as floats; 5 lo terms; 6 where to write
+    // (`live` = the lane's pixel is inside the image and the slice is a raw one, else the dummy chunk: no branch in the MFMA
+    // stream); 7 write
     [[maybe_unused]] auto convert_step = [&](int j, Conv &c, int hs, int step, bool live) {
-        char *chunk = reinterpret_cast<char *>(smem) + (hs * HALO + (wave + NW * j) * 8 * BK) * 4;
+        const int chunk = (hs * HALO + (wave + NW * j) * 8 * BK) * 4;
+        char *base = reinterpret_cast<char *>(smem);
         if (step == 0) {
-            c.v = *reinterpret_cast<const float4 *>(chunk + cv_rd);
+            c.v = *reinterpret_cast<const float4 *>(base + chunk + cv_rd);
         } else if (step == 1) {
             c.y.x = fmaxf(fmaf(c.v.x, ssa.x, ssa.y), 0.f);
             c.y.y = fmaxf(fmaf(c.v.y, ssa.z, ssa.w), 0.f);
+        } else if (step == 2) {
             c.y.z = fmaxf(fmaf(c.v.z, ssb.x, ssb.y), 0.f);
             c.y.w = fmaxf(fmaf(c.v.w, ssb.z, ssb.w), 0.f);
-        } else if (step == 2) {
-            c.h[0] = (__bf16)c.y.x; c.h[1] = (__bf16)c.y.y; c.h[2] = (__bf16)c.y.z; c.h[3] = (__bf16)c.y.w;
         } else if (step == 3) {
-            c.l[0] = (__bf16)(c.y.x - (float)c.h[0]); c.l[1] = (__bf16)(c.y.y - (float)c.h[1]);
-            c.l[2] = (__bf16)(c.y.z - (float)c.h[2]); c.l[3] = (__bf16)(c.y.w - (float)c.h[3]);
+            c.h[0] = (__bf16)c.y.x; c.h[1] = (__bf16)c.y.y; c.h[2] = (__bf16)c.y.z; c.h[3] = (__bf16)c.y.w;
+        } else if (step == 4) {
+            c.hf = make_float4((float)c.h[0], (float)c.h[1], (float)c.h[2], (float)c.h[3]);
+        } else if (step == 5) {
+            c.l[0] = (__bf16)(c.y.x - c.hf.x); c.l[1] = (__bf16)(c.y.y - c.hf.y);
+            c.l[2] = (__bf16)(c.y.z - c.hf.z); c.l[3] = (__bf16)(c.y.w - c.hf.w);
+        } else if (step == 6) {
+            c.ahi = live ? chunk + cv_hi : cv_dummy;
+            c.alo = live ? chunk + cv_lo : cv_dummy + 8;
         } else {
-            char *base = reinterpret_cast<char *>(smem);
-            *reinterpret_cast<bf16x4_t *>(live ? chunk + cv_hi : base + cv_dummy) = c.h;
-            *reinterpret_cast<bf16x4_t *>(live ? chunk + cv_lo : base + cv_dummy + 8) = c.l;
+            *reinterpret_cast<bf16x4_t *>(base + c.ahi) = c.h;
+            *reinterpret_cast<bf16x4_t *>(base + c.alo) = c.l;
         }
     };
     // weight piece jb of reduction stage (tap it, slice is) into ring slot `slot`
@@ -1241,6 +1278,8 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
         int nxt_a[WM];
         // RAW: the chunks of slice sl+1 whose piece was issued three taps ago have landed (counted wait of tap T-1): normalise them
         // under this tap's MFMAs, ahead of its barrier
+        // (a slice that arrives in the split format -- the skip half of a decoder level's input -- runs the same instructions
+        // with every lane's result sent to the dummy chunk: separate stage bodies for it cost the compiler its register allocation)
         [[maybe_unused]] const bool raw_next = RAW && sl + 1 < nslices && (sl + 1) * BK >= a.raw_from;
         [[maybe_unused]] const unsigned live_bits = raw_next ? inside : 0u;
         if constexpr (RAW) {
@@ -1283,24 +1322,25 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
                 // the conversion of the pieces issued three taps ago, five steps per piece, one step behind each of the MFMAs ahead
                 // of the barrier (four steps where the stage has fewer than ten MFMAs there: the 64-channel tile)
                 constexpr int NCONV = T >= 3 ? S::nh(T - 3) : 0, K0 = T >= 3 ? S::hstart(T - 3) : 0;
-                constexpr int ST = QB >= 10 ? 5 : 4;
-                static_assert(NCONV <= 2 && NCONV * ST <= QB, "conversion steps fit ahead of the barrier");
-                if (q < NCONV * ST) {
-                    const int u = q / ST, step = q % ST;
-                    const bool live = (live_bits >> (K0 + u)) & 1u;
-                    if (ST == 5) {
-                        convert_step(K0 + u, cv[u], hs ^ 1, step, live);
-                    } else {   // 0: read, 1: normalise + hi, 2: lo, 3: write
-                        if (step == 0) convert_step(K0 + u, cv[u], hs ^ 1, 0, live);
-                        if (step == 1) { convert_step(K0 + u, cv[u], hs ^ 1, 1, live); convert_step(K0 + u, cv[u], hs ^ 1, 2, live); }
-                        if (step == 2) convert_step(K0 + u, cv[u], hs ^ 1, 3, live);
-                        if (step == 3) convert_step(K0 + u, cv[u], hs ^ 1, 4, live);
+                // ... behind the MFMAs that follow the pinned fragment reads of k-block 1 (q >= NL) where ten or more are left ahead
+                // of the barrier, else from the first one (the 64-channel tile)
+                constexpr int Q0 = QB - NL >= 10 ? NL : 0;
+                constexpr int NF = S::nfree(T, Q0);   // free MFMA slots
+                static_assert(NCONV <= 2 && NF >= (NCONV == 2 ? 6 : 5), "conversion steps fit ahead of the barrier");
+                const int fi = S::free_index(T, Q0, q);
+                if (NCONV > 0 && fi >= 0) {
+                    const int a0 = S::conv_first(NCONV, NF, fi, 0), a1 = S::conv_last(NCONV, NF, fi, 0);
+                    const int b0 = S::conv_first(NCONV, NF, fi, 1), b1 = S::conv_last(NCONV, NF, fi, 1);
+                    if (a1 > a0 || b1 > b0) {
+                        __builtin_amdgcn_sched_barrier(0);   // the micro-steps stay behind THIS MFMA: a handful of instructions per gap
+#pragma unroll
+                        for (int m = 0; m < 8; ++m)
+                            if (m >= a0 && m < a1) convert_step(K0, cvA, hs ^ 1, m, (live_bits >> K0) & 1u);
+#pragma unroll
+                        for (int m = 0; m < 8; ++m)
+                            if (m >= b0 && m < b1) convert_step(K0 + 1, cvB, hs ^ 1, m, (live_bits >> (K0 + 1)) & 1u);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    const bool rd = step == 0, wr = step == ST - 1;
-                    if (q >= NL) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    else if (wr) { __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); __builtin_amdgcn_sched_group_barrier(0x200, 2, 0); }
-                    else __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
                 }
             }
             if (ISSUE) {
@@ -1344,7 +1384,7 @@ __global__ __launch_bounds__(64 * (BMT / (32 * WM)) * (BN / (32 * WN))) void con
 #pragma unroll
             for (int j = 0; j < NHW; ++j)
 #pragma unroll
-                for (int step = 0; step < 5; ++step) convert_step(j, cv[0], 0, step, (inside >> j) & 1u);
+                for (int step = 0; step < 8; ++step) convert_step(j, cvA, 0, step, (inside >> j) & 1u);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
