@@ -43,12 +43,20 @@ class _ConvIN(object):
         return self.y
 
     def backward(self, dy, need_dx=True):
-        P, G = self.tr.P, self.tr.G
-        draw, dg, db = ops.instance_norm_backward(self.raw, self.y if self.relu else None, dy.contiguous(), self.stats, P[self.gkey])
-        G[self.gkey].add_(dg)
-        G[self.bkey].add_(db)
-        G[self.wkey].add_(ops.conv2d_backward_weight(self.x, draw, tuple(P[self.wkey].shape), self.stride, self.pad, self.transposed,
-                                                      precision=self.tr.conv_precision))
+        P, G, tr = self.tr.P, self.tr.G, self.tr
+        # a parameter's FIRST gradient contribution of an iteration is written straight into its slice of the flat gradient buffer
+        # (GeneratorTrainer.first_write); a further one (none today: every layer runs once per iteration) would be added
+        og, ob, ow = tr.first_write(self.gkey), tr.first_write(self.bkey), tr.first_write(self.wkey)
+        draw, dg, db = ops.instance_norm_backward(self.raw, self.y if self.relu else None, dy.contiguous(), self.stats, P[self.gkey],
+                                                  out_dgamma=og, out_dbeta=ob)
+        if og is None:
+            G[self.gkey].add_(dg)
+        if ob is None:
+            G[self.bkey].add_(db)
+        dw = ops.conv2d_backward_weight(self.x, draw, tuple(P[self.wkey].shape), self.stride, self.pad, self.transposed,
+                                        precision=self.tr.conv_precision, out=ow)
+        if ow is None:
+            G[self.wkey].add_(dw)
         if not need_dx:
             return None
         return ops.conv2d_backward_data(draw, P[self.wkey], tuple(self.x.shape), self.stride, self.pad, self.transposed,
@@ -94,7 +102,10 @@ class _Head(object):
         d8[..., 0:3] = d_img * (1 - self.img * self.img)
         if d_mask is not None:
             d8[..., 3:4] = d_mask * self.mask * (1 - self.mask)
-        G[self.key].add_(ops.heads_backward_weight(self.x, d8))
+        ow = self.tr.first_write(self.key)
+        dw = ops.heads_backward_weight(self.x, d8, out=ow)
+        if ow is None:
+            G[self.key].add_(dw)
         return ops.conv2d_backward_data(d8, P[self.key], tuple(self.x.shape), 1, 3)
 
 
@@ -183,6 +194,7 @@ class GeneratorTrainer(object):
         self.flat_g = torch.zeros(n, device=dev)
         self.flat_m = torch.zeros(n, device=dev)
         self.flat_v = torch.zeros(n, device=dev)
+        self._untouched = set()   # gradient slices nothing has been written to in the current backward pass (see first_write)
         self.P, self.G, off = {}, {}, 0
         for key, shape, parts in self.spec:
             cnt = int(torch.Size(shape).numel())
@@ -206,6 +218,14 @@ class GeneratorTrainer(object):
         self.bg_head = _Head(self, "heads:bg")
         self.src = _ResUnet(self, "src_model", self.repeat)
         self.tsf = _ResUnet(self, "tsf_model", self.repeat)
+
+    def first_write(self, key):
+        """The gradient slice of `key` if nothing has been written to it in this backward pass yet (then the kernel writes there
+        directly: no temporary, no add launch), else None (the caller accumulates)."""
+        if key in self._untouched:
+            self._untouched.discard(key)
+            return self.G[key]
+        return None
 
     # ------------------------------------------------------------------ parameters
     def state_dict(self):
@@ -273,6 +293,7 @@ class GeneratorTrainer(object):
     def backward(self):
         b, lam = self.b, self.lam
         self.flat_g.zero_()
+        self._untouched = set(self.G)
         to_nhwc = lambda t: t.permute(0, 2, 3, 1)
         src_img, src_mask, tsf_img, tsf_mask = self.src.img, self.src.mask, self.tsf.img, self.tsf.mask
         n = src_img.shape[0]

@@ -67,12 +67,23 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, transposed=False, prec
 
 
 @torch.no_grad()
-def conv2d_backward_weight(x, dy, w_shape, stride=1, pad=0, transposed=False, with_bias=False, precision="fp32"):
-    """Gradient wrt the weight (PyTorch layout `w_shape`) and, optionally, the bias."""
+def _out(out, shape, device):
+    """`out` when it is a usable destination (contiguous fp32 tensor of `shape` on `device`), else a fresh tensor."""
+    if out is None:
+        return torch.empty(tuple(shape), device=device, dtype=torch.float32)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != device:
+        raise ValueError("out= must be a contiguous fp32 tensor of shape %s on %s" % (tuple(shape), device))
+    return out
+
+
+@torch.no_grad()
+def conv2d_backward_weight(x, dy, w_shape, stride=1, pad=0, transposed=False, with_bias=False, precision="fp32", out=None):
+    """Gradient wrt the weight (PyTorch layout `w_shape`) and, optionally, the bias.  `out`: write dw there (e.g. the
+    parameter's slice of a flat gradient buffer) instead of into a fresh tensor."""
     _chk(x, dy)
     cin, cout = (w_shape[0], w_shape[1]) if transposed else (w_shape[1], w_shape[0])
     d = _desc(x.shape, cin, cout, w_shape[2], stride, pad, transposed, precision)
-    dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
+    dw = _out(out, w_shape, x.device)
     db = torch.empty(cout, device=x.device, dtype=torch.float32) if with_bias else None
     ws, nb = _ws(d, x.device)
     _lib.check(_lib.load().lwg_conv2d_backward_weight(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db),
@@ -103,13 +114,13 @@ def heads_forward(x, w):
 
 
 @torch.no_grad()
-def heads_backward_weight(x, dy8):
+def heads_backward_weight(x, dy8, out=None):
     """x (N,H,W,64), dy8 (N,H,W,8) (gradient wrt the pre-activation head outputs, channels 4-7 zero) -> dw (8,64,7,7)."""
     _chk(x, dy8)
     n, h, wd, c = x.shape
     if c != 64 or tuple(dy8.shape) != (n, h, wd, 8):
         raise RuntimeError("heads_backward_weight: x (N,H,W,64) and dy8 (N,H,W,8) expected")
-    dw = torch.empty((8, 64, 7, 7), device=x.device, dtype=torch.float32)
+    dw = _out(out, (8, 64, 7, 7), x.device)
     ws, nb = _heads_ws(n, h, wd, x.device)
     _lib.check(_lib.load().lwg_heads_backward_weight(_lib.ptr(x), _lib.ptr(dy8), n, h, wd, _lib.ptr(dw), _lib.ptr(ws), nb,
                                                      _lib.stream_ptr()))
@@ -130,13 +141,13 @@ def instance_norm_forward(x, gamma, beta, relu=False):
 
 
 @torch.no_grad()
-def instance_norm_backward(x, y, dy, stats, gamma):
+def instance_norm_backward(x, y, dy, stats, gamma, out_dgamma=None, out_dbeta=None):
     """-> (dx, dgamma, dbeta); pass y (the forward output) when the forward applied the ReLU, else None."""
     _chk(x, y, dy, stats, gamma)
     n, h, w, c = x.shape
     dx = torch.empty_like(x)
-    dgamma = torch.empty(c, device=x.device, dtype=torch.float32)
-    dbeta = torch.empty(c, device=x.device, dtype=torch.float32)
+    dgamma = _out(out_dgamma, (c,), x.device)
+    dbeta = _out(out_dbeta, (c,), x.device)
     scratch = torch.empty(_lib.load().lwg_instance_norm_scratch_bytes(n, h * w, c) // 8 + 1, device=x.device, dtype=torch.float64)
     _lib.check(_lib.load().lwg_instance_norm_backward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(dy), _lib.ptr(stats), _lib.ptr(gamma), n,
                                                       h * w, c, _lib.ptr(dx), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(scratch),
