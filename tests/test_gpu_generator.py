@@ -230,3 +230,30 @@ def test_fused_instance_norm_apply_is_bit_identical_to_the_apply_kernel(tmp_path
         assert p.returncode == 0, p.stderr[-3000:]
         out[v] = [l for l in p.stdout.splitlines() if l.startswith("HASH")][0]
     assert out["0"] == out["1"], out
+
+
+@pytest.mark.parametrize("size,bs", [(512, 2), (384, 1)])
+def test_generator_at_other_image_sizes(size, bs):
+    """The bf16x3 per-frame stream away from 256x256: 512 (sixteen 32-column tiles per row at the last level, the trunk on 64x64
+    maps) and 384 (48x48 trunk maps: not whole 32-column tiles, so the trunk takes the DMA-ring kernel and the un-fused apply
+    while the decoder's 96- to 384-wide levels take the halo kernel with the fused one) against the CPU oracle."""
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    sd = torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=0, affine="random"))
+    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, image_size=size, max_batch=bs, precision="bf16x3")
+    G.load_state_dict(sd)
+    G = G.cuda()
+    g = torch.Generator().manual_seed(size)
+    src = torch.rand(1, 6, size, size, generator=g) * 2 - 1
+    x = torch.rand(bs, 6, size, size, generator=g) * 2 - 1
+    T = torch.rand(bs, size, size, 2, generator=g) * 2.4 - 1.2
+    T[0, size // 4:size // 2, size // 8:size // 3] = -2
+    bg = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+    enc, res = G.encode_src(src.cuda())
+    pred, color, mask = G.inference(enc, res, x.cuda(), T.cuda(), bg_img=bg.cuda())
+    with torch.no_grad():
+        oenc, ores = torch_ref.encode_src(sd, src)
+        opred, ocolor, omask = torch_ref.imitator_forward(sd, oenc, ores, bg, x, T)
+    for name, a, b in (("pred", pred, opred), ("color", color, ocolor), ("mask", mask, omask)):
+        err = float((a.cpu() - b).abs().max())
+        assert err <= TOL_IMAGE, (size, name, err)
+    G.release()
