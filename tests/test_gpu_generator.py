@@ -194,42 +194,49 @@ def test_state_and_shape_errors(ctx):
         ctx["G"].encode_src(ctx["src_inputs"])   # CPU tensor: no silent fallback
 
 
-def test_fused_instance_norm_apply_is_bit_identical_to_the_apply_kernel(tmp_path):
+_FUSED_PROBE = (
+    "import hashlib, torch\n"
+    "from impersonator_amd.networks.generator import ImpersonatorGenerator\n"
+    "from oracle import torch_ref\n"
+    "from tests import helpers\n"
+    "def run():\n"
+    "    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, image_size=256, max_batch=8, precision='bf16x3')\n"
+    "    G.load_state_dict(torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=0, affine='random')))\n"
+    "    G = G.cuda()\n"
+    "    g = torch.Generator().manual_seed(21)\n"
+    "    src = torch.rand(1, 6, 256, 256, generator=g) * 2 - 1\n"
+    "    enc, res = G.encode_src(src.cuda())\n"
+    "    h = hashlib.sha256()\n"
+    "    for bs in (1, 3, 8):\n"
+    "        x = torch.rand(bs, 6, 256, 256, generator=g) * 2 - 1\n"
+    "        T = torch.rand(bs, 256, 256, 2, generator=g) * 2.4 - 1.2\n"
+    "        T[0, 60:140, 30:90] = -2\n"
+    "        bg = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1\n"
+    "        for t in G.inference(enc, res, x.cuda(), T.cuda(), bg_img=bg.cuda()):\n"
+    "            h.update(t.cpu().numpy().tobytes())\n"
+    "    G.release()\n"
+    "    return h.hexdigest()\n")
+
+
+def test_fused_instance_norm_apply_is_bit_identical_to_the_apply_kernel():
     """ConvArgs::raw_in (the consumer conv normalises + ReLUs + splits its raw input inside the halo, no apply pass in between:
-    six trunk layers and the whole decoder of the bf16x3 path) against the same pass with `apply_kernel` launches in between
-    (LWG_FUSED_APPLY=0, read once per process: two subprocesses): every output bit must agree, at batch 1, 3 and 8."""
-    import hashlib
+    six trunk layers and the whole decoder of the bf16x3 path; this process, the default) against the same pass with
+    `apply_kernel` launches in between (LWG_FUSED_APPLY=0 is read once per process: a subprocess): every output bit must agree,
+    at batch 1, 3 and 8."""
     import os
     import subprocess
     import sys
+    assert os.environ.get("LWG_FUSED_APPLY", "1") != "0", "this process must run the fused path"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import hashlib, torch\n"
-        "from impersonator_amd.networks.generator import ImpersonatorGenerator\n"
-        "from oracle import torch_ref\n"
-        "from tests import helpers\n"
-        "G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, image_size=256, max_batch=8, precision='bf16x3')\n"
-        "G.load_state_dict(torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=0, affine='random')))\n"
-        "G = G.cuda()\n"
-        "g = torch.Generator().manual_seed(21)\n"
-        "src = torch.rand(1, 6, 256, 256, generator=g) * 2 - 1\n"
-        "enc, res = G.encode_src(src.cuda())\n"
-        "h = hashlib.sha256()\n"
-        "for bs in (1, 3, 8):\n"
-        "    x = torch.rand(bs, 6, 256, 256, generator=g) * 2 - 1\n"
-        "    T = torch.rand(bs, 256, 256, 2, generator=g) * 2.4 - 1.2\n"
-        "    T[0, 60:140, 30:90] = -2\n"
-        "    bg = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1\n"
-        "    for t in G.inference(enc, res, x.cuda(), T.cuda(), bg_img=bg.cuda()):\n"
-        "        h.update(t.cpu().numpy().tobytes())\n"
-        "print('HASH', h.hexdigest())\n")
-    out = {}
-    for v in ("0", "1"):
-        env = dict(os.environ, LWG_FUSED_APPLY=v, PYTHONPATH=root)
-        p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-3000:]
-        out[v] = [l for l in p.stdout.splitlines() if l.startswith("HASH")][0]
-    assert out["0"] == out["1"], out
+    ns = {}
+    exec(_FUSED_PROBE, ns)
+    fused = ns["run"]()
+    p = subprocess.run([sys.executable, "-c", _FUSED_PROBE + "print('HASH', run())\n"], cwd=root,
+                       env=dict(os.environ, LWG_FUSED_APPLY="0", PYTHONPATH=root), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    unfused = [l for l in p.stdout.splitlines() if l.startswith("HASH")][0].split()[1]
+    assert fused == unfused, (fused, unfused)
 
 
 @pytest.mark.parametrize("size,bs", [(512, 2), (384, 1)])
