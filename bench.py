@@ -16,8 +16,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant implicit-GEMM conv kernel, algorithmic FLOP / HIP-event time of its launches, as a
                  fraction of the MFMA peak both ways (algorithmic and executed products); exact_fp32_mode has its own
   cpu_baseline : the CPU oracle (port of the reference's PyTorch path + C rasteriser) timed on this box's host cores
-  parity       : the timed pipeline re-run on 16 frames after the timed region and compared with the oracle; a failed
-                 check marks the line `"invalid"` and the process exits 1
+  parity       : the timed pipeline re-run on 16 frames after the timed region and compared with the oracle -- from the device's
+                 posed vertices (`linf`, `fim_mismatch`) and from theta with the oracle's own SMPL in fp64 (`theta_chain`: the
+                 whole chain on identical SMPL inputs); a failed check marks the line `"invalid"` and the process exits 1
+  rccl         : with a process group (N > 1, or LWG_FORCE_DIST=1): backend, communicator size, RCCL version, and an all-reduce
+                 of ones that must equal the rank count
   secondary    : after the timed region -- `swap`: Swapper.swap (BASELINE config 4, appearance transfer with the
                  two-stream Liquid Warping Block) at 256x256, one pair and eight pairs per launch sequence, with the
                  same HIP-event roofline pass; `train`: one G + D training iteration (config 5) at 512x512 batch 1

@@ -1,3 +1,4 @@
+# one rocprofv3 kernel trace of the bench steps on one lane + the per-layer table (tools/roofline_from_profiles.py): bash tools/trace_only.sh <tag>
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$1; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 BF="python $R/bench.py --lanes 1 --steps 16 --warmup 4 --settle-ms 0 --no-cpu-baseline --no-fp32-mode --no-secondary"
