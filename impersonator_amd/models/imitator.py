@@ -376,6 +376,8 @@ class Imitator(BaseModel):
 
     # ------------------------------------------------------------------ drivers (imitator.py:157-214)
     def _run_batches(self, tgt_smpls, cam_strategy, on_batch):
+        if len(tgt_smpls) == 0:      # the reference's loop over range(0) (imitator.py:166,196): nothing to do
+            return []
         smpls = torch.as_tensor(np.asarray(tgt_smpls), dtype=torch.float32).reshape(len(tgt_smpls), -1)
         bs = max(1, int(self._opt.batch_size))
         outputs = []

@@ -105,6 +105,8 @@ def imitate_sharded(imitator, tgt_smpls, batch, cam_strategy='smooth', rank=0, w
     gets the (H,W,3) frames of ALL ranks in frame order (None elsewhere).  `first_cam` is frame 0's camera on every
     rank (the reference discovers it at t == 0, imitator.py:243-244).  No data-path collective."""
     import numpy as np
+    if len(tgt_smpls) == 0:
+        return [] if rank == 0 else None
     smpls = torch.as_tensor(np.asarray(tgt_smpls), dtype=torch.float32).reshape(len(tgt_smpls), -1).cuda()
     n = smpls.shape[0]
     if cam_strategy == 'smooth' and n:

@@ -68,6 +68,30 @@ def test_inference_by_smpls_matches_oracle_and_is_batch_invariant(imi):
         assert k in info, k
 
 
+def test_empty_sequence_off_screen_and_full_frame_bodies(imi):
+    """Edge cases of the sequence drivers: no target frames at all; a target whose body is entirely outside the image (every
+    face-index pixel -1: cond is the background row, T the -2 sentinel, the warped source zero -- the generator still runs);
+    a body that covers most of the frame (camera scale 4: faces dozens of pixels wide); a ragged last batch.
+    All against the CPU oracle on the same vertices, 'copy' strategy so that the camera is the target's own."""
+    imitator, _, src_img, bg_img = imi
+    assert imitator.inference_by_smpls(np.zeros((0, 85), np.float32), cam_strategy="copy") == []
+    smpls = demo.synthetic_smpls(64, seed=0)[[3, 20, 41, 50, 60]].copy()      # batches of 4 + 1
+    smpls[1, 0:3] = (1.0, 5.0, 0.0)       # translated five image half-widths away: nothing on screen
+    smpls[3, 0:3] = (4.0, 0.0, 0.0)       # scaled up: the torso covers most of the frame
+    outs = imitator.inference_by_smpls(smpls, cam_strategy="copy")
+    assert len(outs) == 5
+    imitator.transfer_params_by_smpl(torch.from_numpy(smpls).cuda(), cam_strategy="copy", t=1)   # the geometry of all five at once
+    info = imitator.tsf_info
+    fim = info["fim"].cpu()
+    assert bool((fim[1] == -1).all()) and bool((info["T"][1] == -2).all()) and bool((info["tsf_img"][1] == 0).all())
+    assert int((fim[3] == -1).sum()) < 0.3 * fim[3].numel(), "the scaled-up body should cover most of the frame"
+    fr, pred = _oracle_frames(imitator, src_img, bg_img, info["verts"].cpu(), info["cam"].cpu())
+    assert torch.equal(fr["fim"], fim) and float((fr["T"] - info["T"].cpu()).abs().max()) <= 1e-6
+    got = np.stack(outs).transpose(0, 3, 1, 2)
+    err = np.abs(got - pred.numpy()).reshape(5, -1).max(1)
+    assert err.max() <= 1e-3, err
+
+
 def test_reference_call_sequence_and_camera_strategies(imi):
     imitator, _, _, _ = imi
     smpls = demo.synthetic_smpls(64, seed=0)
