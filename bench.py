@@ -284,7 +284,8 @@ def secondary_train(steps=3):
     out = {}
     for name, (n, s) in (("512x512_batch1", (1, 512)), ("256x256_batch4", (4, 256))):
         r = bench_train.measure(n, s, steps=steps, warmup=2, precision="bf16x3")
-        out[name] = {"ms_per_iteration": r["ms_per_iteration"], "images_per_s": r["images_per_s"]}
+        out[name] = {"ms_per_iteration": r["ms_per_iteration"], "images_per_s": r["images_per_s"],
+                     "conv_gflop_per_iteration": r["conv_gflop_per_iteration"], "conv_tflops": r["conv_tflops"]}
         torch.cuda.empty_cache()
     out["what"] = ("G update (three streams forward, losses adv + L1 + mask, hand-written backward, Adam) + D update; "
                    "bf16x3 generator convolutions, fp32 elsewhere; 1 GPU, no all-reduce")

@@ -46,6 +46,39 @@ def build(batch, image_size, precision="bf16x3", script_loss=False, seed=0):
     return model
 
 
+def conv_gflop_per_iteration(batch, image_size, repeat=6):
+    """Algorithmic work of the convolutions of one training iteration (2 * output pixels * Cout * taps * Cin per conv, real taps and
+    channels), in GFLOP.  Forward of one image: the two ResUnets (networks/generator.py:68-184: 7x7 stem, three stride-2 convs, 2 x
+    `repeat` trunk convs, three transposed convs, three skipper convs on the concatenated maps, 7x7 heads with 3 + 1 outputs) and
+    the BGNet (generator.py:23-65: the same without skippers, 4 input channels, 3 outputs).  A training iteration runs every conv
+    three times (forward, data gradient, weight gradient) on `batch` images; the PatchGAN discriminator (networks/discriminator.py:
+    8-57: 4x4 convs 6-64-128-256-512 stride 2, 512-512 and 512-1 stride 1) runs forward + both gradients on 2 x batch images for
+    its own update and forward + data gradient on `batch` images for the generator's adversarial term.  Loss networks (--script-loss)
+    are not counted."""
+    s = float(image_size)
+
+    def conv(cin, cout, k, out_edge):
+        return 2.0 * out_edge * out_edge * cout * k * k * cin
+
+    def unet(cin, heads_out, skippers):
+        f = conv(cin, 64, 7, s)
+        for i in range(3):
+            f += conv(64 << i, 128 << i, 3, s / (2 << i))
+        f += 2 * repeat * conv(512, 512, 3, s / 8)
+        for i in range(3):
+            c = 512 >> i
+            f += 2.0 * (s / (8 >> i)) ** 2 * (c // 2) * 9 * c        # ConvTranspose2d: 9 taps per INPUT pixel over its four phases
+            if skippers:
+                f += conv(c, c // 2, 3, s / (4 >> i))
+        return f + conv(64, heads_out, 7, s)
+
+    g_fwd = 2 * unet(6, 4, True) + unet(4, 3, False)
+    e = s / 2
+    d_fwd = conv(6, 64, 4, e) + conv(64, 128, 4, e / 2) + conv(128, 256, 4, e / 4) + conv(256, 512, 4, e / 8) + \
+        conv(512, 512, 4, e / 8 - 1) + conv(512, 1, 4, e / 8 - 2)
+    return (3.0 * batch * g_fwd + 3.0 * 2 * batch * d_fwd + 2.0 * batch * d_fwd) / 1e9
+
+
 def measure(batch, image_size, steps=5, warmup=1, precision="bf16x3", script_loss=False):
     """-> dict(ms_per_iteration, images_per_s, ...) of `steps` optimize_parameters() calls after `warmup`; under an
     initialised multi-rank group: max over ranks, images of all ranks."""
@@ -64,6 +97,11 @@ def measure(batch, image_size, steps=5, warmup=1, precision="bf16x3", script_los
            "world": world, "image_size": image_size,
            "dtype": "f32" if precision == "fp32" else "bf16x3 generator convs (forward, data and weight gradient) + f32",
            "loss": "train_iPER.sh (mask_bce, vgg, face)" if script_loss else "adv + L1 + mask",
+           "conv_gflop_per_iteration": round(conv_gflop_per_iteration(batch, image_size), 1),
+           "conv_tflops": round(world * conv_gflop_per_iteration(batch, image_size) / dt / 1e3, 1),
+           "conv_tflops_note": "algorithmic conv work (forward + data gradient + weight gradient of the three generator streams, the "
+                               "discriminator update and the adversarial term) / iteration time; the bf16x3 kernels' ceiling is "
+                               "833 TFLOP/s algorithmic (three products per multiply-add), fp32's 157",
            "losses": {k: round(v, 6) for k, v in losses.items()}}
     if world > 1:
         # the two collectives of an iteration on their own: the same buffers, the same call
