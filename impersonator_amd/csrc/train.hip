@@ -13,6 +13,7 @@
 // the weight gradient is its own MFMA kernel below.  Parameters, gradients and Adam moments live in flat device
 // buffers in the forward-matrix layout [Cout][tap][Cin]; the gradient buffer is what a data-parallel job all-reduces
 // (27.8 MB for the reference's n_layers = 4, ndf = 64), through torch.distributed/RCCL on the Python side.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -176,6 +177,42 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restr
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
     out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void reduce_slices4_kernel(const float4 *__restrict__ part, int S, long n4, float4 *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);   // the same sums in the same order as reduce_slices_kernel, four at a time
+    for (int k = 0; k < S; ++k) {
+        const float4 v = part[(size_t)k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[i] = s;
+}
+
+// partials [slice][tap][co][ci] (wgrad_row3_bf16x3_kernel) -> out in the (co, ci, tap) or (co, tap, ci) layout; slices summed in
+// order.  A block owns 64 consecutive (co, ci) pairs: thread (pair, tl) sums taps tl, tl + 4, tl + 8 -- coalesced reads along the
+// pairs -- and the 64 x 9 sums leave through LDS as one contiguous run of the (co, ci, tap) layout.
+__global__ __launch_bounds__(256) void reduce_taps_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int oihw,
+                                                          float *__restrict__ out)
+{
+    __shared__ float sm[64 * 9];
+    const long n = (long)Cout * Cin, pair0 = (long)blockIdx.x * 64;
+    const int pl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const long pair = pair0 + pl;
+    for (int t = tl; t < 9; t += 4) {
+        float sum = 0.f;
+        if (pair < n)
+            for (int k = 0; k < S; ++k) sum += part[((size_t)k * 9 + t) * n + pair];
+        if (oihw) sm[pl * 9 + t] = sum;
+        else if (pair < n) out[((size_t)(pair / Cin) * 9 + t) * Cin + pair % Cin] = sum;
+    }
+    if (!oihw) return;
+    __syncthreads();
+    const long total = n * 9;
+    for (int i = threadIdx.x; i < 64 * 9; i += 256)
+        if (pair0 * 9 + i < total) out[pair0 * 9 + i] = sm[i];
 }
 
 // ---- weight gradient on the fp32 matrix cores:  dW[co][tap][ci] = sum_p dY[p][co] * X[pix(p, tap)][ci].
@@ -473,6 +510,300 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const float *__res
     }
 }
 
+typedef __bf16 bf16x2w_t __attribute__((ext_vector_type(2)));
+// two fp32 values -> their bf16 hi terms and lo terms, each pair packed in a dword (first value in the low half)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo)
+{
+    bf16x2w_t h;
+    h[0] = (__bf16)a;
+    h[1] = (__bf16)b;
+    hi = __builtin_bit_cast(unsigned, h);
+    bf16x2w_t l;
+    l[0] = (__bf16)(a - __builtin_bit_cast(float, hi << 16));
+    l[1] = (__bf16)(b - __builtin_bit_cast(float, hi & 0xffff0000u));
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ float quad_ch(const float4 &v, int ch) { return ch == 0 ? v.x : ch == 1 ? v.y : ch == 2 ? v.z : v.w; }
+
+// ---- 3x3 / stride 1 / pad 1 layers (the trunk and the skippers: nine tenths of the generator's weight-gradient arithmetic):
+// ONE KERNEL ROW -- three taps -- per workgroup.  wgrad_bf16x3_kernel streams both operand tiles once per tap, every tile
+// of the other operand and every slice: a 128x128 tile gets 32 flop per byte it loads, the working set (X and dY, 16 MiB on
+// the trunk at batch 4) does not fit an XCD's 4 MiB L2, and the launch runs at the fabric's rate (594 MB in 121 us) with
+// the matrix pipe a fifth busy.  Here
+//   * a step is 32 pixels of ONE output row (Wo % 32 == 0): dY's tile is loaded and split once for the three taps, X's
+//     once with a one-pixel apron -- a loader thread fetches pixels 8*blk-1 .. 8*blk+8 of its channels and writes the
+//     three 8-pixel windows the taps need (the MFMA's reduction index must be the same pixel in both operands, so each
+//     tap gets its own shifted copy in LDS); 26 KB loaded per 3 x 0.52 Mflop (128 x 64 tile) instead of 96 KB per 3 x 1.05;
+//   * work items are ordered (slice, co tile, ci tile, kernel row) and dealt to the XCDs in contiguous runs (a 1-D grid is
+//     dispatched round-robin over the eight XCDs), so an XCD's workgroups share a pixel slice and its L2 holds what
+//     they re-read;
+//   * the LDS image is wgrad_bf16x3_kernel's, with bit 0 of the row index XORed by the loader's channel-group parity: a
+//     loader's 16 lanes write rows C apart -- all even or all odd, i.e. one half of the banks -- and the flip sends every
+//     other one to the other half;
+//   * loader items are sized per operand so that every SIMD converts: CA / CB channels x 8 (+2) pixels per thread,
+//     (TA / CA + TB / CB) * 4 items;
+//   * the big tiles run EIGHT waves (128 x 128 x 3 taps needs 128 KiB of LDS, one workgroup per CU): two waves per SIMD,
+//     one splitting dY and one splitting X, each other's conversions under each other's MFMAs.  (Four waves of a
+//     128 x 64 tile, 80 KiB, do not get a second workgroup beside them: 1.8 us per step alone against 0.64 of MFMAs.)
+// TA x TB = co x ci tile on WGM x WGN waves; accumulators 3 x (TA / 32 WGM) x (TB / 32 WGN) x 16 per lane.
+
+template <int TA, int TB, int CA, int CB, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, (2 * (TA + 3 * TB) * 256 <= 160 * 1024) ? 2 : 1)
+void wgrad_row3_bf16x3_kernel(const float *__restrict__ dy, int Cout, const float *__restrict__ x, int Cin, int N, int H, int W,
+                              long px_per_slice, int S, float *__restrict__ out, int oihw)
+{
+    constexpr int NT = 64 * WGM * WGN;                    // WGM x WGN waves of (TA / WGM) x (TB / WGN) outputs per tap
+    constexpr int TWA = TA / (32 * WGM), TWB = TB / (32 * WGN);
+    constexpr int QA = TA / CA, QB = TB / CB;             // channel groups per operand tile
+    constexpr int SA = CA == 4 ? 2 : 1, SB = CB == 4 ? 2 : 1;   // log2 of the group sizes
+    constexpr int OPA = TA * 128, OPB = TB * 128;         // bytes of an operand tile in LDS
+    constexpr int BUF = OPA + 3 * OPB;
+    static_assert((CA == 2 || CA == 4) && (CB == 2 || CB == 4) && (QA + QB) * 4 <= NT && (QA * 4) % 64 == 0, "loader items");
+    static_assert(TWA >= 1 && TWB >= 1 && 2 * BUF <= 160 * 1024, "tile");
+    extern __shared__ __attribute__((aligned(16))) char wsb[];   // [2 buffers][dY | X tap 0 | X tap 1 | X tap 2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // work item of this workgroup: XCD c = blockIdx.x % 8 owns items [c * chunk, (c + 1) * chunk)
+    const int tiles_ci = Cin / TB, tiles_co = Cout / TA;
+    const int units = tiles_ci * tiles_co * 3 * S, chunk = (units + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || item >= units) return;
+    const int kh = item % 3, ci0 = (item / 3) % tiles_ci * TB, co0 = (item / (3 * tiles_ci)) % tiles_co * TA;
+    const int slice = item / (3 * tiles_ci * tiles_co);
+    const long P = (long)N * H * W;
+    const long p0 = slice * px_per_slice, p1 = p0 + px_per_slice < P ? p0 + px_per_slice : P;
+    const int K = (int)((p1 - p0) / WG_PX);               // whole steps: P and the slices are multiples of 32 pixels
+
+    // loader roles (wave-uniform): threads [0, 4 QA) one dY item each, [4 QA, 4 QA + 4 QB) one X item, the rest none
+    const int role = tid < 4 * QA ? 0 : (tid < 4 * (QA + QB) ? 1 : 2);
+    const int idx = role == 1 ? tid - 4 * QA : tid;
+    const int q = role == 1 ? idx % QB : idx % QA, blk = role == 1 ? idx / QB : idx / QA;
+    // position of the next step to load: image ln, row loh, first column low (a multiple of 32)
+    int ln = (int)(p0 / ((long)H * W)), loh, low;
+    {
+        const int rem = (int)(p0 - (long)ln * H * W);
+        loh = rem / W;
+        low = rem - loh * W;
+    }
+    auto advance = [&]() {   // branch-free: a step's loads, MFMAs and conversions stay one scheduling region
+        low += WG_PX;
+        const bool row_end = low == W;
+        low = row_end ? 0 : low;
+        loh += row_end ? 1 : 0;
+        const bool img_end = loh == H;
+        loh = img_end ? 0 : loh;
+        ln += img_end ? 1 : 0;
+    };
+    // r[0..7] (dY: pixels 8*blk .. +7) or r[0..9] (X: pixels 8*blk-1 .. 8*blk+8 of input row loh + kh - 1).
+    // Out-of-image pixels (X only: the apron's first / last pixel at the ends of a row, a whole row above or below the image)
+    // are fetched from the tensor's first element and zeroed AFTER the split, by masks on the packed pairs (m.x: pixels 0-1,
+    // m.y: pixels 2-7, m.z: pixels 8-9) -- nothing between a load and its use one step later touches the registers, so
+    // the loads stay in flight across the MFMAs.  The loader role is a template argument of the whole main loop (run_role
+    // below), not a branch inside it: with a branch the values meet in phi copies right behind the loads and the in-order
+    // memory counter has to be waited down to zero there.
+    auto fetch = [&](auto c_tag, const float *src) -> float4 {
+        if constexpr (decltype(c_tag)::value == 4) {
+            return ld4(src);
+        } else {
+            const float2 v2 = *reinterpret_cast<const float2 *>(src);
+            return make_float4(v2.x, v2.y, 0.f, 0.f);
+        }
+    };
+    auto load = [&](auto role_tag, float4 (&r)[10], uint3 &m) {
+        constexpr int ROLE = decltype(role_tag)::value;
+        if constexpr (ROLE == 0) {
+            unsigned off = ((unsigned)(ln * H + loh) * (unsigned)W + (unsigned)(low + 8 * blk)) * (unsigned)Cout + (unsigned)(co0 + CA * q);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                r[i] = fetch(std::integral_constant<int, CA>{}, dy + off);
+                off += (unsigned)Cout;
+            }
+        } else if constexpr (ROLE == 1) {
+            const int ih = loh + kh - 1, iw0 = low + 8 * blk - 1;
+            const bool row_ok = (unsigned)ih < (unsigned)H;
+            const unsigned base = ((unsigned)(ln * H + (row_ok ? ih : 0)) * (unsigned)W) * (unsigned)Cin + (unsigned)(ci0 + CB * q);
+            m.y = row_ok ? 0xffffffffu : 0u;
+            m.x = iw0 < 0 ? (m.y & 0xffff0000u) : m.y;
+            m.z = iw0 + 9 >= W ? (m.y & 0x0000ffffu) : m.y;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const bool ok = row_ok && (unsigned)(iw0 + i) < (unsigned)W;
+                r[i] = fetch(std::integral_constant<int, CB>{}, x + (ok ? base + (unsigned)(iw0 + i) * (unsigned)Cin : 0u));
+            }
+        }
+        advance();
+    };
+    // physical LDS row of logical row `row` of a tile written in groups of 1 << cs channels (see above) and the 16-byte slot
+    // swizzle of wgrad_bf16x3_kernel on it
+    auto lds_at = [&](int buf, int tile_off, int row, int col, int cs) -> char * {
+        const int pr = row ^ ((row >> cs) & 1);
+        return wsb + buf * BUF + tile_off + pr * 128 + ((col ^ wg_swz(pr)) * 16);
+    };
+    auto store = [&](auto role_tag, const float4 (&r)[10], const uint3 &m, int buf) {
+        constexpr int ROLE = decltype(role_tag)::value;
+        if constexpr (ROLE == 0) {
+#pragma unroll
+            for (int ch = 0; ch < CA; ++ch) {
+                uint4 hv, lv;
+                split_pair(quad_ch(r[0], ch), quad_ch(r[1], ch), hv.x, lv.x);
+                split_pair(quad_ch(r[2], ch), quad_ch(r[3], ch), hv.y, lv.y);
+                split_pair(quad_ch(r[4], ch), quad_ch(r[5], ch), hv.z, lv.z);
+                split_pair(quad_ch(r[6], ch), quad_ch(r[7], ch), hv.w, lv.w);
+                *reinterpret_cast<uint4 *>(lds_at(buf, 0, CA * q + ch, blk, SA)) = hv;
+                *reinterpret_cast<uint4 *>(lds_at(buf, 0, CA * q + ch, 4 + blk, SA)) = lv;
+            }
+        } else if constexpr (ROLE == 1) {
+#pragma unroll
+            for (int ch = 0; ch < CB; ++ch) {
+                // pixels (0,1) (2,3) (4,5) (6,7) (8,9) as packed pairs; the odd-aligned pairs (1,2) .. (7,8) by funnel shifts
+                unsigned h0, h1, h2, h3, h4, l0, l1, l2, l3, l4;
+                split_pair(quad_ch(r[0], ch), quad_ch(r[1], ch), h0, l0);
+                split_pair(quad_ch(r[2], ch), quad_ch(r[3], ch), h1, l1);
+                split_pair(quad_ch(r[4], ch), quad_ch(r[5], ch), h2, l2);
+                split_pair(quad_ch(r[6], ch), quad_ch(r[7], ch), h3, l3);
+                split_pair(quad_ch(r[8], ch), quad_ch(r[9], ch), h4, l4);
+                h0 &= m.x; l0 &= m.x; h1 &= m.y; l1 &= m.y; h2 &= m.y; l2 &= m.y; h3 &= m.y; l3 &= m.y; h4 &= m.z; l4 &= m.z;
+                // tap kw pairs output pixel j with input pixel j + kw - 1 = r[j + kw]
+                const uint4 hv0 = make_uint4(h0, h1, h2, h3), lv0 = make_uint4(l0, l1, l2, l3);
+                const uint4 hv1 = make_uint4(__builtin_amdgcn_alignbit(h1, h0, 16), __builtin_amdgcn_alignbit(h2, h1, 16),
+                                             __builtin_amdgcn_alignbit(h3, h2, 16), __builtin_amdgcn_alignbit(h4, h3, 16));
+                const uint4 lv1 = make_uint4(__builtin_amdgcn_alignbit(l1, l0, 16), __builtin_amdgcn_alignbit(l2, l1, 16),
+                                             __builtin_amdgcn_alignbit(l3, l2, 16), __builtin_amdgcn_alignbit(l4, l3, 16));
+                const uint4 hv2 = make_uint4(h1, h2, h3, h4), lv2 = make_uint4(l1, l2, l3, l4);
+                *reinterpret_cast<uint4 *>(lds_at(buf, OPA, CB * q + ch, blk, SB)) = hv0;
+                *reinterpret_cast<uint4 *>(lds_at(buf, OPA, CB * q + ch, 4 + blk, SB)) = lv0;
+                *reinterpret_cast<uint4 *>(lds_at(buf, OPA + OPB, CB * q + ch, blk, SB)) = hv1;
+                *reinterpret_cast<uint4 *>(lds_at(buf, OPA + OPB, CB * q + ch, 4 + blk, SB)) = lv1;
+                *reinterpret_cast<uint4 *>(lds_at(buf, OPA + 2 * OPB, CB * q + ch, blk, SB)) = hv2;
+                *reinterpret_cast<uint4 *>(lds_at(buf, OPA + 2 * OPB, CB * q + ch, 4 + blk, SB)) = lv2;
+            }
+        }
+    };
+    f32x16 acc[3][TWA][TWB];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < TWA; ++i)
+#pragma unroll
+            for (int j = 0; j < TWB; ++j)
+#pragma unroll
+                for (int r2 = 0; r2 < 16; ++r2) acc[t][i][j][r2] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int col = 2 * kb + (lane >> 5);
+            bf16x8_t ah[TWA], al[TWA];
+#pragma unroll
+            for (int i = 0; i < TWA; ++i) {
+                const int row = (wm * TWA + i) * 32 + (lane & 31);
+                ah[i] = *reinterpret_cast<const bf16x8_t *>(lds_at(buf, 0, row, col, SA));
+                al[i] = *reinterpret_cast<const bf16x8_t *>(lds_at(buf, 0, row, 4 + col, SA));
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                bf16x8_t bh[TWB], bl[TWB];
+#pragma unroll
+                for (int j = 0; j < TWB; ++j) {
+                    const int row = (wn * TWB + j) * 32 + (lane & 31);
+                    bh[j] = *reinterpret_cast<const bf16x8_t *>(lds_at(buf, OPA + t * OPB, row, col, SB));
+                    bl[j] = *reinterpret_cast<const bf16x8_t *>(lds_at(buf, OPA + t * OPB, row, 4 + col, SB));
+                }
+                // small terms first; tiles inside a product, so consecutive MFMAs do not share an accumulator
+#pragma unroll
+                for (int i = 0; i < TWA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TWB; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TWA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TWB; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TWA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TWB; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[t][i][j], 0, 0, 0);
+            }
+        }
+    };
+    // pipeline as wgrad_bf16x3_kernel: step k multiplies buffer k & 1, the loads of step k + 2 fly, step k + 1 is split and
+    // written to the other buffer behind the MFMAs
+    // pipeline: step k multiplies LDS buffer k & 1 while the loads of step k + 2 fly into one register set and step k + 1,
+    // already in the other, is split and written to the other buffer.  Every wave leaves the barrier in the same phase, so
+    // "MFMAs, then conversions" in all of them leaves the matrix pipe idle while a SIMD's waves convert (measured: 3 us per
+    // step of 1.3 us of MFMAs).  The X loaders therefore split FIRST and multiply second, the others the other way round:
+    // a SIMD of the eight-wave tiles holds one wave of each kind, each converting under the other's MFMAs.
+    auto run_role = [&](auto role_tag) {
+        constexpr bool SPLIT_FIRST = decltype(role_tag)::value == 1;
+        float4 r0[10], r1[10];
+        uint3 m0 = make_uint3(0u, 0u, 0u), m1 = m0;
+        auto work = [&](const float4 (&rnext)[10], const uint3 &mnext, int kk, bool do_store) {
+            if (SPLIT_FIRST) {
+                if (do_store) store(role_tag, rnext, mnext, (kk + 1) & 1);
+                compute(kk & 1);
+            } else {
+                compute(kk & 1);
+                if (do_store) store(role_tag, rnext, mnext, (kk + 1) & 1);
+            }
+        };
+        int k = 0;
+        if (K >= 4) {   // steady state without a condition between a load and its use
+            load(role_tag, r0, m0);
+            store(role_tag, r0, m0, 0);
+            load(role_tag, r1, m1);
+            __syncthreads();
+            for (; k + 3 < K; k += 2) {
+                load(role_tag, r0, m0);
+                work(r1, m1, 0, true);
+                __syncthreads();
+                load(role_tag, r1, m1);
+                work(r0, m0, 1, true);
+                __syncthreads();
+            }
+        } else {
+            if (K > 0) {
+                load(role_tag, r0, m0);
+                store(role_tag, r0, m0, 0);
+                if (K > 1) load(role_tag, r1, m1);
+            }
+            __syncthreads();
+        }
+        auto step = [&](float4 (&rload)[10], uint3 &mload, const float4 (&rnext)[10], const uint3 &mnext, int kk) {
+            if (kk + 2 < K) load(role_tag, rload, mload);
+            work(rnext, mnext, kk, kk + 1 < K);
+            __syncthreads();
+        };
+        for (; k < K; k += 2) {   // the last two or three steps (k is even: buffer 0 holds step k, r1 step k + 1)
+            step(r0, m0, r1, m1, k);
+            if (k + 1 < K) step(r1, m1, r0, m0, k + 1);
+        }
+    };
+    // (wave-uniform: every wave meets the same number of barriers whichever copy of the loop it runs)
+    if (role == 0) run_role(std::integral_constant<int, 0>{});
+    else if (role == 1) run_role(std::integral_constant<int, 1>{});
+    else run_role(std::integral_constant<int, 2>{});
+    // S == 1: the gradient itself, in the caller's layout.  S > 1: this slice's partial as [tap][co][ci] -- a wave's 32
+    // ci lanes store 128 contiguous bytes (in the (co, ci, tap) layout of the result every lane would touch its own cache
+    // line: a quarter of this kernel's time went there) -- and reduce_taps_kernel writes the caller's layout.
+    float *o = out + (size_t)slice * Cout * 9 * Cin;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int tap = kh * 3 + t;
+#pragma unroll
+        for (int j = 0; j < TWB; ++j) {
+            const int ci = ci0 + (wn * TWB + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TWA; ++i)
+#pragma unroll
+                for (int r2 = 0; r2 < 16; ++r2) {
+                    const int co = co0 + (wm * TWA + i) * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * (lane >> 5);
+                    const size_t at = S > 1 ? ((size_t)tap * Cout + co) * Cin + ci
+                                            : (oihw ? ((size_t)co * Cin + ci) * 9 + tap : ((size_t)co * 9 + tap) * Cin + ci);
+                    o[at] = acc[t][i][j][r2];
+                }
+        }
+    }
+}
+
 // launcher: picks the tile, the pixel slices (split-K) and the partial buffer.  `part` must hold 32 * Cout*ntaps*Cin floats
 // (at most 32 slices); the result lands in `out`.
 int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin, int Win, int Hg, int Wg, int stride, int pad,
@@ -480,6 +811,68 @@ int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin,
 {
     const long P = (long)N * Hg * Wg;
     const size_t w_floats = (size_t)O * ntaps * I;
+    auto reduce = [&](long S) -> int {
+        if (S > 1) {
+            if (w_floats % 4 == 0) reduce_slices4_kernel<<<ceil_div((long)(w_floats / 4), 256), 256, 0, st>>>(
+                reinterpret_cast<const float4 *>(part), (int)S, (long)(w_floats / 4), reinterpret_cast<float4 *>(out));
+            else reduce_slices_kernel<<<ceil_div((long)w_floats, 256), 256, 0, st>>>(part, (int)S, (long)w_floats, out);
+            LWG_LAUNCH_CHECK("reduce_slices_kernel");
+        }
+        return LWG_OK;
+    };
+    // 3x3 / stride 1 / pad 1 on whole 32-pixel row segments: one kernel row per workgroup (wgrad_row3_bf16x3_kernel)
+    static const char *row3_env = getenv("LWG_WGRAD_ROW3");   // "0": the per-tap kernel everywhere (A/B switch)
+    if (precision == 1 && stride == 1 && pad == 1 && KWd == 3 && ntaps == 9 && Hin == Hg && Win == Wg && Wg % WG_PX == 0 &&
+        O % 64 == 0 && I % 64 == 0 && !(row3_env && row3_env[0] == '0')) {
+        static const char *s_env = getenv("LWG_WGRAD_ROW3_SLICES");  // force the slice count (measurement)
+        const int TA = O % 128 == 0 ? 128 : 64, TB = I % 128 == 0 ? 128 : 64;
+        const int nwaves = TB == 128 ? 8 : 4;
+        const size_t lds = (size_t)2 * (TA + 3 * TB) * 128;
+        const long units = (long)(O / TA) * (I / TB) * 3, slots = (long)device_cu_count() * (lds <= 80 * 1024 - 4096 ? 2 : 1);
+        // a step is 3 x (TA x TB / 1024 / waves) x 6 MFMAs of 32 cycles per wave, the waves (and workgroups) of a SIMD
+        // share its pipe; a slice costs its partial's trip through reduce_slices
+        const double step_us = (slots / device_cu_count()) * (nwaves / 4) * 3.0 * (TA * TB / 1024 / nwaves) * 6 * 32 / 1800.0;
+        const double slice_us = (double)w_floats * 4 / 5e6;
+        long cap = (long)(part_floats / w_floats);
+        if (cap > kWgradMaxSlices) cap = kWgradMaxSlices;
+        if (cap > P / WG_PX) cap = P / WG_PX;
+        if (cap < 1) cap = 1;
+        long S = 1, per = P;
+        double best = -1.;
+        for (long s2 = 1; s2 <= cap; ++s2) {
+            const long ps = ceil_div(ceil_div(P, s2), WG_PX) * (long)WG_PX;
+            const long se = ceil_div(P, ps);
+            const double cost = (double)ceil_div(units * se, slots) * (ps / WG_PX + 3) * step_us + (se > 1 ? 3. + (se + 1) * slice_us : 0.);
+            if (best < 0 || cost < best) { best = cost; S = se; per = ps; }
+        }
+        if (s_env && atol(s_env) >= 1 && atol(s_env) <= cap) {
+            per = ceil_div(ceil_div(P, atol(s_env)), WG_PX) * (long)WG_PX;
+            S = ceil_div(P, per);
+        }
+        float *wout = S == 1 ? out : part;
+        const unsigned grid = 8u * (unsigned)ceil_div(units * S, 8);
+        auto run = [&](auto kern, DeviceOnce &once) -> int {
+            if (!once.done()) {
+                LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                once.mark();
+            }
+            kern<<<grid, 64 * nwaves, lds, st>>>(go, O, in, I, N, Hg, Wg, per, (int)S, wout, oihw);
+            return LWG_OK;
+        };
+        static DeviceOnce once[4];
+        int rc;
+        if (TA == 128 && TB == 128) rc = run(&wgrad_row3_bf16x3_kernel<128, 128, 2, 2, 2, 4>, once[0]);
+        else if (TB == 128) rc = run(&wgrad_row3_bf16x3_kernel<64, 128, 2, 2, 2, 4>, once[1]);
+        else if (TA == 128) rc = run(&wgrad_row3_bf16x3_kernel<128, 64, 4, 2, 2, 2>, once[2]);
+        else rc = run(&wgrad_row3_bf16x3_kernel<64, 64, 2, 2, 2, 2>, once[3]);
+        if (rc != LWG_OK) return rc;
+        LWG_LAUNCH_CHECK("wgrad_row3_bf16x3_kernel");
+        if (S > 1) {
+            reduce_taps_kernel<<<ceil_div((long)O * I, 64), 256, 0, st>>>(part, (int)S, O, I, oihw, out);
+            LWG_LAUNCH_CHECK("reduce_taps_kernel");
+        }
+        return LWG_OK;
+    }
     const int T = (O % 128 == 0 && I % 128 == 0) ? 128 : 64;
     const long tiles = (long)(O / T) * ceil_div(I, T) * ntaps;
     // Pixel slices (split-K).  The grid runs in rounds of `slots` resident workgroups (LDS: two 128-wide or four
@@ -515,11 +908,7 @@ int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin,
             wgrad_bf16x3_kernel<64><<<grid, 256, lds16, st>>>(go, O, in, I, N, Hin, Win, Hg, Wg, stride, pad, per, wout, KWd, ntaps, oihw);
         }
         LWG_LAUNCH_CHECK("wgrad_bf16x3_kernel");
-        if (S > 1) {
-            reduce_slices_kernel<<<ceil_div((long)w_floats, 256), 256, 0, st>>>(part, (int)S, (long)w_floats, out);
-            LWG_LAUNCH_CHECK("reduce_slices_kernel");
-        }
-        return LWG_OK;
+        return reduce(S);
     }
     const size_t lds = (size_t)4 * WG_PX * (T + 4) * sizeof(float);
     if (T == 128) {
@@ -534,11 +923,7 @@ int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin,
         wgrad_kernel<64><<<grid, 256, lds, st>>>(go, O, in, I, N, Hin, Win, Hg, Wg, stride, pad, per, wout, KWd, ntaps, oihw);
     }
     LWG_LAUNCH_CHECK("wgrad_kernel");
-    if (S > 1) {
-        reduce_slices_kernel<<<ceil_div((long)w_floats, 256), 256, 0, st>>>(part, (int)S, (long)w_floats, out);
-        LWG_LAUNCH_CHECK("reduce_slices_kernel");
-    }
-    return LWG_OK;
+    return reduce(S);
 }
 
 // ---- data-gradient weight matrices from the master copy W[co][kh*4+kw][ci] (run after every optimiser step).

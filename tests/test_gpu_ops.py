@@ -14,6 +14,9 @@ CASES = [
     ("decoder convT 3x3 s2", 128, 64, 3, 2, 1, True, 16),
     ("stem 7x7 (Cin 6 in 8)", 8, 64, 7, 1, 3, False, 32),
     ("1x1", 64, 64, 1, 1, 0, False, 24),
+    # row segments that do not start at column 0 (W = 64: two 32-pixel steps per row) on both tiles of the kernel-row weight gradient
+    ("3x3 s1 128->64 @64", 128, 64, 3, 1, 1, False, 64),
+    ("3x3 s1 64->128 @64", 64, 128, 3, 1, 1, False, 64),
 ]
 
 
