@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "conv.h"
+#include "split.h"
 #include "sample.h"
 
 namespace lwg {
@@ -152,7 +153,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs &a, const ConvPhas
 //   1 no global loads in the loop, 2 no LDS staging stores, 4 no barrier, 8 no fragment re-reads, 16 s_setprio around MFMAs
 // GEN = true is the general mode of ConvArgs (rows tiled across images with a masked tail, per-phase input offsets,
 // bias epilogue, no statistics).
-template <int BN, int WM, int WN, bool SMALL_CIN, int DBG = 0, bool GEN = false>
+// X3 = true (general mode with ConvArgs.precision 1): same fp32 operands in memory, same loads and masks; a staged float4 is
+// split into its bf16 hi and lo terms on the way to LDS (row = [hi x32 | lo x32], the layout of conv.h in a 144-byte pitch)
+// and the stage is multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16: 6 MFMAs of 32 cycles per tile and
+// stage instead of 16 of 64 -- the PatchGAN's 4x4 convolutions and their data gradients in the bf16x3 training mode.
+template <int BN, int WM, int WN, bool SMALL_CIN, int DBG = 0, bool GEN = false, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 {
     constexpr int WAVES_N = BN / (32 * WN);
@@ -260,18 +265,31 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
         for (int j = 0; j < B_ROWS; ++j)
             rb[j] = *reinterpret_cast<const float4 *>(wt + (size_t)(32 * j) * ph.Kpad + kt * BK);
     };
+    // X3: k = 4 kq .. 4 kq + 3 of the row's 32 -> 8 bytes of hi terms at byte 8 kq, 8 bytes of lo terms 64 bytes further
+    auto put_split = [&](float *row, const float4 v) {
+        uint2 h, l;
+        split_pair(v.x, v.y, h.x, l.x);
+        split_pair(v.z, v.w, h.y, l.y);
+        char *dst = reinterpret_cast<char *>(row) + kq * 8;
+        *reinterpret_cast<uint2 *>(dst) = h;
+        *reinterpret_cast<uint2 *>(dst + 64) = l;
+    };
     auto store_a = [&](int buf) {
-        float *ad = As + buf * BM * LDK + lrow * LDK + kq * 4;
+        float *ad = As + buf * BM * LDK + lrow * LDK;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 v = ((rvalid >> j) & 1u) ? ra[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(ad + 32 * j * LDK) = v;
+            if constexpr (X3) put_split(ad + 32 * j * LDK, v);
+            else *reinterpret_cast<float4 *>(ad + 32 * j * LDK + kq * 4) = v;
         }
     };
     auto store_b = [&](int buf) {
-        float *bd = Bs + buf * BN * LDK + lrow * LDK + kq * 4;
+        float *bd = Bs + buf * BN * LDK + lrow * LDK;
 #pragma unroll
-        for (int j = 0; j < B_ROWS; ++j) *reinterpret_cast<float4 *>(bd + 32 * j * LDK) = rb[j];
+        for (int j = 0; j < B_ROWS; ++j) {
+            if constexpr (X3) put_split(bd + 32 * j * LDK, rb[j]);
+            else *reinterpret_cast<float4 *>(bd + 32 * j * LDK + kq * 4) = rb[j];
+        }
     };
 
     f32x16 acc[WM][WN];
@@ -292,6 +310,47 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     // MFMAs (straight-line body, no branches) instead of in front of them.  One barrier per stage.
     auto stage_body = [&](int kt, auto do_store, auto do_load) {
         const int buf = kt & 1;
+        if constexpr (X3) {
+            // lane -> row lane & 31, k chunk (lane >> 5) * 8 + 16 ks of the stage's 32: 16 bytes of hi terms, 16 of lo terms
+            const char *Ab = reinterpret_cast<const char *>(As + buf * BM * LDK + (wave_m * 32 * WM + (lane & 31)) * LDK) + (lane >> 5) * 16;
+            const char *Bb = reinterpret_cast<const char *>(Bs + buf * BN * LDK + (wave_n * 32 * WN + (lane & 31)) * LDK) + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8_t *>(Ab + i * 32 * LDK * 4 + ks * 32);
+                    al[i] = *reinterpret_cast<const bf16x8_t *>(Ab + i * 32 * LDK * 4 + ks * 32 + 64);
+                }
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8_t *>(Bb + j * 32 * LDK * 4 + ks * 32);
+                    bl[j] = *reinterpret_cast<const bf16x8_t *>(Bb + j * 32 * LDK * 4 + ks * 32 + 64);
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                if (decltype(do_store)::value && ks == 0) {
+                    store_a(buf ^ 1);
+                    store_b(buf ^ 1);
+                }
+                if (decltype(do_load)::value && ks == 1) {
+                    load_a(kt + 2);
+                    load_b(kt + 2);
+                }
+            }
+            __syncthreads();
+            return;
+        }
         const float *Ab = As + buf * BM * LDK + a_frag;
         const float *Bb = Bs + buf * BN * LDK + b_frag;
         float4 af[WM], bf[WN];
@@ -392,8 +451,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 //   * zero padding: a tap outside the image makes the lane read from a 16-byte zero buffer instead;
 //   * synchronisation is a raw s_barrier plus counted vmcnt: at the end of iteration t every wave waits until only
 //     its DMAs of stage t+2 are outstanding (=> stage t+1 has landed), then the barrier publishes it.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
 template <int BN, int WM, int WN, int DBG, int NS>
 __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
@@ -1757,8 +1814,9 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cout=%d not a multiple of the %d-channel tile", a.Cout, bn);
     if (!a.general && ((a.Hm * a.Wm) % BM != 0 || a.mtiles * BM != a.N * a.Hm * a.Wm))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: %dx%d output grid per image is not a multiple of %d pixels", a.Hm, a.Wm, BM);
-    if (a.general && (a.partials || a.fuse_phases || a.precision != 0 || a.mtiles != ceil_div((long)a.N * a.Hm * a.Wm, BM)))
-        LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: general mode is fp32, unfused, without statistics, mtiles = ceil(M/128)");
+    if (a.general && (a.partials || a.fuse_phases || (a.precision != 0 && a.precision != 1) ||
+                      a.mtiles != ceil_div((long)a.N * a.Hm * a.Wm, BM)))
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: general mode is unfused, without statistics, mtiles = ceil(M/128)");
     if (a.dil < 1) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: dilation must be >= 1");
     if ((1 << a.cin_log2) != a.Cin || a.Cin < 4 || (a.ldx & 3))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d must be a power of two >= 4 with a 16-byte aligned pixel stride", a.Cin);
@@ -1802,7 +1860,18 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
         if (small_cin && bn != 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d < %d is only built for the 64-channel tile", a.Cin, BK);
         for (int p = 0; p < a.nphase; ++p)
             if (a.ph[p].ntaps > 64) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 64 taps");
-        if (small_cin) {
+        if (a.precision == 1) {   // plain fp32 operands, split in the kernel (conv_igemm_f32<..., X3>)
+            static DeviceOnce x3_opt_in;
+            if (!x3_opt_in.done()) {
+                const int l128 = 2 * (BM + 128) * LDK * (int)sizeof(float);
+                LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_f32<128, 2, 2, false, 0, true, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, l128));
+                x3_opt_in.mark();
+            }
+            if (small_cin) conv_igemm_f32<64, 1, 2, true, 0, true, true><<<grid, 256, lds, st>>>(a);
+            else if (bn == 64) conv_igemm_f32<64, 1, 2, false, 0, true, true><<<grid, 256, lds, st>>>(a);
+            else conv_igemm_f32<128, 2, 2, false, 0, true, true><<<grid, 256, lds, st>>>(a);
+        } else if (small_cin) {
             conv_igemm_f32<64, 1, 2, true, 0, true><<<grid, 256, lds, st>>>(a);
         } else if (bn == 64) {
             conv_igemm_f32<64, 1, 2, false, 0, true><<<grid, 256, lds, st>>>(a);

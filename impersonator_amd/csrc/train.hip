@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "conv.h"
+#include "split.h"
 #include "sample.h"
 
 namespace lwg {
@@ -194,25 +195,50 @@ __global__ __launch_bounds__(256) void reduce_slices4_kernel(const float4 *__res
 // partials [slice][tap][co][ci] (wgrad_row3_bf16x3_kernel) -> out in the (co, ci, tap) or (co, tap, ci) layout; slices summed in
 // order.  A block owns 64 consecutive (co, ci) pairs: thread (pair, tl) sums taps tl, tl + 4, tl + 8 -- coalesced reads along the
 // pairs -- and the 64 x 9 sums leave through LDS as one contiguous run of the (co, ci, tap) layout.
-__global__ __launch_bounds__(256) void reduce_taps_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int oihw,
+constexpr int kReduceTapsMax = 49;
+__global__ __launch_bounds__(256) void reduce_taps_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int ntaps, int oihw,
                                                           float *__restrict__ out)
 {
-    __shared__ float sm[64 * 9];
+    __shared__ float sm[64 * kReduceTapsMax];
     const long n = (long)Cout * Cin, pair0 = (long)blockIdx.x * 64;
     const int pl = threadIdx.x & 63, tl = threadIdx.x >> 6;
     const long pair = pair0 + pl;
-    for (int t = tl; t < 9; t += 4) {
+    for (int t = tl; t < ntaps; t += 4) {
         float sum = 0.f;
         if (pair < n)
-            for (int k = 0; k < S; ++k) sum += part[((size_t)k * 9 + t) * n + pair];
-        if (oihw) sm[pl * 9 + t] = sum;
-        else if (pair < n) out[((size_t)(pair / Cin) * 9 + t) * Cin + pair % Cin] = sum;
+            for (int k = 0; k < S; ++k) sum += part[((size_t)k * ntaps + t) * n + pair];
+        if (oihw) sm[pl * ntaps + t] = sum;
+        else if (pair < n) out[((size_t)(pair / Cin) * ntaps + t) * Cin + pair % Cin] = sum;
     }
     if (!oihw) return;
     __syncthreads();
-    const long total = n * 9;
-    for (int i = threadIdx.x; i < 64 * 9; i += 256)
-        if (pair0 * 9 + i < total) out[pair0 * 9 + i] = sm[i];
+    const long total = n * ntaps;
+    for (int i = threadIdx.x; i < 64 * ntaps; i += 256)
+        if (pair0 * ntaps + i < total) out[pair0 * ntaps + i] = sm[i];
+}
+
+// the same for small filters (the stem: 64 x 8 pairs, 49 taps, ~150 slices): one thread per (tap, pair), four partial sums
+// (slices k = 0, 4, 8, ... / 1, 5, ... / ...) added in a fixed order
+__global__ __launch_bounds__(256) void reduce_taps_direct_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int ntaps,
+                                                                 int oihw, float *__restrict__ out)
+{
+    const long n = (long)Cout * Cin, e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * ntaps) return;
+    const int t = (int)(e / n);
+    const long pair = e - (long)t * n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float *src = part + (size_t)t * n + pair;
+    const size_t pitch = (size_t)ntaps * n;
+    int k = 0;
+    for (; k + 3 < S; k += 4) {
+        s0 += src[(size_t)k * pitch];
+        s1 += src[(size_t)(k + 1) * pitch];
+        s2 += src[(size_t)(k + 2) * pitch];
+        s3 += src[(size_t)(k + 3) * pitch];
+    }
+    for (; k < S; ++k) s0 += src[(size_t)k * pitch];
+    const float sum = (s0 + s1) + (s2 + s3);
+    out[oihw ? pair * ntaps + t : ((size_t)(pair / Cin) * ntaps + t) * Cin + pair % Cin] = sum;
 }
 
 // ---- weight gradient on the fp32 matrix cores:  dW[co][tap][ci] = sum_p dY[p][co] * X[pix(p, tap)][ci].
@@ -330,7 +356,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dy
 // image of an operand tile is the inference kernel's: row = channel, 128 bytes = [hi: k 0-7 | 8-15 | 16-23 | 24-31 | lo ...],
 // 16-byte slots XOR-swizzled by the row so that fragment reads (32 rows x one slot) and loader writes (rows 4 apart)
 // spread over the banks.  Tile, grid, split-K slices and epilogue as wgrad_kernel.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4w_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int wg_swz(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
 
@@ -510,19 +535,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const float *__res
     }
 }
 
-typedef __bf16 bf16x2w_t __attribute__((ext_vector_type(2)));
-// two fp32 values -> their bf16 hi terms and lo terms, each pair packed in a dword (first value in the low half)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo)
-{
-    bf16x2w_t h;
-    h[0] = (__bf16)a;
-    h[1] = (__bf16)b;
-    hi = __builtin_bit_cast(unsigned, h);
-    bf16x2w_t l;
-    l[0] = (__bf16)(a - __builtin_bit_cast(float, hi << 16));
-    l[1] = (__bf16)(b - __builtin_bit_cast(float, hi & 0xffff0000u));
-    lo = __builtin_bit_cast(unsigned, l);
-}
 __device__ __forceinline__ float quad_ch(const float4 &v, int ch) { return ch == 0 ? v.x : ch == 1 ? v.y : ch == 2 ? v.z : v.w; }
 
 // ---- 3x3 / stride 1 / pad 1 layers (the trunk and the skippers: nine tenths of the generator's weight-gradient arithmetic):
@@ -804,6 +816,197 @@ void wgrad_row3_bf16x3_kernel(const float *__restrict__ dy, int Cout, const floa
     }
 }
 
+// ---- the 7x7 stem (8 input channels, 6 of them real): wgrad_bf16x3_kernel gives every tap its own workgroup with a 64 x 64
+// tile of which 8 columns are channels -- 49 passes over dY, seven eighths of the MFMAs on zeros, 0.55 ms per launch at
+// 256 x 256, batch 4.  Here a workgroup owns ONE KERNEL ROW and the tile's 64 columns are (kw, ci): 7 x 8 = 56 used.  As
+// wgrad_row3_bf16x3_kernel otherwise (32-pixel steps of one output row, XCD-local work order, partials [tap][co][ci]);
+// loader items: waves 0-1 split dY (2 channels x 8 pixels), wave 2 splits X (one channel, 4 pixels + a 6-pixel apron,
+// the seven 4-pixel windows of the taps as 8-byte LDS stores), wave 3 only multiplies.  KW x KW taps, pad (KW - 1) / 2.
+template <int KW>
+__global__ __launch_bounds__(256, 4) void wgrad_rowk_c8_bf16x3_kernel(const float *__restrict__ dy, int Cout, const float *__restrict__ x,
+                                                                    int N, int H, int W, long px_per_slice, int S,
+                                                                    float *__restrict__ out, int oihw)
+{
+    constexpr int PADW = (KW - 1) / 2, NPX = 4 + KW - 1, NPAIR = (NPX + 1) / 2;   // pixels an X item loads, as packed pairs
+    constexpr int OPT = 64 * 128, BUF = 2 * OPT;   // one operand tile (64 rows x 128 B), one buffer (dY | X)
+    static_assert(KW * 8 <= 64 && (KW & 1) && NPAIR * 2 >= NPX + 1 - 1, "tile");
+    extern __shared__ __attribute__((aligned(16))) char wsb[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_co = Cout / 64;
+    const int units = tiles_co * KW * S, chunk = (units + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || item >= units) return;
+    const int kh = item % KW, co0 = (item / KW) % tiles_co * 64, slice = item / (KW * tiles_co);
+    const long P = (long)N * H * W;
+    const long p0 = slice * px_per_slice, p1 = p0 + px_per_slice < P ? p0 + px_per_slice : P;
+    const int K = (int)((p1 - p0) / WG_PX);
+
+    int ln = (int)(p0 / ((long)H * W)), loh, low;
+    {
+        const int rem = (int)(p0 - (long)ln * H * W);
+        loh = rem / W;
+        low = rem - loh * W;
+    }
+    auto advance = [&]() {
+        low += WG_PX;
+        const bool row_end = low == W;
+        low = row_end ? 0 : low;
+        loh += row_end ? 1 : 0;
+        const bool img_end = loh == H;
+        loh = img_end ? 0 : loh;
+        ln += img_end ? 1 : 0;
+    };
+    auto lds_at = [&](int buf, int tile_off, int row, int col, int cs) -> char * {
+        const int pr = row ^ ((row >> cs) & 1);
+        return wsb + buf * BUF + tile_off + pr * 128 + ((col ^ wg_swz(pr)) * 16);
+    };
+    // role 0 (waves 0-1): dY item = channel pair q of 32, pixel block blk of 4 (8 pixels)
+    // role 1 (wave 2):    X item = channel ci of 8, pixel block b8 of 8 (4 pixels, NPX loaded)
+    const int q = tid & 31, blk = (tid >> 5) & 3, ci = tid & 7, b8 = (tid >> 3) & 7;
+    struct Regs { float v[NPX > 16 ? NPX : 16]; unsigned m[NPAIR]; };
+    auto load = [&](auto role_tag, Regs &r) {
+        constexpr int ROLE = decltype(role_tag)::value;
+        if constexpr (ROLE == 0) {
+            unsigned off = ((unsigned)(ln * H + loh) * (unsigned)W + (unsigned)(low + 8 * blk)) * (unsigned)Cout + (unsigned)(co0 + 2 * q);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float2 v2 = *reinterpret_cast<const float2 *>(dy + off);
+                r.v[2 * i] = v2.x;
+                r.v[2 * i + 1] = v2.y;
+                off += (unsigned)Cout;
+            }
+        } else if constexpr (ROLE == 1) {
+            const int ih = loh + kh - PADW, iw0 = low + 4 * b8 - PADW;
+            const bool row_ok = (unsigned)ih < (unsigned)H;
+            const unsigned base = ((unsigned)(ln * H + (row_ok ? ih : 0)) * (unsigned)W) * 8u + (unsigned)ci;
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                const bool ok = row_ok && (unsigned)(iw0 + i) < (unsigned)W;
+                r.v[i] = x[ok ? base + (unsigned)(iw0 + i) * 8u : 0u];
+            }
+#pragma unroll
+            for (int pp = 0; pp < NPAIR; ++pp) {
+                const bool ok0 = row_ok && (unsigned)(iw0 + 2 * pp) < (unsigned)W;
+                const bool ok1 = 2 * pp + 1 < NPX && row_ok && (unsigned)(iw0 + 2 * pp + 1) < (unsigned)W;
+                r.m[pp] = (ok0 ? 0x0000ffffu : 0u) | (ok1 ? 0xffff0000u : 0u);
+            }
+        }
+        advance();
+    };
+    auto store = [&](auto role_tag, const Regs &r, int buf) {
+        constexpr int ROLE = decltype(role_tag)::value;
+        if constexpr (ROLE == 0) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                uint4 hv, lv;
+                split_pair(r.v[0 + ch], r.v[2 + ch], hv.x, lv.x);
+                split_pair(r.v[4 + ch], r.v[6 + ch], hv.y, lv.y);
+                split_pair(r.v[8 + ch], r.v[10 + ch], hv.z, lv.z);
+                split_pair(r.v[12 + ch], r.v[14 + ch], hv.w, lv.w);
+                *reinterpret_cast<uint4 *>(lds_at(buf, 0, 2 * q + ch, blk, 1)) = hv;
+                *reinterpret_cast<uint4 *>(lds_at(buf, 0, 2 * q + ch, 4 + blk, 1)) = lv;
+            }
+        } else if constexpr (ROLE == 1) {
+            unsigned h[NPAIR], l[NPAIR];
+#pragma unroll
+            for (int pp = 0; pp < NPAIR; ++pp) {
+                split_pair(r.v[2 * pp], 2 * pp + 1 < NPX ? r.v[2 * pp + 1] : 0.f, h[pp], l[pp]);
+                h[pp] &= r.m[pp];
+                l[pp] &= r.m[pp];
+            }
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {   // tap kw pairs output pixel j with loaded pixel j + kw
+                uint2 hv, lv;
+                if (kw & 1) {
+                    hv = make_uint2(__builtin_amdgcn_alignbit(h[kw / 2 + 1], h[kw / 2], 16), __builtin_amdgcn_alignbit(h[kw / 2 + 2], h[kw / 2 + 1], 16));
+                    lv = make_uint2(__builtin_amdgcn_alignbit(l[kw / 2 + 1], l[kw / 2], 16), __builtin_amdgcn_alignbit(l[kw / 2 + 2], l[kw / 2 + 1], 16));
+                } else {
+                    hv = make_uint2(h[kw / 2], h[kw / 2 + 1]);
+                    lv = make_uint2(l[kw / 2], l[kw / 2 + 1]);
+                }
+                // rows are written one channel apart (cs = 0 would flip every row: no flip, the eight lanes of a pixel block cover
+                // eight consecutive rows = both bank halves already)
+                const int row = kw * 8 + ci;
+                char *dst = wsb + buf * BUF + OPT + row * 128 + (b8 & 1) * 8;
+                *reinterpret_cast<uint2 *>(dst + (((b8 >> 1) ^ wg_swz(row)) * 16)) = hv;
+                *reinterpret_cast<uint2 *>(dst + (((4 + (b8 >> 1)) ^ wg_swz(row)) * 16)) = lv;
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) acc[r2] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int col = 2 * kb + (lane >> 5);
+            const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31);
+            const bf16x8_t ah = *reinterpret_cast<const bf16x8_t *>(lds_at(buf, 0, arow, col, 1));
+            const bf16x8_t al = *reinterpret_cast<const bf16x8_t *>(lds_at(buf, 0, arow, 4 + col, 1));
+            const char *bb = wsb + buf * BUF + OPT + brow * 128;
+            const bf16x8_t bh = *reinterpret_cast<const bf16x8_t *>(bb + ((col ^ wg_swz(brow)) * 16));
+            const bf16x8_t bl = *reinterpret_cast<const bf16x8_t *>(bb + (((4 + col) ^ wg_swz(brow)) * 16));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        }
+    };
+    auto run_role = [&](auto role_tag) {
+        Regs r0, r1;
+        auto step = [&](Regs &rload, const Regs &rnext, int kk) {
+            if (kk + 2 < K) load(role_tag, rload);
+            compute(kk & 1);
+            if (kk + 1 < K) store(role_tag, rnext, (kk + 1) & 1);
+            __syncthreads();
+        };
+        int k = 0;
+        if (K >= 4) {
+            load(role_tag, r0);
+            store(role_tag, r0, 0);
+            load(role_tag, r1);
+            __syncthreads();
+            for (; k + 3 < K; k += 2) {
+                load(role_tag, r0);
+                compute(0);
+                store(role_tag, r1, 1);
+                __syncthreads();
+                load(role_tag, r1);
+                compute(1);
+                store(role_tag, r0, 0);
+                __syncthreads();
+            }
+        } else {
+            if (K > 0) {
+                load(role_tag, r0);
+                store(role_tag, r0, 0);
+                if (K > 1) load(role_tag, r1);
+            }
+            __syncthreads();
+        }
+        for (; k < K; k += 2) {
+            step(r0, r1, k);
+            if (k + 1 < K) step(r1, r0, k + 1);
+        }
+    };
+    if (wave < 2) run_role(std::integral_constant<int, 0>{});
+    else if (wave == 2) run_role(std::integral_constant<int, 1>{});
+    else run_role(std::integral_constant<int, 2>{});
+
+    // column n of the tile = (kw, ci); the columns behind the last tap multiplied whatever the LDS held and are dropped
+    const int n = wn * 32 + (lane & 31), kw = n >> 3, cin = n & 7;
+    if (kw >= KW) return;
+    const int tap = kh * KW + kw, ntaps = KW * KW;
+    float *o = out + (size_t)slice * Cout * ntaps * 8;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) {
+        const int co = co0 + wm * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * (lane >> 5);
+        const size_t at = S > 1 ? ((size_t)tap * Cout + co) * 8 + cin
+                                : (oihw ? ((size_t)co * 8 + cin) * ntaps + tap : ((size_t)co * ntaps + tap) * 8 + cin);
+        o[at] = acc[r2];
+    }
+}
+
 // launcher: picks the tile, the pixel slices (split-K) and the partial buffer.  `part` must hold 32 * Cout*ntaps*Cin floats
 // (at most 32 slices); the result lands in `out`.
 int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin, int Win, int Hg, int Wg, int stride, int pad,
@@ -867,9 +1070,35 @@ int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin,
         else rc = run(&wgrad_row3_bf16x3_kernel<64, 64, 2, 2, 2, 2>, once[3]);
         if (rc != LWG_OK) return rc;
         LWG_LAUNCH_CHECK("wgrad_row3_bf16x3_kernel");
-        if (S > 1) {
-            reduce_taps_kernel<<<ceil_div((long)O * I, 64), 256, 0, st>>>(part, (int)S, O, I, oihw, out);
+        if (S > 1) {   // small filters with many slices: a thread per element; big ones: coalesced through LDS
+            if ((long)O * I * 9 <= 512 * 1024)
+                reduce_taps_direct_kernel<<<ceil_div((long)O * I * 9, 256), 256, 0, st>>>(part, (int)S, O, I, 9, oihw, out);
+            else
+                reduce_taps_kernel<<<ceil_div((long)O * I, 64), 256, 0, st>>>(part, (int)S, O, I, 9, oihw, out);
             LWG_LAUNCH_CHECK("reduce_taps_kernel");
+        }
+        return LWG_OK;
+    }
+    // the 7x7 stem: eight input channels, one kernel row per workgroup (wgrad_rowk_c8_bf16x3_kernel)
+    if (precision == 1 && stride == 1 && KWd == 7 && ntaps == 49 && pad == 3 && I == 8 && Hin == Hg && Win == Wg && Wg % WG_PX == 0 &&
+        O % 64 == 0 && !(row3_env && row3_env[0] == '0')) {
+        const long units = (long)(O / 64) * 7, slots = (long)device_cu_count() * 4;
+        long cap = (long)(part_floats / w_floats);
+        if (cap > kWgradMaxSlices) cap = kWgradMaxSlices;
+        if (cap > P / WG_PX) cap = P / WG_PX;
+        if (cap < 1) cap = 1;
+        long S = ceil_div(slots, units);   // one round of workgroups, no fewer than 8 steps each
+        if (S > cap) S = cap;
+        while (S > 1 && ceil_div(P, S) < 8 * WG_PX) --S;
+        const long per = ceil_div(ceil_div(P, S), WG_PX) * (long)WG_PX;
+        S = ceil_div(P, per);
+        float *wout = S == 1 ? out : part;
+        wgrad_rowk_c8_bf16x3_kernel<7><<<8u * (unsigned)ceil_div(units * S, 8), 256, 2 * 2 * 64 * 128, st>>>(go, O, in, N, Hg, Wg, per, (int)S,
+                                                                                                      wout, oihw);
+        LWG_LAUNCH_CHECK("wgrad_rowk_c8_bf16x3_kernel");
+        if (S > 1) {
+            reduce_taps_direct_kernel<<<ceil_div((long)O * I * 49, 256), 256, 0, st>>>(part, (int)S, O, I, 49, oihw, out);
+            LWG_LAUNCH_CHECK("reduce_taps_direct_kernel");
         }
         return LWG_OK;
     }
@@ -956,13 +1185,21 @@ __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float *__restr
     }
 }
 
-// ---- Adam (torch.optim.Adam, no weight decay, no amsgrad)
+// ---- Adam (torch.optim.Adam, no weight decay, no amsgrad).  step_dev != null: the step count lives in device memory
+// (incremented by step_inc_kernel in front of this launch) and the bias corrections are computed from it here -- the form a
+// captured graph can replay: a host-side count would be frozen into the launch arguments.
+__global__ void step_inc_kernel(long *step) { *step += 1; }
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2_sqrt)
+                                                   float bc1, float bc2_sqrt, const long *__restrict__ step_dev)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (step_dev) {
+        const float t = (float)*step_dev;
+        bc1 = 1.f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    }
     const float gi = g[i];
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -1471,6 +1708,9 @@ struct lwg_discriminator {
     float *loss = nullptr;      // device scalar
     long step = 0;
     bool wd_stale = true;
+    int precision = 0;          // 0: fp32 MFMA; 1: bf16x3 (operands split inside the conv / weight-gradient kernels)
+    long *step_dev = nullptr;   // device copy of `step` (lwg_discriminator_use_device_step): what a captured graph replays
+    bool device_step = false;
 };
 
 namespace lwg {
@@ -1511,6 +1751,7 @@ int d_conv_forward(lwg_discriminator *d, int l, const float *x, int B, hipStream
     a.nphase = 1;
     a.ph[0] = ConvPhase{4, 4, 16, 16 * L.cin_pad, 0, 0, 0, 0, 0};
     a.mtiles = ceil_div((long)B * L.Ho * L.Ho, kConvBM);
+    a.precision = d->precision;
     return launch_conv_igemm(a, d_tile_width(a.mtiles, L.cout_pad), st);
 }
 
@@ -1535,6 +1776,7 @@ int d_conv_dgrad(lwg_discriminator *d, int l, int B, hipStream_t st)
         }
     }
     a.mtiles = ceil_div((long)B * a.Hm * a.Wm, kConvBM);
+    a.precision = d->precision;
     return launch_conv_igemm(a, d_tile_width(a.mtiles, L.cin_pad), st);
 }
 
@@ -1717,6 +1959,7 @@ void lwg_discriminator_destroy(lwg_discriminator *d)
         for (float *p : ptrs)
             if (p) (void)hipFree(p);
     }
+    if (d->step_dev) (void)hipFree(d->step_dev);
     float *ptrs[] = {d->params, d->grads, d->m, d->v, d->x0, d->part, d->loss, d->wd0, d->dx0};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1778,6 +2021,14 @@ int lwg_discriminator_read_weight(lwg_discriminator *d, const char *key, int fro
     return LWG_OK;
 }
 
+int lwg_discriminator_set_precision(lwg_discriminator *d, int mode)
+{
+    LWG_REQUIRE(d, "discriminator_set_precision: NULL handle");
+    if (mode != 0 && mode != 1) LWG_FAIL(LWG_ERR_INVALID_ARG, "discriminator_set_precision: mode %d (0: fp32, 1: bf16x3)", mode);
+    d->precision = mode;
+    return LWG_OK;
+}
+
 int lwg_discriminator_output_size(const lwg_discriminator *d, int *h)
 {
     LWG_REQUIRE(d && h, "output_size: NULL argument");
@@ -1834,7 +2085,7 @@ int lwg_discriminator_backward(lwg_discriminator *d, const float *real_nchw, con
         // weight gradient
         const float *xin = l == 0 ? d->x0 : (d->L[l - 1].act ? d->L[l - 1].actv : d->L[l - 1].raw);
         if ((rc = launch_wgrad(L.draw, L.cout_pad, xin, L.cin_pad, B, L.Hin, L.Hin, L.Ho, L.Ho, L.stride, 1, 4, 16, 0,
-                               d->grads + L.w_off, d->part, d->part_floats, st)) != LWG_OK)
+                               d->grads + L.w_off, d->part, d->part_floats, st, d->precision)) != LWG_OK)
             return rc;
         if (l > 0 && (rc = d_conv_dgrad(d, l, B, st)) != LWG_OK) return rc;
     }
@@ -1856,10 +2107,27 @@ int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float beta1, flo
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     d->step += 1;
     const float bc1 = 1.f - powf(beta1, (float)d->step), bc2 = 1.f - powf(beta2, (float)d->step);
+    if (d->device_step) {
+        step_inc_kernel<<<1, 1, 0, st>>>(d->step_dev);
+        LWG_LAUNCH_CHECK("step_inc_kernel");
+    }
     adam_kernel<<<ceil_div((long)d->nparams, 256), 256, 0, st>>>(d->params, d->grads, d->m, d->v, (long)d->nparams, lr, beta1,
-                                                                 beta2, eps, bc1, sqrtf(bc2));
+                                                                 beta2, eps, bc1, sqrtf(bc2), d->device_step ? d->step_dev : nullptr);
     LWG_LAUNCH_CHECK("adam_kernel");
     return d_refresh_dgrad_weights(d, st);
+}
+
+int lwg_discriminator_use_device_step(lwg_discriminator *d, int on)
+{
+    LWG_REQUIRE(d, "use_device_step: NULL handle");
+    if (on) {
+        if (!d->step_dev) LWG_HIP(hipMalloc(reinterpret_cast<void **>(&d->step_dev), sizeof(long)));
+        LWG_HIP(hipMemcpy(d->step_dev, &d->step, sizeof(long), hipMemcpyHostToDevice));
+    } else if (d->device_step) {
+        LWG_HIP(hipMemcpy(&d->step, d->step_dev, sizeof(long), hipMemcpyDeviceToHost));   // replays advanced only the device copy
+    }
+    d->device_step = on != 0;
+    return LWG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1892,7 +2160,6 @@ int conv_geom(const lwg_conv2d_desc *d, ConvGeom *g)
 // Scratch of the bf16x3 route (precision 1): the operand tensor and the weight matrices are re-written in the
 // split-bf16 format of conv.h ([hi x32 | lo x32] per 32 values, same offsets as fp32) and the DMA-fed kernel of the
 // inference path runs on them.  The zero run the kernel reads out-of-image taps from sits right behind the operand.
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 struct SplitWs {
     float *w = nullptr;       // split weight matrices (as many floats as the fp32 ones)
     float *x = nullptr;       // split operand tensor
@@ -1900,10 +2167,16 @@ struct SplitWs {
     size_t zero_floats = 0;
 };
 
-__global__ __launch_bounds__(256) void split_pack_kernel(const float4 *__restrict__ src, float *__restrict__ dst, size_t n4)
+// (the threads behind the tensor clear the zero run the conv kernel reads out-of-image taps from: one launch instead of a
+// kernel and a memset per convolution)
+__global__ __launch_bounds__(256) void split_pack_kernel(const float4 *__restrict__ src, float *__restrict__ dst, size_t n4,
+                                                         float4 *__restrict__ zeros, size_t z4)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
+    if (i >= n4) {
+        if (i - n4 < z4) zeros[i - n4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const float4 v = src[i];
     const size_t e = i * 4;
     const size_t soff = (e >> 5) * 32 + ((e & 31) >> 1);   // 4-byte units: 8 bytes of hi, 8 of lo 64 B further
@@ -1915,10 +2188,12 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float4 *__restric
     *reinterpret_cast<bf16x4_t *>(dst + soff + 16) = l;
 }
 
-int split_pack(const float *src, float *dst, size_t n, hipStream_t st)
+int split_pack(const float *src, float *dst, size_t n, hipStream_t st, float *zeros = nullptr, size_t zero_floats = 0)
 {
-    if (n % 32) LWG_FAIL(LWG_ERR_INVALID_ARG, "split: %zu floats is not a whole number of 32-value groups", n);
-    split_pack_kernel<<<(unsigned)ceil_div((long)(n / 4), 256), 256, 0, st>>>(reinterpret_cast<const float4 *>(src), dst, n / 4);
+    if (n % 32 || zero_floats % 4) LWG_FAIL(LWG_ERR_INVALID_ARG, "split: %zu floats is not a whole number of 32-value groups", n);
+    const size_t z4 = zeros ? zero_floats / 4 : 0;
+    split_pack_kernel<<<(unsigned)ceil_div((long)(n / 4 + z4), 256), 256, 0, st>>>(reinterpret_cast<const float4 *>(src), dst, n / 4,
+                                                                                  reinterpret_cast<float4 *>(zeros), z4);
     LWG_LAUNCH_CHECK("split_pack_kernel");
     return LWG_OK;
 }
@@ -1935,8 +2210,7 @@ bool split_route_ok(int precision, int Cin, int Hm, int Wm, int taps, const floa
 int to_split_route(ConvArgs &a, const float *x, size_t x_floats, const SplitWs &sw, hipStream_t st)
 {
     int rc;
-    if ((rc = split_pack(x, sw.x, x_floats, st)) != LWG_OK) return rc;
-    LWG_HIP(hipMemsetAsync(sw.zeros, 0, sw.zero_floats * sizeof(float), st));
+    if ((rc = split_pack(x, sw.x, x_floats, st, sw.zeros, sw.zero_floats)) != LWG_OK) return rc;
     a.x = sw.x;
     a.w_split = sw.w;
     a.zeros = sw.zeros;
@@ -1969,6 +2243,9 @@ int op_conv(const float *x, int N, int H, int W, int Cin, const float *wmat, con
         const bool wide = Cout % 128 == 0 && (long)a.mtiles * (Cout / 128) >= device_cu_count();
         return launch_conv_igemm(a, wide ? 128 : 64, st);
     }
+    // general mode, plain fp32 tensors: bf16x3 by splitting inside the kernel (the 8-channel stem and the heads' data gradient).
+    // Biased convolutions -- the loss networks -- stay fp32 in both modes.
+    a.precision = (precision == 1 && !bias) ? 1 : 0;
     return launch_conv_igemm(a, (Cout % 128 == 0 && Cin >= kConvBK) ? 128 : 64, st);
 }
 
@@ -2465,7 +2742,20 @@ int lwg_adam_update(float *param, const float *grad, float *exp_avg, float *exp_
     LWG_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_update: bad argument");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     adam_kernel<<<ceil_div((long)n, 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(param, grad, exp_avg, exp_avg_sq, (long)n,
-                                                                                          lr, beta1, beta2, eps, bc1, sqrtf(bc2));
+                                                                                          lr, beta1, beta2, eps, bc1, sqrtf(bc2), nullptr);
+    LWG_LAUNCH_CHECK("adam_kernel");
+    return LWG_OK;
+}
+
+int lwg_adam_update_device_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, long *step_device,
+                                float lr, float beta1, float beta2, float eps, lwg_stream_t stream)
+{
+    LWG_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_device, "adam_update_device_step: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    step_inc_kernel<<<1, 1, 0, st>>>(step_device);
+    LWG_LAUNCH_CHECK("step_inc_kernel");
+    adam_kernel<<<ceil_div((long)n, 256), 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, 1.f, 1.f,
+                                                        step_device);
     LWG_LAUNCH_CHECK("adam_kernel");
     return LWG_OK;
 }
@@ -2517,6 +2807,7 @@ int lwg_discriminator_input_grad(lwg_discriminator *d, const float *x_nchw, int 
                 a.ph[p] = ConvPhase{2, 2, 4, 4 * L.cout_pad, (long)p * 64 * 4 * L.cout_pad, py, px, py ? 0 : -1, px ? 0 : -1};
             }
             a.mtiles = ceil_div((long)bs * a.Hm * a.Wm, kConvBM);
+            a.precision = d->precision;
             if ((rc = launch_conv_igemm(a, 64, st)) != LWG_OK) return rc;
             if ((rc = lwg_unpack_nchw(d->dx0, bs, d->input_nc, d->is, d->is, 64, dx_nchw, stream)) != LWG_OK) return rc;
         }

@@ -170,6 +170,7 @@ class GeneratorTrainer(object):
         self.generator, self.D = generator, discriminator
         self.lam = dict(adv=lambda_D_prob, rec=lambda_rec, tsf=lambda_tsf, mask=lambda_mask, smooth=lambda_mask_smooth)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        self.t_dev = None   # use_device_step(): Adam's step count on the device (graph replay)
         self.repeat = generator.repeat_num
         self.align = bool(generator.align_corners)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -385,7 +386,19 @@ class GeneratorTrainer(object):
         if all_reduce:
             sharding.average_gradients(self.flat_g)
         self.t += 1
-        ops.adam_update(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.t, self.lr, self.betas, self.eps)
+        if self.t_dev is not None:
+            ops.adam_update_device_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.t_dev, self.lr, self.betas, self.eps)
+        else:
+            ops.adam_update(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.t, self.lr, self.betas, self.eps)
+
+    def use_device_step(self, on=True):
+        """Keep Adam's step count in device memory (ops.adam_update_device_step) so that an iteration captured in a graph
+        replays with the right bias corrections; off: back to the host count (which replays did not advance)."""
+        if on and self.t_dev is None:
+            self.t_dev = torch.tensor(self.t, dtype=torch.int64, device=self.flat_p.device)
+        elif not on and self.t_dev is not None:
+            self.t = int(self.t_dev.item())
+            self.t_dev = None
 
     def optimize_G(self, batch):
         """forward + losses + backward + Adam: the generator half of optimize_parameters (impersonator_trainer.py:350-357)."""

@@ -8,6 +8,7 @@ op-level HIP kernels), the discriminator update networks/discriminator.py.  Loss
 (--use_vgg, --use_style, --use_face: VGG19, SphereFace) are not available and fail loudly."""
 import torch
 
+from .. import _lib
 from ..networks.discriminator import PatchDiscriminator
 from ..networks.generator import ImpersonatorGenerator
 from ..networks.facenet import SphereFaceLoss
@@ -130,6 +131,8 @@ class Impersonator(BaseModel):
                                           "vgg19(pretrained=True).state_dict(); there is no download here)")
             self._vgg_state = path if isinstance(path, dict) else torch.load(path, map_location='cpu')
         self._g_trainer = None
+        self._graph = self._graph_terms = None   # optimize_parameters_graphed
+        self._graph_warm = 0
         self._real_src = self._bg_mask = None
 
     def _generator_trainer(self):
@@ -163,7 +166,8 @@ class Impersonator(BaseModel):
         # impersonator_trainer.py:219-222
         return PatchDiscriminator(input_nc=3 + self._D_cond_nc, norm_type=getattr(self._opt, 'norm_type', 'instance'), ndf=64,
                                   n_layers=4, use_sigmoid=False, image_size=self._opt.image_size,
-                                  max_batch=getattr(self._opt, 'batch_size', 4)).cuda()
+                                  max_batch=getattr(self._opt, 'batch_size', 4),
+                                  conv_precision=getattr(self._opt, 'conv_precision', 'fp32')).cuda()
 
     @torch.no_grad()
     def set_input(self, input_G_tsf, real_tsf=None, input_G_bg=None, input_G_src=None, T=None, real_src=None, bg_mask=None,
@@ -189,9 +193,22 @@ class Impersonator(BaseModel):
                           else input_G_src_bg)   # impersonator_trainer.py:306-309
         else:
             self._head_bbox, self._body_bbox = head_bbox, body_bbox
-        self._input_G_tsf, self._real_tsf = input_G_tsf, real_tsf
-        self._input_G_bg, self._input_G_src, self._T = input_G_bg, input_G_src, T
-        self._real_src, self._bg_mask = real_src, bg_mask
+        new = dict(_input_G_tsf=input_G_tsf, _real_tsf=real_tsf, _input_G_bg=input_G_bg, _input_G_src=input_G_src, _T=T,
+                   _real_src=real_src, _bg_mask=bg_mask)
+        if self._graph is not None:
+            # a captured iteration reads the tensors it was captured on: the new batch is copied into them
+            for k, v in new.items():
+                cur = getattr(self, k)
+                if (cur is None) != (v is None) or (v is not None and tuple(cur.shape) != tuple(v.shape)):
+                    self.drop_graph()
+                    break
+            else:
+                for k, v in new.items():
+                    if v is not None:
+                        getattr(self, k).copy_(v)
+                return
+        for k, v in new.items():
+            setattr(self, k, v)
 
     @torch.no_grad()
     def forward(self, keep_data_for_visuals=False, return_estimates=False):
@@ -221,6 +238,44 @@ class Impersonator(BaseModel):
         real_input_D = torch.cat([self._real_tsf, tsf_cond], dim=1)
         self._d_loss = self._D.optimize_D(real_input_D, fake_input_D, lr=self._current_lr_D, betas=self._D_betas)
         return self._d_loss
+
+    def drop_graph(self):
+        """Forget the captured iteration (new batch shape, new learning rate: both are baked into it)."""
+        if self._graph is not None:
+            self._graph = self._graph_terms = None
+            self._generator_trainer().use_device_step(False)
+            _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 0))
+
+    def optimize_parameters_graphed(self, warmup=2):
+        """optimize_parameters() as ONE launch (extension): a training iteration is ~1500 kernel launches issued from Python at
+        ~20 us each -- as long as the kernels themselves take.  The first `warmup` calls run eagerly (every lazily allocated
+        buffer and per-device kernel attribute exists afterwards), the next one captures generator pass + update and discriminator
+        update in a HIP graph (torch.cuda.graph; liblwg launches on torch's current stream, which is the capturing one), and
+        every call from then on is a replay.  What a replay cannot re-read from the host lives on the device: the batch
+        (set_input copies into the captured tensors), Adam's step counts (lwg_adam_update_device_step).  The learning rates
+        ARE baked in: whoever changes one calls drop_graph().  Single-process only (the gradient all-reduce of a data-parallel
+        job stays outside a capture here).  Returns the same loss terms."""
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            return self.optimize_parameters()
+        if self._graph is None:
+            if self._graph_warm < warmup:
+                self._graph_warm += 1
+                return self.optimize_parameters()
+            tr = self._generator_trainer()
+            tr.use_device_step(True)
+            _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 1))
+            batch = dict(input_G_bg=self._input_G_bg, input_G_src=self._input_G_src, input_G_tsf=self._input_G_tsf, T=self._T,
+                         real_src=self._real_src, real_tsf=self._real_tsf, bg_mask=self._bg_mask)
+            if self._face_state is not None:
+                batch['head_bbox'] = self._head_bbox
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                terms, (_, _, fake_tsf_imgs, _) = tr.optimize_G(batch)
+                terms = dict(terms, d_loss=self._optimize_D(fake_tsf_imgs))
+            self._graph, self._graph_terms = graph, terms
+        self._graph.replay()
+        return {k: float(v) for k, v in self._graph_terms.items()}
 
     def optimize_parameters(self, trainable=True, keep_data_for_visuals=False):
         """impersonator_trainer.py:350-366: generator pass, generator update, then (trainable) the discriminator update on

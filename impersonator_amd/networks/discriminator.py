@@ -24,8 +24,14 @@ class _DeviceView(object):
 
 
 class PatchDiscriminator(NetworkBase):
-    def __init__(self, input_nc, ndf=64, n_layers=3, norm_type='batch', use_sigmoid=False, image_size=256, max_batch=8):
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_type='batch', use_sigmoid=False, image_size=256, max_batch=8,
+                 conv_precision='fp32'):
+        """conv_precision (extension): 'fp32' or 'bf16x3' -- the arithmetic of the convolutions and their gradients
+        (include/lwg.h, lwg_discriminator_set_precision); norms, activations, loss and Adam are fp32 in both."""
         super().__init__()
+        if conv_precision not in ('fp32', 'bf16x3'):
+            raise ValueError("conv_precision must be 'fp32' or 'bf16x3'")
+        self.conv_precision = conv_precision
         self._name = 'discriminator_patch_gan'
         if norm_type != 'instance':
             raise NotImplementedError("normalization layer [%s]: the MI355X build implements the trainer's default, "
@@ -59,6 +65,7 @@ class PatchDiscriminator(NetworkBase):
                                                     self.max_batch))
             self._handle = h
             self._uploaded = None
+            _lib.check(lib.lwg_discriminator_set_precision(h, 1 if self.conv_precision == 'bf16x3' else 0))
         if self._uploaded != self._version():
             self.push_parameters()
         return self._handle

@@ -176,6 +176,17 @@ def adam_update(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), 
                                            int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.stream_ptr()))
 
 
+def adam_update_device_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8):
+    """adam_update with the step count in `step_dev` (0-d int64 CUDA tensor, incremented by the call on the stream): the form
+    that can be captured in a graph and replayed (include/lwg.h, lwg_adam_update_device_step)."""
+    _chk(param, grad, exp_avg, exp_avg_sq)
+    if not step_dev.is_cuda or step_dev.dtype != torch.int64 or step_dev.numel() != 1:
+        raise RuntimeError("adam_update_device_step: step_dev must be a single int64 on the device")
+    _lib.check(_lib.load().lwg_adam_update_device_step(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                                       param.numel(), _lib.ptr(step_dev), float(lr), float(betas[0]), float(betas[1]),
+                                                       float(eps), _lib.stream_ptr()))
+
+
 @torch.no_grad()
 def grid_sample_nhwc(x, grid, align_corners=False):
     """F.grid_sample (bilinear, zeros) on NHWC tensors: x (xn,H,W,C) with xn in {1, n}, grid (n,Ho,Wo,2) -> (n,Ho,Wo,C)."""

@@ -276,6 +276,11 @@ LWG_API int lwg_discriminator_load_weight(lwg_discriminator *d, const char *key,
 LWG_API int lwg_discriminator_read_weight(lwg_discriminator *d, const char *key, int from_grads, float *data_host,
                                           size_t n_floats);
 LWG_API int lwg_discriminator_num_params(const lwg_discriminator *d, size_t *n_floats);
+/* Arithmetic of the discriminator's convolutions (forward, data gradient, weight gradient): 0 (default) fp32 MFMA; 1 bf16x3 --
+ * the same fp32 tensors in memory, every operand split into two bf16 terms inside the kernels (hi*hi + hi*lo + lo*hi with
+ * fp32 accumulation, ~2^-16 relative per product), what `conv_precision='bf16x3'` selects for the generator's streams
+ * (reference: networks/discriminator.py:8-57 run in fp32 by cuDNN; the training step's tolerance is a loss curve, not bits). */
+LWG_API int lwg_discriminator_set_precision(lwg_discriminator *d, int mode);
 LWG_API int lwg_discriminator_output_size(const lwg_discriminator *d, int *h);   /* patch map edge (14 at 256, n_layers 4) */
 /* x (bs,input_nc,is,is) NCHW device -> out (bs,1,h,h) */
 LWG_API int lwg_discriminator_forward(lwg_discriminator *d, const float *x_nchw, int bs, float *out, lwg_stream_t stream);
@@ -353,6 +358,14 @@ LWG_API int lwg_grid_sample_backward(const float *dy, const float *grid, int xn,
 /* torch.optim.Adam step (no weight decay, no amsgrad) on a flat fp32 device tensor; step counts from 1 */
 LWG_API int lwg_adam_update(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, long step, float lr,
                             float beta1, float beta2, float eps, lwg_stream_t stream);
+/* The same update with the step count in device memory: `*step_device` (a long on the device, 0 before the first step) is
+ * incremented on the stream, then used for the bias corrections -- nothing about the step is baked into launch arguments, so a
+ * captured HIP graph of a training iteration replays correctly. */
+LWG_API int lwg_adam_update_device_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                                        long *step_device, float lr, float beta1, float beta2, float eps, lwg_stream_t stream);
+/* lwg_discriminator_adam_step keeps its step count on the device as well (on != 0; synchronous, call outside a capture): see
+ * lwg_adam_update_device_step.  Switching it off copies the count back. */
+LWG_API int lwg_discriminator_use_device_step(lwg_discriminator *d, int on);
 
 /* Test hook: copies an internal scratch buffer (device to device) after inference/swap/encode_src.
  * which: 0..2 = concat buffers cat[l] (bs, is>>l, is>>l, 2*conv_dim<<l)  [skip half | decoder half],

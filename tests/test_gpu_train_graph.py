@@ -1,0 +1,69 @@
+"""GPU: a training iteration captured in a HIP graph (Impersonator.optimize_parameters_graphed) replays the same training run as
+the eager calls -- same loss terms iteration by iteration (Adam's step count lives on the device: lwg_adam_update_device_step,
+lwg_discriminator_use_device_step), and a new batch reaches the replay through set_input."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def _inputs(model):
+    return dict(input_G_tsf=model._input_G_tsf, real_tsf=model._real_tsf, input_G_bg=model._input_G_bg, input_G_src=model._input_G_src,
+                T=model._T, real_src=model._real_src, bg_mask=model._bg_mask)
+
+
+def test_adam_with_the_step_count_on_the_device():
+    """lwg_adam_update_device_step == lwg_adam_update step for step (the count incremented on the stream, the bias corrections
+    evaluated from it in the kernel)."""
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n = 10007
+    p0 = torch.randn(n, generator=g).cuda()
+    pa, pb = p0.clone(), p0.clone()
+    ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
+    t_dev = torch.zeros((), dtype=torch.int64, device="cuda")
+    for t in range(1, 7):
+        grad = (torch.randn(n, generator=g) * 10.0 ** float(torch.randint(-4, 2, (1,), generator=g))).cuda()
+        ops.adam_update(pa, grad, ma, va, t, 2e-4, (0.5, 0.999), 1e-8)
+        ops.adam_update_device_step(pb, grad, mb, vb, t_dev, 2e-4, (0.5, 0.999), 1e-8)
+        assert int(t_dev) == t
+        assert torch.equal(ma, mb) and torch.equal(va, vb)
+        # powf on the device against powf on the host: the step sizes agree to a few float32 ulps of 1 - 0.999^t
+        assert float((pa - pb).abs().max()) <= 1e-4 * 2e-4, t
+    assert float((pa - p0).abs().max()) > 5e-4
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_graph_replay_trains_like_eager_calls(precision):
+    """Two eager runs of one seeded job drift apart on their own (grid_sample's backward scatters with float atomics, and Adam's
+    first steps move every weight by +-lr whatever the size of its gradient: `tools/experiments/r04/graph_vs_eager.py` -- 2 % on
+    d_loss after five iterations), so only the first replayed iteration can be compared tightly: it starts from the parameters
+    of two eager iterations.  Later ones are held to that drift, and the step counts must have advanced on the device."""
+    import bench_train
+    eager, graphed = bench_train.build(2, 64, precision, seed=3), bench_train.build(2, 64, precision, seed=3)
+    other = _inputs(bench_train.build(2, 64, precision, seed=11))          # a second batch, same shapes
+    ref, got = [], []
+    for it in range(7):
+        if it == 5:                                                          # after the capture (iteration 2) and two replays
+            eager.set_input(**{k: v.clone() for k, v in other.items()})
+            graphed.set_input(**{k: v.clone() for k, v in other.items()})
+        ref.append(eager.optimize_parameters())
+        got.append(graphed.optimize_parameters_graphed())
+    assert graphed._graph is not None
+    for it, (a, b) in enumerate(zip(ref, got)):
+        assert a.keys() == b.keys()
+        for k in a:
+            tol = 1e-3 if it <= 2 else 0.1
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (it, k, a[k], b[k])
+    assert abs(ref[5]["g_rec"] - ref[4]["g_rec"]) > 0.05 * ref[4]["g_rec"], "the second batch is a different one"
+    pe, pg = eager._generator_trainer().flat_p, graphed._generator_trainer().flat_p
+    assert float((pe - pg).abs().max()) <= 2 * 7 * 2e-4          # every weight moves by at most lr per iteration in either run
+    graphed.drop_graph()
+    assert graphed._generator_trainer().t == eager._generator_trainer().t == 7
+    last = graphed.optimize_parameters()                                     # eager again after the graph is dropped
+    assert abs(last["g_rec"] - eager.optimize_parameters()["g_rec"]) <= 0.1 * abs(last["g_rec"])

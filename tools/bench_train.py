@@ -79,23 +79,25 @@ def conv_gflop_per_iteration(batch, image_size, repeat=6):
     return (3.0 * batch * g_fwd + 3.0 * 2 * batch * d_fwd + 2.0 * batch * d_fwd) / 1e9
 
 
-def measure(batch, image_size, steps=5, warmup=1, precision="bf16x3", script_loss=False):
+def measure(batch, image_size, steps=5, warmup=1, precision="bf16x3", script_loss=False, graph=False):
     """-> dict(ms_per_iteration, images_per_s, ...) of `steps` optimize_parameters() calls after `warmup`; under an
     initialised multi-rank group: max over ranks, images of all ranks."""
     rank, _, world = sharding.env_world()
     dev = torch.device("cuda", torch.cuda.current_device())
     model = build(batch, image_size, precision, script_loss)
-    for _ in range(max(1, warmup)):
-        losses = model.optimize_parameters()
+    # graph: Impersonator.optimize_parameters_graphed -- two eager iterations, one that captures, then replays (single process)
+    iterate = model.optimize_parameters_graphed if graph else model.optimize_parameters
+    for _ in range(max(4 if graph else 1, warmup)):
+        losses = iterate()
     sharding.barrier(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses = model.optimize_parameters()
+        losses = iterate()
     sharding.barrier(dev)
     dt = sharding.max_over_ranks((time.perf_counter() - t0) / steps, "cpu")
-    out = {"ms_per_iteration": round(dt * 1e3, 2), "images_per_s": round(world * batch / dt, 2), "batch_per_rank": batch,
+    out = {"ms_per_iteration": round(dt * 1e3, 2), "launch": "one HIP graph replay per iteration" if graph and world == 1 else "eager", "images_per_s": round(world * batch / dt, 2), "batch_per_rank": batch,
            "world": world, "image_size": image_size,
-           "dtype": "f32" if precision == "fp32" else "bf16x3 generator convs (forward, data and weight gradient) + f32",
+           "dtype": "f32" if precision == "fp32" else "bf16x3 convs of generator and discriminator (forward, data and weight gradient) + f32",
            "loss": "train_iPER.sh (mask_bce, vgg, face)" if script_loss else "adv + L1 + mask",
            "conv_gflop_per_iteration": round(conv_gflop_per_iteration(batch, image_size), 1),
            "conv_tflops": round(world * conv_gflop_per_iteration(batch, image_size) / dt / 1e3, 1),
@@ -136,12 +138,13 @@ def main():
                     help="the loss of scripts/train_iPER.sh: --mask_bce --use_vgg --use_face (seeded VGG19 / Sphere20a weights)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="forward / data-gradient convolutions of the generator update")
+    ap.add_argument("--graph", action="store_true", help="replay the iteration as a captured HIP graph (single process)")
     a = ap.parse_args()
     rank, local_rank, world = sharding.init_process_group()
     if local_rank >= torch.cuda.device_count() and os.environ.get("LWG_DIST_BACKEND") == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    line = measure(a.batch, a.image_size, a.steps, 1, a.precision, a.script_loss)
+    line = measure(a.batch, a.image_size, a.steps, 1, a.precision, a.script_loss, a.graph)
     if rank == 0:
         line = dict({"metric": "training iteration (G update + D update)",
                      "note": "BASELINE.json config 5 is --image-size 512 (--batch 1..4 per GPU)", "batch": a.batch}, **line)
