@@ -282,13 +282,17 @@ def secondary_train(steps=3):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_train
     out = {}
-    for name, (n, s) in (("512x512_batch1", (1, 512)), ("256x256_batch4", (4, 256))):
-        r = bench_train.measure(n, s, steps=steps, warmup=2, precision="bf16x3")
-        out[name] = {"ms_per_iteration": r["ms_per_iteration"], "images_per_s": r["images_per_s"],
-                     "conv_gflop_per_iteration": r["conv_gflop_per_iteration"], "conv_tflops": r["conv_tflops"]}
-        torch.cuda.empty_cache()
+    for name, (n, s) in (("512x512_batch1", (1, 512)), ("256x256_batch4", (4, 256)), ("512x512_batch4", (4, 512))):
+        out[name] = {}
+        # eager: ~1500 launches per iteration from Python; graph: Impersonator.optimize_parameters_graphed, the same iteration
+        # captured once and replayed (what a training loop on one GPU would call)
+        for mode in ("eager", "graph"):
+            r = bench_train.measure(n, s, steps=steps, warmup=2, precision="bf16x3", graph=mode == "graph")
+            out[name][mode] = {"ms_per_iteration": r["ms_per_iteration"], "images_per_s": r["images_per_s"], "conv_tflops": r["conv_tflops"]}
+            torch.cuda.empty_cache()
+        out[name]["conv_gflop_per_iteration"] = r["conv_gflop_per_iteration"]
     out["what"] = ("G update (three streams forward, losses adv + L1 + mask, hand-written backward, Adam) + D update; "
-                   "bf16x3 generator convolutions, fp32 elsewhere; 1 GPU, no all-reduce")
+                   "bf16x3 convolutions of generator and discriminator, fp32 elsewhere; 1 GPU, no all-reduce")
     return out
 
 

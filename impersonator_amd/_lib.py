@@ -86,7 +86,7 @@ _PROTOS = {
     "lwg_grid_sample_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "lwg_adam_update": (_i, [_vp, _vp, _vp, _vp, _c.c_size_t, _c.c_long, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
     "lwg_adam_update_device_step": (_i, [_vp, _vp, _vp, _vp, _c.c_size_t, _vp, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
-    "lwg_discriminator_use_device_step": (_i, [_vp, _i]),
+    "lwg_discriminator_use_device_step": (_i, [_vp, _i, _c.c_float, _c.c_float]),
     "lwg_discriminator_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _i]),
     "lwg_discriminator_set_precision": (_i, [_vp, _i]),
     "lwg_discriminator_destroy": (None, [_vp]),

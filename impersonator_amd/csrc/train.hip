@@ -1186,19 +1186,26 @@ __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float *__restr
 }
 
 // ---- Adam (torch.optim.Adam, no weight decay, no amsgrad).  step_dev != null: the step count lives in device memory
-// (incremented by step_inc_kernel in front of this launch) and the bias corrections are computed from it here -- the form a
-// captured graph can replay: a host-side count would be frozen into the launch arguments.
-__global__ void step_inc_kernel(long *step) { *step += 1; }
+// (advanced by step_inc_kernel in front of this launch) and the bias corrections come from it -- the form a captured graph
+// can replay: a host-side count would be frozen into the launch arguments.  The state carries beta1^t and beta2^t as running
+// products in double (a powf in the kernel would do, but its expansion contains packed-fp32 instructions of the form
+// tests/test_pk_opsel_lint.py bans from this library).
+struct AdamStep { long step; double p1, p2; };
+__global__ void step_inc_kernel(AdamStep *s, float b1, float b2)
+{
+    s->step += 1;
+    s->p1 *= (double)b1;
+    s->p2 *= (double)b2;
+}
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2_sqrt, const long *__restrict__ step_dev)
+                                                   float bc1, float bc2_sqrt, const AdamStep *__restrict__ step_dev)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (step_dev) {
-        const float t = (float)*step_dev;
-        bc1 = 1.f - powf(b1, t);
-        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+        bc1 = 1.f - (float)step_dev->p1;
+        bc2_sqrt = sqrtf(1.f - (float)step_dev->p2);
     }
     const float gi = g[i];
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -1709,7 +1716,7 @@ struct lwg_discriminator {
     long step = 0;
     bool wd_stale = true;
     int precision = 0;          // 0: fp32 MFMA; 1: bf16x3 (operands split inside the conv / weight-gradient kernels)
-    long *step_dev = nullptr;   // device copy of `step` (lwg_discriminator_use_device_step): what a captured graph replays
+    lwg::AdamStep *step_dev = nullptr;   // device copy of `step` (lwg_discriminator_use_device_step): what a captured graph replays
     bool device_step = false;
 };
 
@@ -2108,7 +2115,7 @@ int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float beta1, flo
     d->step += 1;
     const float bc1 = 1.f - powf(beta1, (float)d->step), bc2 = 1.f - powf(beta2, (float)d->step);
     if (d->device_step) {
-        step_inc_kernel<<<1, 1, 0, st>>>(d->step_dev);
+        step_inc_kernel<<<1, 1, 0, st>>>(d->step_dev, beta1, beta2);
         LWG_LAUNCH_CHECK("step_inc_kernel");
     }
     adam_kernel<<<ceil_div((long)d->nparams, 256), 256, 0, st>>>(d->params, d->grads, d->m, d->v, (long)d->nparams, lr, beta1,
@@ -2117,14 +2124,17 @@ int lwg_discriminator_adam_step(lwg_discriminator *d, float lr, float beta1, flo
     return d_refresh_dgrad_weights(d, st);
 }
 
-int lwg_discriminator_use_device_step(lwg_discriminator *d, int on)
+int lwg_discriminator_use_device_step(lwg_discriminator *d, int on, float beta1, float beta2)
 {
     LWG_REQUIRE(d, "use_device_step: NULL handle");
     if (on) {
-        if (!d->step_dev) LWG_HIP(hipMalloc(reinterpret_cast<void **>(&d->step_dev), sizeof(long)));
-        LWG_HIP(hipMemcpy(d->step_dev, &d->step, sizeof(long), hipMemcpyHostToDevice));
+        if (!d->step_dev) LWG_HIP(hipMalloc(reinterpret_cast<void **>(&d->step_dev), sizeof(AdamStep)));
+        const AdamStep h = {d->step, pow((double)beta1, (double)d->step), pow((double)beta2, (double)d->step)};
+        LWG_HIP(hipMemcpy(d->step_dev, &h, sizeof(h), hipMemcpyHostToDevice));
     } else if (d->device_step) {
-        LWG_HIP(hipMemcpy(&d->step, d->step_dev, sizeof(long), hipMemcpyDeviceToHost));   // replays advanced only the device copy
+        AdamStep h;
+        LWG_HIP(hipMemcpy(&h, d->step_dev, sizeof(h), hipMemcpyDeviceToHost));   // replays advanced only the device copy
+        d->step = h.step;
     }
     d->device_step = on != 0;
     return LWG_OK;
@@ -2747,15 +2757,16 @@ int lwg_adam_update(float *param, const float *grad, float *exp_avg, float *exp_
     return LWG_OK;
 }
 
-int lwg_adam_update_device_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, long *step_device,
+int lwg_adam_update_device_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, void *step_state,
                                 float lr, float beta1, float beta2, float eps, lwg_stream_t stream)
 {
-    LWG_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_device, "adam_update_device_step: bad argument");
+    LWG_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_state, "adam_update_device_step: bad argument");
+    static_assert(sizeof(AdamStep) == 24, "three 8-byte words: include/lwg.h");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    step_inc_kernel<<<1, 1, 0, st>>>(step_device);
+    AdamStep *sd = static_cast<AdamStep *>(step_state);
+    step_inc_kernel<<<1, 1, 0, st>>>(sd, beta1, beta2);
     LWG_LAUNCH_CHECK("step_inc_kernel");
-    adam_kernel<<<ceil_div((long)n, 256), 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, 1.f, 1.f,
-                                                        step_device);
+    adam_kernel<<<ceil_div((long)n, 256), 256, 0, st>>>(param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, 1.f, 1.f, sd);
     LWG_LAUNCH_CHECK("adam_kernel");
     return LWG_OK;
 }

@@ -395,9 +395,9 @@ class GeneratorTrainer(object):
         """Keep Adam's step count in device memory (ops.adam_update_device_step) so that an iteration captured in a graph
         replays with the right bias corrections; off: back to the host count (which replays did not advance)."""
         if on and self.t_dev is None:
-            self.t_dev = torch.tensor(self.t, dtype=torch.int64, device=self.flat_p.device)
+            self.t_dev = ops.adam_step_state(self.t, self.betas, self.flat_p.device)
         elif not on and self.t_dev is not None:
-            self.t = int(self.t_dev.item())
+            self.t = int(self.t_dev[0].item())
             self.t_dev = None
 
     def optimize_G(self, batch):

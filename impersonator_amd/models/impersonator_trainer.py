@@ -244,7 +244,7 @@ class Impersonator(BaseModel):
         if self._graph is not None:
             self._graph = self._graph_terms = None
             self._generator_trainer().use_device_step(False)
-            _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 0))
+            _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 0, 0.0, 0.0))
 
     def optimize_parameters_graphed(self, warmup=2):
         """optimize_parameters() as ONE launch (extension): a training iteration is ~1500 kernel launches issued from Python at
@@ -263,7 +263,8 @@ class Impersonator(BaseModel):
                 return self.optimize_parameters()
             tr = self._generator_trainer()
             tr.use_device_step(True)
-            _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 1))
+            _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 1, float(self._D_betas[0]),
+                                                                     float(self._D_betas[1])))
             batch = dict(input_G_bg=self._input_G_bg, input_G_src=self._input_G_src, input_G_tsf=self._input_G_tsf, T=self._T,
                          real_src=self._real_src, real_tsf=self._real_tsf, bg_mask=self._bg_mask)
             if self._face_state is not None:

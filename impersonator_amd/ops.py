@@ -176,14 +176,22 @@ def adam_update(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), 
                                            int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.stream_ptr()))
 
 
-def adam_update_device_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, betas=(0.9, 0.999), eps=1e-8):
-    """adam_update with the step count in `step_dev` (0-d int64 CUDA tensor, incremented by the call on the stream): the form
-    that can be captured in a graph and replayed (include/lwg.h, lwg_adam_update_device_step)."""
+def adam_step_state(step=0, betas=(0.9, 0.999), device="cuda"):
+    """The device-resident step state of adam_update_device_step after `step` steps: int64 tensor of three words
+    [t, bits of float64(beta1^t), bits of float64(beta2^t)] (include/lwg.h)."""
+    import numpy as np
+    pows = np.array([float(betas[0]) ** int(step), float(betas[1]) ** int(step)], dtype=np.float64).view(np.int64)
+    return torch.tensor([int(step), int(pows[0]), int(pows[1])], dtype=torch.int64, device=device)
+
+
+def adam_update_device_step(param, grad, exp_avg, exp_avg_sq, step_state, lr, betas=(0.9, 0.999), eps=1e-8):
+    """adam_update with the step count in `step_state` (adam_step_state(); advanced by the call on the stream): the form that
+    can be captured in a graph and replayed (include/lwg.h, lwg_adam_update_device_step).  `int(step_state[0])` is the count."""
     _chk(param, grad, exp_avg, exp_avg_sq)
-    if not step_dev.is_cuda or step_dev.dtype != torch.int64 or step_dev.numel() != 1:
-        raise RuntimeError("adam_update_device_step: step_dev must be a single int64 on the device")
+    if not step_state.is_cuda or step_state.dtype != torch.int64 or step_state.numel() != 3 or not step_state.is_contiguous():
+        raise RuntimeError("adam_update_device_step: step_state must be adam_step_state(): three int64 words on the device")
     _lib.check(_lib.load().lwg_adam_update_device_step(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
-                                                       param.numel(), _lib.ptr(step_dev), float(lr), float(betas[0]), float(betas[1]),
+                                                       param.numel(), _lib.ptr(step_state), float(lr), float(betas[0]), float(betas[1]),
                                                        float(eps), _lib.stream_ptr()))
 
 

@@ -358,14 +358,15 @@ LWG_API int lwg_grid_sample_backward(const float *dy, const float *grid, int xn,
 /* torch.optim.Adam step (no weight decay, no amsgrad) on a flat fp32 device tensor; step counts from 1 */
 LWG_API int lwg_adam_update(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, long step, float lr,
                             float beta1, float beta2, float eps, lwg_stream_t stream);
-/* The same update with the step count in device memory: `*step_device` (a long on the device, 0 before the first step) is
- * incremented on the stream, then used for the bias corrections -- nothing about the step is baked into launch arguments, so a
- * captured HIP graph of a training iteration replays correctly. */
+/* The same update with the step count in device memory: `step_state` is three 8-byte words on the device -- the count t
+ * (int64) and beta1^t, beta2^t (doubles); {0, 1.0, 1.0} before the first step -- which the call advances on the stream (with the
+ * betas it is given: keep them fixed) and then uses for the bias corrections.  Nothing about the step is baked into launch
+ * arguments, so a captured HIP graph of a training iteration replays correctly. */
 LWG_API int lwg_adam_update_device_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
-                                        long *step_device, float lr, float beta1, float beta2, float eps, lwg_stream_t stream);
-/* lwg_discriminator_adam_step keeps its step count on the device as well (on != 0; synchronous, call outside a capture): see
- * lwg_adam_update_device_step.  Switching it off copies the count back. */
-LWG_API int lwg_discriminator_use_device_step(lwg_discriminator *d, int on);
+                                        void *step_state, float lr, float beta1, float beta2, float eps, lwg_stream_t stream);
+/* lwg_discriminator_adam_step keeps its step count on the device as well (on != 0; synchronous, call outside a capture, with the
+ * betas the following steps will use): see lwg_adam_update_device_step.  Switching it off copies the count back. */
+LWG_API int lwg_discriminator_use_device_step(lwg_discriminator *d, int on, float beta1, float beta2);
 
 /* Test hook: copies an internal scratch buffer (device to device) after inference/swap/encode_src.
  * which: 0..2 = concat buffers cat[l] (bs, is>>l, is>>l, 2*conv_dim<<l)  [skip half | decoder half],

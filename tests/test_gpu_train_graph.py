@@ -26,14 +26,14 @@ def test_adam_with_the_step_count_on_the_device():
     p0 = torch.randn(n, generator=g).cuda()
     pa, pb = p0.clone(), p0.clone()
     ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
-    t_dev = torch.zeros((), dtype=torch.int64, device="cuda")
+    t_dev = ops.adam_step_state(0, (0.5, 0.999))
     for t in range(1, 7):
         grad = (torch.randn(n, generator=g) * 10.0 ** float(torch.randint(-4, 2, (1,), generator=g))).cuda()
         ops.adam_update(pa, grad, ma, va, t, 2e-4, (0.5, 0.999), 1e-8)
         ops.adam_update_device_step(pb, grad, mb, vb, t_dev, 2e-4, (0.5, 0.999), 1e-8)
-        assert int(t_dev) == t
+        assert int(t_dev[0]) == t
         assert torch.equal(ma, mb) and torch.equal(va, vb)
-        # powf on the device against powf on the host: the step sizes agree to a few float32 ulps of 1 - 0.999^t
+        # beta^t as a running product in double on the device against powf on the host: a few float32 ulps of 1 - 0.999^t
         assert float((pa - pb).abs().max()) <= 1e-4 * 2e-4, t
     assert float((pa - p0).abs().max()) > 5e-4
 

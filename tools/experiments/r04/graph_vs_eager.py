@@ -13,11 +13,11 @@ tr = lambda m: m._generator_trainer()
 for it in range(6):
     if it == 2:   # C: device step, eager
         tr(C).use_device_step(True)
-        _lib.check(_lib.load().lwg_discriminator_use_device_step(C._D._ensure_handle(), 1))
+        _lib.check(_lib.load().lwg_discriminator_use_device_step(C._D._ensure_handle(), 1, 0.5, 0.999))
     a, b, c, d = A.optimize_parameters(), B.optimize_parameters(), C.optimize_parameters(), D.optimize_parameters_graphed()
     pa = tr(A).flat_p
     print("it %d  g_tsf A %.7f  B-A %+.2e  devstep-A %+.2e  graph-A %+.2e | d_loss A %.6f  B-A %+.2e devstep-A %+.2e graph-A %+.2e | |p| diffs B %.2e C %.2e D %.2e"
           % (it, a["g_tsf"], b["g_tsf"] - a["g_tsf"], c["g_tsf"] - a["g_tsf"], d["g_tsf"] - a["g_tsf"], a["d_loss"], b["d_loss"] - a["d_loss"],
              c["d_loss"] - a["d_loss"], d["d_loss"] - a["d_loss"], float((tr(B).flat_p - pa).abs().max()), float((tr(C).flat_p - pa).abs().max()),
              float((tr(D).flat_p - pa).abs().max())))
-print("t_dev C", int(tr(C).t_dev), "t_dev D", int(tr(D).t_dev), "host t A", tr(A).t)
+print("t_dev C", int(tr(C).t_dev[0]), "t_dev D", int(tr(D).t_dev[0]), "host t A", tr(A).t)
