@@ -273,3 +273,40 @@ def test_grid_sample_nhwc_forward():
     assert _rel(y.cpu().permute(0, 3, 1, 2), ref) < 1e-5
     y1 = ops.grid_sample_nhwc(x[:1].permute(0, 2, 3, 1).contiguous().cuda(), grid.cuda())
     assert _rel(y1.cpu().permute(0, 3, 1, 2), F.grid_sample(x[:1].expand(3, -1, -1, -1), grid, align_corners=False)) < 1e-5
+
+
+_WGRAD_PROBE = r"""
+import sys, torch
+import torch.nn.functional as F
+from impersonator_amd import ops
+cin, cout, H, W, N = (int(v) for v in sys.argv[1:6])
+g = torch.Generator().manual_seed(5)
+x = torch.randn(N, cin, H, W, generator=g)
+w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+wr = w.clone().double().requires_grad_(True)
+y = F.conv2d(x.double(), wr, None, stride=1, padding=1)
+dy = torch.randn(y.shape, generator=g)
+y.backward(dy.double())
+nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+dw = ops.conv2d_backward_weight(nhwc(x), nhwc(dy), tuple(w.shape), 1, 1, False, precision="bf16x3")
+print("REL %.3e" % (float((dw.cpu().double() - wr.grad).abs().max()) / float(wr.grad.abs().max())))
+"""
+
+
+@pytest.mark.parametrize("slices", ["1", "2", "16"])
+@pytest.mark.parametrize("shape", [(128, 256, 8, 96, 2), (128, 64, 16, 32, 1), (64, 128, 4, 64, 3), (64, 64, 12, 32, 1)],
+                         ids=["128x128 tile W=96", "64x128 tile", "128x64 tile", "64x64 tile"])
+def test_kernel_row_weight_gradient_paths(shape, slices):
+    """wgrad_row3_bf16x3_kernel away from what its launcher would pick: ONE slice (the gradient written directly in PyTorch's
+    layout, no partials), two, and sixteen (two- or three-step slices: the short pipeline without the steady-state loop); a width
+    that is not a power of two (three 32-pixel steps per row), rectangular maps, all four tile shapes.  LWG_WGRAD_ROW3_SLICES is
+    read once per process, hence the subprocess.  Against float64 autograd, the bound of test_weight_gradient_bf16x3."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cin, cout, H, W, N = shape
+    env = dict(os.environ, LWG_WGRAD_ROW3_SLICES=slices, PYTHONPATH=root)
+    p = subprocess.run([sys.executable, "-c", _WGRAD_PROBE] + [str(v) for v in (cin, cout, H, W, N)], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rel = float(p.stdout.strip().split("REL")[-1])
+    assert rel < 3e-5, (shape, slices, rel)
