@@ -73,6 +73,12 @@ struct ConvArgs {
     unsigned long long *trace;      // measurement builds only (LWG_CONV_TRACE): per-wave cycle accounting, see conv_igemm_bf16x3
     int general;
     const float *bias;
+    // General mode, few output tiles and a long reduction (the PatchGAN's 512-channel layers on 16 x 16 maps: 64-128 workgroups
+    // of 256 stages): ksplit > 1 workgroups share a tile's reduction; split s writes its raw sums (no bias) to
+    // kpart + s * kpart_stride at y's offsets, and the caller adds the slices in order (+ bias) -- deterministic.
+    int ksplit;
+    float *kpart;
+    size_t kpart_stride;
     ConvPhase ph[4];
 };
 

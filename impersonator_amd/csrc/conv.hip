@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
 
-    const ConvPhase ph = a.ph[blockIdx.z];
+    const int ksn = GEN && a.ksplit > 1 ? a.ksplit : 1;           // reduction split (general mode only): z = split * nphase + phase
+    const int kss = GEN ? (int)blockIdx.z / a.nphase : 0;
+    const ConvPhase ph = a.ph[GEN ? (int)blockIdx.z % a.nphase : (int)blockIdx.z];
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int hw_m = a.Hm * a.Wm;
@@ -225,8 +227,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
 #pragma unroll
     for (int j = 0; j < B_ROWS; ++j) rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // scalar walk over (tap, ci0) for the wave-uniform case
-    int s_tap = 0, s_kh = 0, s_kw = 0, s_ci0 = 0;
+    // stages [kb, kb + nk) of the phase's Kpad / BK are this workgroup's (all of them without a reduction split)
+    const int nk_all = ph.Kpad / BK;
+    const int kb = (int)((long)kss * nk_all / ksn), nk = (int)((long)(kss + 1) * nk_all / ksn) - kb;
+    // scalar walk over (tap, ci0) for the wave-uniform case, started at stage kb
+    int s_tap = SMALL_CIN ? 0 : (kb * BK) >> a.cin_log2, s_kh = s_tap / ph.KW, s_kw = s_tap - s_kh * ph.KW,
+        s_ci0 = SMALL_CIN ? 0 : (kb * BK) & (a.Cin - 1);
     // stage fetch, split in two halves so that they can be slotted between MFMA groups
     int toff = 0;
     auto load_a = [&](int kt) {
@@ -344,8 +350,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
                     store_b(buf ^ 1);
                 }
                 if (decltype(do_load)::value && ks == 1) {
-                    load_a(kt + 2);
-                    load_b(kt + 2);
+                    load_a(kb + kt + 2);
+                    load_b(kb + kt + 2);
                 }
             }
             __syncthreads();
@@ -385,8 +391,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
                 store_b(buf ^ 1);
             }
             if (decltype(do_load)::value && k8 == 1 && !(DBG & 1)) {
-                load_a(kt + 2);
-                load_b(kt + 2);
+                load_a(kb + kt + 2);
+                load_b(kb + kt + 2);
             }
             if (k8 + 1 < BK / 8 && !(DBG & 8)) {
 #pragma unroll
@@ -400,14 +406,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
 
-    const int nk = ph.Kpad / BK;
-    load_a(0);
-    load_b(0);
+    load_a(kb);
+    load_b(kb);
     store_a(0);
     store_b(0);
     if (nk > 1) {
-        load_a(1);
-        load_b(1);
+        load_a(kb + 1);
+        load_b(kb + 1);
     }
     __syncthreads();
     int kt = 0;
@@ -427,11 +432,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
                 const int im = m / hw_m, rem = m - im * hw_m;
                 const int hm = rem / a.Wm, wm = rem - hm * a.Wm;
                 const size_t opix = ((size_t)im * a.Ho + hm * a.os + ph.oy0) * a.Wo + wm * a.os + ph.ox0;
-                float *yo = a.y + opix * a.ldy + n0 + wave_n * 32 * WN + col;
+                float *yo = (ksn > 1 ? a.kpart + (size_t)kss * a.kpart_stride : a.y) + opix * a.ldy + n0 + wave_n * 32 * WN + col;
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const int co = n0 + wave_n * 32 * WN + j * 32 + col;
-                    yo[j * 32] = acc[i][j][r] + (a.bias ? a.bias[co] : 0.f);
+                    yo[j * 32] = acc[i][j][r] + (a.bias && ksn == 1 ? a.bias[co] : 0.f);
                 }
             }
     } else {
@@ -1817,6 +1822,8 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
     if (a.general && (a.partials || a.fuse_phases || (a.precision != 0 && a.precision != 1) ||
                       a.mtiles != ceil_div((long)a.N * a.Hm * a.Wm, BM)))
         LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: general mode is unfused, without statistics, mtiles = ceil(M/128)");
+    if (a.ksplit > 1 && (!a.general || !a.kpart || a.kpart_stride < (size_t)a.N * a.Ho * a.Wo * a.ldy))
+        LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: a reduction split needs the general mode and a partial buffer of ksplit outputs");
     if (a.dil < 1) LWG_FAIL(LWG_ERR_INVALID_ARG, "conv: dilation must be >= 1");
     if ((1 << a.cin_log2) != a.Cin || a.Cin < 4 || (a.ldx & 3))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cin=%d must be a power of two >= 4 with a 16-byte aligned pixel stride", a.Cin);
@@ -1830,7 +1837,7 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
                          a.ph[p].ntaps, a.Cin);
     if (a.raw_in && (!a.in_ss || !conv_raw_input_supported(a, bn)))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: raw (un-normalised) input is only taken by the halo-resident bf16x3 kernels");
-    const dim3 grid(a.mtiles, a.Cout / bn, a.fuse_phases ? 1 : a.nphase);
+    const dim3 grid(a.mtiles, a.Cout / bn, a.fuse_phases ? 1 : a.nphase * (a.ksplit > 1 ? a.ksplit : 1));
     const size_t lds = (size_t)2 * (BM + bn) * LDK * sizeof(float);
     // the 128-channel tile needs 72 KiB of LDS: above the 64 KiB default, well inside gfx950's 160 KiB per CU
     static DeviceOnce lds_opt_in;

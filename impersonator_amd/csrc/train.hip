@@ -1014,6 +1014,9 @@ int launch_wgrad(const float *go, int O, const float *in, int I, int N, int Hin,
 {
     const long P = (long)N * Hg * Wg;
     const size_t w_floats = (size_t)O * ntaps * I;
+    // the bf16x3 loaders address both tensors with 32-bit element offsets
+    if (precision == 1 && ((size_t)N * Hin * Win * I >= ((size_t)1 << 32) || (size_t)P * O >= ((size_t)1 << 32)))
+        LWG_FAIL(LWG_ERR_UNSUPPORTED, "wgrad: tensors of 2^32 elements or more (%d x %d x %d x %d)", N, Hin, Win, I > O ? I : O);
     auto reduce = [&](long S) -> int {
         if (S > 1) {
             if (w_floats % 4 == 0) reduce_slices4_kernel<<<ceil_div((long)(w_floats / 4), 256), 256, 0, st>>>(
@@ -1688,6 +1691,24 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float *__restr
     }
 }
 
+// sums the `KS` reduction-split slices of a general-mode conv (ConvArgs::ksplit) in order and adds the bias: y[i] = bias[i % C] + sum_k part[k][i]
+__global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float4 *__restrict__ part, int KS, size_t stride4, long n4, int C,
+                                                            const float *__restrict__ bias, float4 *__restrict__ y)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = part[i];
+    for (int k = 1; k < KS; ++k) {
+        const float4 v = part[(size_t)k * stride4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+        const float4 b = ld4(bias + (int)((i * 4) % C));
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    y[i] = s;
+}
+
 struct DLayer {
     int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, stride = 2;
     bool norm = false, act = false;
@@ -1747,6 +1768,29 @@ int d_tile_width(int mtiles, int cout)
     return (cout % 128 == 0 && (long)mtiles * (cout / 128) >= device_cu_count()) ? 128 : 64;
 }
 
+// launch_conv_igemm with a reduction split where a general-mode conv has few output tiles and many stages (ConvArgs::ksplit);
+// the split's partials go through d->part (free between the weight gradients that use it on the same stream)
+int d_launch_conv(lwg_discriminator *d, ConvArgs &a, int bn, hipStream_t st)
+{
+    static const char *ks_env = getenv("LWG_D_KSPLIT");   // "0": never split (A/B switch)
+    const long tiles = (long)a.mtiles * (a.Cout / bn) * a.nphase;
+    const size_t y_floats = (size_t)a.N * a.Ho * a.Wo * a.ldy;
+    int nk = a.ph[0].Kpad / kConvBK, ks = 1;
+    for (int p = 1; p < a.nphase; ++p) nk = a.ph[p].Kpad / kConvBK < nk ? a.ph[p].Kpad / kConvBK : nk;
+    if (!(ks_env && ks_env[0] == '0') && a.ldy == a.Cout && a.Cout % 4 == 0)
+        for (int k = 4; k >= 2; k >>= 1)
+            if (tiles * k <= device_cu_count() && nk >= 16 * k && (size_t)k * y_floats <= d->part_floats) { ks = k; break; }
+    if (ks == 1) return launch_conv_igemm(a, bn, st);
+    const float *bias = a.bias;
+    a.ksplit = ks; a.kpart = d->part; a.kpart_stride = y_floats; a.bias = nullptr;
+    const int rc = launch_conv_igemm(a, bn, st);
+    if (rc != LWG_OK) return rc;
+    ksplit_reduce_kernel<<<ceil_div((long)(y_floats / 4), 256), 256, 0, st>>>(reinterpret_cast<const float4 *>(d->part), ks, y_floats / 4,
+                                                                           (long)(y_floats / 4), a.Cout, bias, reinterpret_cast<float4 *>(a.y));
+    LWG_LAUNCH_CHECK("ksplit_reduce_kernel");
+    return LWG_OK;
+}
+
 // forward conv of layer l on `x` (2N images): raw = conv(x) + bias
 int d_conv_forward(lwg_discriminator *d, int l, const float *x, int B, hipStream_t st)
 {
@@ -1759,7 +1803,7 @@ int d_conv_forward(lwg_discriminator *d, int l, const float *x, int B, hipStream
     a.ph[0] = ConvPhase{4, 4, 16, 16 * L.cin_pad, 0, 0, 0, 0, 0};
     a.mtiles = ceil_div((long)B * L.Ho * L.Ho, kConvBM);
     a.precision = d->precision;
-    return launch_conv_igemm(a, d_tile_width(a.mtiles, L.cout_pad), st);
+    return d_launch_conv(d, a, d_tile_width(a.mtiles, L.cout_pad), st);
 }
 
 // data gradient of layer l: dact[l-1] = conv^T(draw[l])
@@ -1784,7 +1828,7 @@ int d_conv_dgrad(lwg_discriminator *d, int l, int B, hipStream_t st)
     }
     a.mtiles = ceil_div((long)B * a.Hm * a.Wm, kConvBM);
     a.precision = d->precision;
-    return launch_conv_igemm(a, d_tile_width(a.mtiles, L.cin_pad), st);
+    return d_launch_conv(d, a, d_tile_width(a.mtiles, L.cin_pad), st);
 }
 
 int d_refresh_dgrad_weights(lwg_discriminator *d, hipStream_t st)

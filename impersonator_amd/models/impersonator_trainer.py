@@ -254,9 +254,12 @@ class Impersonator(BaseModel):
         every call from then on is a replay.  What a replay cannot re-read from the host lives on the device: the batch
         (set_input copies into the captured tensors), Adam's step counts (lwg_adam_update_device_step).  The learning rates
         ARE baked in: whoever changes one calls drop_graph().  Single-process only (the gradient all-reduce of a data-parallel
-        job stays outside a capture here).  Returns the same loss terms."""
+        job stays outside a capture here), and not with --use_face (its crops are host-side integers per batch): both fall back to
+        optimize_parameters().  Returns the same loss terms."""
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             return self.optimize_parameters()
+        if self._face_state is not None:
+            return self.optimize_parameters()   # --use_face crops at the batch's head boxes: host integers, different every batch
         if self._graph is None:
             if self._graph_warm < warmup:
                 self._graph_warm += 1
@@ -267,8 +270,6 @@ class Impersonator(BaseModel):
                                                                      float(self._D_betas[1])))
             batch = dict(input_G_bg=self._input_G_bg, input_G_src=self._input_G_src, input_G_tsf=self._input_G_tsf, T=self._T,
                          real_src=self._real_src, real_tsf=self._real_tsf, bg_mask=self._bg_mask)
-            if self._face_state is not None:
-                batch['head_bbox'] = self._head_bbox
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
