@@ -87,3 +87,16 @@ def test_smpl_stage_matches_reference():
                                  weights=m.weights, joint_regressor=m.joint_regressor, rotate=False)
     rv, rj, _ = ref.batch_smpl.SMPL.forward(stub, beta, theta, get_skin=True)
     assert torch.allclose(v, rv, atol=1e-6) and torch.allclose(j, rj, atol=1e-6)
+
+
+def test_adam_step_state_words():
+    """ops.adam_step_state: the three 8-byte words lwg_adam_update_device_step keeps on the device (include/lwg.h) -- the step count
+    and beta1^t, beta2^t as float64 bit patterns; {0, 1.0, 1.0} before the first step."""
+    import numpy as np
+    from impersonator_amd import ops
+    s0 = ops.adam_step_state(0, (0.5, 0.999), device="cpu")
+    assert s0.dtype == torch.int64 and s0.shape == (3,) and int(s0[0]) == 0
+    assert np.array_equal(s0.numpy()[1:].view(np.float64), np.array([1.0, 1.0]))
+    s7 = ops.adam_step_state(7, (0.5, 0.999), device="cpu")
+    assert int(s7[0]) == 7
+    assert np.array_equal(s7.numpy()[1:].view(np.float64), np.array([0.5 ** 7, 0.999 ** 7]))
