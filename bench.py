@@ -12,6 +12,15 @@ background blend.  Inputs (SMPL vectors, source image, cached source features) a
 region; the per-batch device->host copy of the result is outside it.  Every rank runs the same per-GPU work on its
 own frames (weak scaling, no data-path collective).
 
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); if fewer than N devices are visible it exits 1 instead
+of measuring one GPU and printing `n_gpus: 1`.  A WORLD_SIZE that disagrees with --gpus is an error, too.
+
+Timing.  After the warm-up the `--steps` window is timed `--repeats` times (default 5), every window bracketed by a barrier and a
+device synchronisation on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN window, the line
+also carries `ms_per_step_min/max`, the per-window list and the GPU's clock / power sampled (amdsmi) while the windows ran -- the part
+is power-limited and boxes differ by +-5 %, a single 45 ms window is as noisy as a round's gain.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant implicit-GEMM conv kernel, algorithmic FLOP / HIP-event time of its launches, as a
                  fraction of the MFMA peak both ways (algorithmic and executed products); exact_fp32_mode has its own
@@ -21,10 +30,15 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  whole chain on identical SMPL inputs); a failed check marks the line `"invalid"` and the process exits 1
   rccl         : with a process group (N > 1, or LWG_FORCE_DIST=1): backend, communicator size, RCCL version, and an all-reduce
                  of ones that must equal the rank count
+  ranks        : (N > 1) per-rank frames/s of the median window measured to each rank's OWN device synchronisation (a straggler
+                 shows here, not only in the max), min / median / max, every rank's device name + UUID / PCI id, `single_rank_fps`
+                 = rank 0 running the same window alone while the others idle, and `linear_frac` = value / (N x single_rank_fps)
   secondary    : after the timed region -- `swap`: Swapper.swap (BASELINE config 4, appearance transfer with the
                  two-stream Liquid Warping Block) at 256x256, one pair and eight pairs per launch sequence, with the
                  same HIP-event roofline pass; `train`: one G + D training iteration (config 5) at 512x512 batch 1
-                 and 256x256 batch 4.
+                 and 256x256 batch 4; `latency`: ONE frame per call as the reference loops it (models/imitator.py:166-171), eager
+                 and as a captured HIP graph, both precisions, and one Swapper.swap; `personalize`: Imitator.personalize (once
+                 per source) with the generator's BGNet and with the InpaintSANet background model, the CPU oracle beside it.
 """
 import argparse
 import json
@@ -77,6 +91,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--repeats", type=int, default=5,
+                   help="timed windows of --steps steps each; the line reports the median window (min / max beside it)")
     p.add_argument("--settle-ms", type=float, default=300.0,
                    help="untimed steps before the warm-up until this much wall time has passed (DVFS: the first ~100 ms "
                         "after idle run ~15%% slower); 0 disables")
@@ -91,6 +107,116 @@ def parse():
     p.add_argument("--lanes", type=int, default=None,
                    help="generator engines/streams consecutive batches are dealt to (default: Imitator.lanes = 2)")
     return p.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started bare, i.e. without torch.distributed.run's environment: re-execute under it, one
+    rank per GPU.  With fewer than N visible devices the run is refused (exit 1) -- it would otherwise measure ONE GPU.  Test hook:
+    LWG_DIST_BACKEND=gloo lets the N ranks share the visible device(s) (RCCL wants a GPU per rank)."""
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    shared = os.environ.get("LWG_DIST_BACKEND") == "gloo" and ndev >= 1
+    if ndev < args.gpus and not shared:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible on this box: refusing to run (a line with n_gpus < --gpus "
+                         "would be a single-GPU measurement).  Start fewer ranks, or for a functional run of the N-rank code path "
+                         "on shared devices set LWG_DIST_BACKEND=gloo.\n" % (args.gpus, ndev))
+        sys.exit(1)
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a torch.distributed environment: launching %s\n" % (args.gpus, " ".join(cmd[1:8])))
+    sys.stderr.flush()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), LWG_SELF_LAUNCHED="1")
+    os.execve(sys.executable, cmd, env)
+
+
+class GpuSampler:
+    """gfx clock (MHz) and socket power (W) of one GPU sampled through amdsmi on a thread while the timed windows run; every
+    failure (no amdsmi, no permission, another field layout) degrades to `None` in the line, never to an exception."""
+
+    def __init__(self, dev_index):
+        self.samples, self._stop, self._thread, self._h, self.error = [], False, None, None, None
+        try:
+            import amdsmi
+            self._smi = amdsmi
+            amdsmi.amdsmi_init()
+            handles = amdsmi.amdsmi_get_processor_handles()
+            want = None
+            try:
+                want = torch.cuda.get_device_properties(dev_index).pci_bus_id
+            except Exception:
+                pass
+            for h in handles:
+                try:
+                    bdf = amdsmi.amdsmi_get_gpu_device_bdf(h)
+                    if want is not None and int(bdf.split(":")[1], 16) == int(want):
+                        self._h = h
+                except Exception:
+                    pass
+            if self._h is None and handles:
+                self._h = handles[min(dev_index, len(handles) - 1)]
+        except Exception as e:   # noqa: BLE001
+            self.error = "%s: %s" % (type(e).__name__, e)
+
+    def _read(self):
+        smi, out = self._smi, {}
+        try:
+            c = smi.amdsmi_get_clock_info(self._h, smi.AmdSmiClkType.GFX)
+            out["mhz"] = float(c.get("clk", c.get("cur_clk")))
+        except Exception:
+            pass
+        try:
+            pw = smi.amdsmi_get_power_info(self._h)
+            for k in ("current_socket_power", "average_socket_power", "socket_power"):
+                v = pw.get(k)
+                if isinstance(v, (int, float)) and v > 0:
+                    out["watt"] = float(v)
+                    break
+        except Exception:
+            pass
+        return out
+
+    def _loop(self):
+        while not self._stop:
+            r = self._read()
+            if r:
+                self.samples.append(r)
+            time.sleep(0.004)
+
+    def start(self):
+        if self._h is not None:
+            import threading
+            self._stop = False
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+            self._thread = None
+
+    def summary(self):
+        def stat(key):
+            v = sorted(s[key] for s in self.samples if key in s)
+            return None if not v else {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+        if not self.samples:
+            return {"samples": 0, "note": "amdsmi gave no sample" + (" (%s)" % self.error if self.error else "")}
+        return {"samples": len(self.samples), "gfx_clock_mhz": stat("mhz"), "socket_power_w": stat("watt"),
+                "note": "amdsmi, ~4 ms period, this rank's GPU, only while the timed windows ran"}
+
+
+def device_identity(dev):
+    """name + a stable identifier of this rank's GPU (what proves that N ranks sit on N different devices)."""
+    p = torch.cuda.get_device_properties(dev)
+    ident = {"name": p.name, "index": dev.index}
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(p, k, None)
+        if v is not None:
+            ident[k] = str(v)
+    return ident
 
 
 def cpu_baseline(seed=0, batches=2):
@@ -276,6 +402,118 @@ def secondary_swap(dev, steps=30):
             "dtype": "bf16x3" if sw.generator.precision != "fp32" else "f32"}
 
 
+def _stats(ms):
+    v = sorted(ms)
+    return {"median": round(v[len(v) // 2], 4), "min": round(v[0], 4), "max": round(v[-1], 4), "calls": len(v)}
+
+
+def secondary_latency(dev, frames=40):
+    """BASELINE config 1's call pattern on the GPU: ONE frame per call, batch 1, `transfer_params_by_smpl` + `forward` with the
+    result awaited before the next frame -- the reference's own loop (models/imitator.py:166-171), no batching across frames, no
+    lanes.  `eager`: the ~70 liblwg launches of a frame issued from Python; `graph`: the same launches captured once
+    (Imitator.frame_graph) and replayed as one launch.  Both precisions; and one Swapper.swap (models/swapper.py:198-239) awaited."""
+    from impersonator_amd.utils import synthetic
+    out = {"workload": "1 frame per call (batch 1), 256x256, device synchronised after every frame; ms per frame",
+           "reference_loop": "models/imitator.py:166-171"}
+    for precision in ("bf16x3", "fp32"):
+        imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=1, seed=0, image_size=IMAGE_SIZE)
+        imitator.generator.precision = precision
+        imitator.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+        smpls = torch.from_numpy(demo.synthetic_smpls(frames + 8, seed=0)).to(dev)
+
+        def eager(t):
+            x = imitator.transfer_params_by_smpl(smpls[t:t + 1], "smooth", t=t)
+            return imitator.forward(x, imitator.tsf_info["T"])
+
+        def timed(fn):
+            for t in range(4):
+                last = fn(t)
+            torch.cuda.synchronize(dev)
+            ms = []
+            for t in range(4, 4 + frames):
+                t0 = time.perf_counter()
+                last = fn(t)
+                torch.cuda.synchronize(dev)
+                ms.append((time.perf_counter() - t0) * 1e3)
+            assert bool(torch.isfinite(last).all())
+            return _stats(ms), last.clone()
+
+        e_ms, e_last = timed(eager)
+        run = imitator.frame_graph(batch=1)
+        g_ms, g_last = timed(lambda t: run(smpls[t:t + 1], t=t))
+        out["f32" if precision == "fp32" else "bf16x3"] = {
+            "eager_ms": e_ms, "graph_ms": g_ms, "frames_per_s_graph": round(1e3 / g_ms["median"], 1),
+            "graph_equals_eager": bool(torch.equal(e_last, g_last))}
+        del run
+        imitator.generator.release()
+    sw, smpl_a, img_a, bg_a = demo.build_synthetic_imitator(batch_size=1, seed=0, image_size=IMAGE_SIZE, model="swapper")
+    smpl_b = demo.synthetic_smpls(8, seed=3)[5]
+    img_b = synthetic.smooth_image(77, (1, 3, IMAGE_SIZE, IMAGE_SIZE))[0]
+    sw.swap_setup(img_a, img_b, src_smpl=smpl_a, tgt_smpl=smpl_b, src_bg=bg_a, tgt_bg=synthetic.smooth_image(78, (1, 3, IMAGE_SIZE, IMAGE_SIZE))[0])
+    ms = []
+    for i in range(4 + 20):
+        t0 = time.perf_counter()
+        p = sw.swap(sw.src_info, sw.tsf_info, target_part="body")
+        torch.cuda.synchronize(dev)
+        if i >= 4:
+            ms.append((time.perf_counter() - t0) * 1e3)
+    out["swap_one_pair_ms"] = dict(_stats(ms), what="Swapper.swap at batch 1 awaited (eager; its mask bookkeeping indexes with a boolean "
+                                                     "mask, which reads the device: not capturable as a graph)")
+    sw.generator.release()
+    return out
+
+
+def secondary_personalize(dev, reps=5):
+    """Imitator.personalize (models/imitator.py:82-155), the once-per-source step north_star names: render + masks + background
+    model + source-stream encoder.  `ORIGINAL` = the generator's own BGNet (--bg_model ORIGINAL), `deepfillv2` = InpaintSANet
+    (networks/inpaintor.py:178-202: 28 gated convs + 4096-token self-attention).  ms per source on the GPU (median of `reps` awaited
+    calls) and the CPU oracle (oracle/torch_ref.py imitator_personalize, all host cores, one call after a warm-up) beside it."""
+    from oracle import torch_ref
+    from impersonator_amd.networks.inpaintor import InpaintSANet
+    from impersonator_amd.utils import synthetic
+    out = {"workload": "Imitator.personalize of one 256x256 source (synthetic SMPL + random-init networks), awaited"}
+    for variant in ("ORIGINAL", "deepfillv2"):
+        imitator, src_smpl, src_img, _ = demo.build_synthetic_imitator(batch_size=1, seed=0, image_size=IMAGE_SIZE)
+        bg_sd = None
+        if variant == "deepfillv2":
+            net = InpaintSANet(c_dim=4).eval()
+            shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.random_inpaintor_state_dict(shapes, 1).items()})
+            imitator.bgnet = net.cuda()
+            bg_sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        ms = []
+        for i in range(2 + reps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            imitator.personalize(src_img, src_smpl=src_smpl)
+            torch.cuda.synchronize(dev)
+            if i >= 2:
+                ms.append((time.perf_counter() - t0) * 1e3)
+        si = imitator.src_info
+        sd = {k: v.detach().cpu() for k, v in imitator.generator.state_dict().items()}
+        faces_t, map_fn = imitator.render.faces.cpu(), imitator.render.map_fn.cpu()
+        info = {k: si[k].cpu() for k in ("cam", "verts", "shape")}
+        img_t = torch.from_numpy(src_img)[None]
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        with torch.no_grad():
+            torch_ref.imitator_personalize(sd, img_t, info, faces_t, map_fn, bg_sd=bg_sd)
+            t0 = time.perf_counter()
+            ref = torch_ref.imitator_personalize(sd, img_t, info, faces_t, map_fn, bg_sd=bg_sd)
+            cpu_ms = (time.perf_counter() - t0) * 1e3
+        bg_err = float((ref["bg"] - si["bg"].cpu()).abs().max())
+        feat_err = max(float((a - b.cpu()).abs().max()) for a, b in zip(list(ref["enc"]) + list(ref["res"]),
+                                                                       list(si["feats"][0]) + list(si["feats"][1])))
+        out[variant] = {"gpu_ms": _stats(ms), "cpu_oracle_ms": round(cpu_ms, 1), "cpu_threads": torch.get_num_threads(),
+                        "speedup": round(cpu_ms / _stats(ms)["median"], 1),
+                        "parity": {"fim_equal": bool(torch.equal(ref["fim"], si["fim"].cpu())), "bg_linf": round(bg_err, 7),
+                                   "src_feature_linf": round(feat_err, 7)}}
+        imitator.generator.release()
+        if variant == "deepfillv2":
+            imitator.bgnet.release() if hasattr(imitator.bgnet, "release") else None
+    out["kernel_table"] = "profiles/r05_personalize_kernel_stats.md (rocprofv3 --kernel-trace --stats -- python tools/personalize_once.py)"
+    return out
+
+
 def secondary_train(steps=3):
     """BASELINE config 5 per GPU: one training iteration (generator fwd/bwd + PatchGAN discriminator update,
     impersonator_trainer.py:350-366) -- tools/bench_train.py's measurement."""
@@ -298,11 +536,15 @@ def secondary_train(steps=3):
 
 def main():
     args = parse()
-    rank, local_rank, world = sharding.init_process_group()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)          # does not return: re-executes under torch.distributed.run, or exits 1
+    if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
+        # never a line whose n_gpus differs from what was asked for
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d (or bare, bench.py starts the "
+                         "ranks itself)" % (args.gpus, os.environ.get("WORLD_SIZE"), args.gpus))
+    rank, local_rank, world = sharding.init_process_group()
     if local_rank >= torch.cuda.device_count() and os.environ.get("LWG_DIST_BACKEND") == "gloo":
         local_rank %= torch.cuda.device_count()   # test hook: N ranks sharing the visible GPU(s), see sharding.init_process_group
     torch.cuda.set_device(local_rank)
@@ -316,6 +558,8 @@ def main():
     smpls = torch.from_numpy(demo.synthetic_smpls(args.frames, seed=0)).to(dev)
     imitator.first_cam = smpls[0:1, 0:3].clone()
     blocks = sharding.shard_blocks(args.frames, BATCH, rank, world)
+    # this rank's frames packed once, before anything is timed: consecutive chunks are adjacent rows of one tensor
+    mine, bounds = sharding.local_rows(smpls, blocks)
 
     def step(i):
         s, e = blocks[i % len(blocks)]
@@ -329,7 +573,8 @@ def main():
         enqueued on a side stream, the generators of consecutive steps on `lanes` engines with a stream each; every
         step's work is inside the loop."""
         out = None
-        chunks = ((smpls[s:e], s) for s, e in (blocks[(first + i) % len(blocks)] for i in range(n)))
+        idx = [(first + i) % len(blocks) for i in range(n)]
+        chunks = ((mine[bounds[k][0]:bounds[k][1]], blocks[k][0]) for k in idx)
         for _, out in imitator.predict_batches(chunks, "smooth", lanes=lanes):
             pass
         return out
@@ -347,12 +592,60 @@ def main():
     run_steps(0, 4)
     host_dt = (time.perf_counter() - th) / 4 * args.steps
     sharding.barrier(dev)
-    t0 = time.perf_counter()
-    out = run_steps(args.warmup, args.steps)
-    sharding.barrier(dev)
     rdev = dev if torch.distributed.is_initialized() else "cpu"   # RCCL reduces device tensors
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, rdev)
+
+    def timed_window(first, everyone=True):
+        """EXACTLY args.steps steps between a barrier + device synchronisation on both sides -> (seconds until every rank was done
+        = MAX over ranks, seconds until THIS rank's device was done)."""
+        if everyone:
+            sharding.barrier(dev)
+        else:
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        o = run_steps(first, args.steps)
+        torch.cuda.synchronize(dev)
+        mine = time.perf_counter() - t0
+        if not everyone:
+            return mine, mine, o
+        sharding.barrier(dev)
+        return sharding.max_over_ranks(time.perf_counter() - t0, rdev), mine, o
+
+    single_rank_fps = None
+    if world > 1:
+        # rank 0 runs one window ALONE (the others wait at the barrier below): the single-GPU rate of this very run, the
+        # denominator of `linear_frac`
+        if rank == 0:
+            solo, _, _ = timed_window(args.warmup, everyone=False)
+            single_rank_fps = BATCH * args.steps / solo
+        sharding.barrier(dev)
+    sampler = GpuSampler(local_rank)
+    sampler.start()
+    windows, mine_all, out = [], [], None
+    for r in range(max(1, args.repeats)):
+        w, mine, out = timed_window(args.warmup + r * args.steps)
+        windows.append(w)
+        mine_all.append(mine)
+    sampler.stop()
+    order = sorted(range(len(windows)), key=lambda i: windows[i])
+    med = order[len(order) // 2]
+    dt = windows[med]                       # the median window: what `value` and `ms_per_step` report
     assert bool(torch.isfinite(out).all())
+    ranks_block = None
+    if world > 1:
+        # every rank's own completion time of the median window, its device, its clocks: a straggler GPU is visible here
+        mine_fps = BATCH * args.steps / mine_all[med]
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, {"rank": rank, "fps": round(mine_fps, 2), "device": device_identity(dev),
+                                                        "clocks": sampler.summary()})
+        if rank == 0:
+            fps = sorted(g["fps"] for g in gathered)
+            ids = [g["device"].get("uuid") or g["device"].get("pci_bus_id") for g in gathered]
+            ranks_block = {"per_rank": gathered, "fps_min": fps[0], "fps_median": fps[len(fps) // 2], "fps_max": fps[-1],
+                           "distinct_devices": len(set(ids)) if all(i is not None for i in ids) else None,
+                           "single_rank_fps": round(single_rank_fps, 3),
+                           "linear_frac": round(world * BATCH * args.steps / dt / (world * single_rank_fps), 4),
+                           "note": "per-rank fps: the median window timed to each rank's own device synchronisation; "
+                                   "single_rank_fps: rank 0 running one window alone in this run; linear_frac = value / (N x that)"}
 
     def roofline_pass():
         """K steps again with HIP events around every launch of the conv kernels (recorded by liblwg on the launch
@@ -429,13 +722,12 @@ def main():
         # the same steps with the convolutions on the exact-fp32 MFMA path, for the record
         imitator.generator.precision = "fp32"
         run_steps(0, args.warmup)
-        sharding.barrier(dev)
-        t1 = time.perf_counter()
-        run_steps(args.warmup, args.steps)
-        sharding.barrier(dev)
-        dt32 = sharding.max_over_ranks(time.perf_counter() - t1, rdev)
+        w32 = sorted(timed_window(args.warmup + r * args.steps)[0] for r in range(max(1, min(3, args.repeats))))
+        dt32 = w32[len(w32) // 2]
         fp32_mode = {"value": round(world * BATCH * args.steps / dt32, 3), "unit": "frames/s",
-                     "ms_per_step": round(dt32 / args.steps * 1e3, 4), "dtype": "f32",
+                     "ms_per_step": round(dt32 / args.steps * 1e3, 4), "repeats": len(w32),
+                     "ms_per_step_min": round(w32[0] / args.steps * 1e3, 4), "ms_per_step_max": round(w32[-1] / args.steps * 1e3, 4),
+                     "dtype": "f32",
                      "note": "same workload, precision='fp32' (v_mfma_f32_32x32x2_f32, bit-exact fmaf chains)"}
         if not args.no_roofline:
             fp32_mode["roofline"] = roofline_pass()
@@ -447,6 +739,11 @@ def main():
             "metric": "frames/sec (256x256 motion-imitation, batch=8)",
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "repeats": len(windows), "ms_per_step_min": round(min(windows) / args.steps * 1e3, 4),
+            "ms_per_step_max": round(max(windows) / args.steps * 1e3, 4),
+            "ms_per_step_windows": [round(w / args.steps * 1e3, 4) for w in windows],
+            "timing": "median of %d windows of %d steps, each bracketed by barrier + device synchronisation, MAX over ranks" % (len(windows), args.steps),
+            "gpu_clocks": sampler.summary(),
             "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if precision == "fp32" else "bf16x3", "data": "synthetic",
             "config": {"workload": "Imitator inference 256x256 batch=8, random-init ImpersonatorGenerator (tsf ResUnet, "
@@ -464,8 +761,13 @@ def main():
             # N > 1 (or LWG_FORCE_DIST=1 at N = 1): the process group behind the timing barrier -- backend 'nccl' IS RCCL on
             # ROCm; `ranks` is the communicator's size as the library reports it, `allreduce_of_ones` must equal it
             line["rccl"] = rccl
-            if rccl["allreduce_of_ones"] != world:
-                line["invalid"] = "the process group's all-reduce of ones returned %r on %d ranks" % (rccl["allreduce_of_ones"], world)
+            if rccl["allreduce_of_ones"] != world or rccl["ranks"] != args.gpus:
+                line["invalid"] = ("the process group spans %r ranks and its all-reduce of ones returned %r; --gpus %d"
+                                   % (rccl["ranks"], rccl["allreduce_of_ones"], args.gpus))
+        if ranks_block is not None:
+            line["ranks"] = ranks_block
+            if ranks_block["distinct_devices"] not in (None, world) and os.environ.get("LWG_DIST_BACKEND") != "gloo":
+                line["invalid"] = "%d ranks on %d distinct devices" % (world, ranks_block["distinct_devices"])
         if fp32_mode is not None:
             line["exact_fp32_mode"] = fp32_mode
         if roofline is not None:
@@ -478,7 +780,8 @@ def main():
                 line["invalid"] = "the timed pipeline's output failed the parity check against the oracle (see `parity`)"
         if world == 1 and not args.no_secondary:
             # other workloads of BASELINE.json, measured after (and outside) the timed region
-            line["secondary"] = {"swap": secondary_swap(dev), "train": secondary_train()}
+            line["secondary"] = {"swap": secondary_swap(dev), "latency": secondary_latency(dev),
+                                 "personalize": secondary_personalize(dev), "train": secondary_train()}
         print(json.dumps(line))
         if line.get("invalid"):
             sys.exit(1)

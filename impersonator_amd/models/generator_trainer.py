@@ -57,6 +57,7 @@ class _ConvIN(object):
                                         precision=self.tr.conv_precision, out=ow)
         if ow is None:
             G[self.wkey].add_(dw)
+        tr.grads_checkpoint()     # the kernels writing this layer's three gradients are enqueued: complete buckets may go on the wire
         if not need_dx:
             return None
         return ops.conv2d_backward_data(draw, P[self.wkey], tuple(self.x.shape), self.stride, self.pad, self.transposed,
@@ -106,6 +107,7 @@ class _Head(object):
         dw = ops.heads_backward_weight(self.x, d8, out=ow)
         if ow is None:
             G[self.key].add_(dw)
+        self.tr.grads_checkpoint()
         return ops.conv2d_backward_data(d8, P[self.key], tuple(self.x.shape), 1, 3)
 
 
@@ -196,9 +198,12 @@ class GeneratorTrainer(object):
         self.flat_m = torch.zeros(n, device=dev)
         self.flat_v = torch.zeros(n, device=dev)
         self._untouched = set()   # gradient slices nothing has been written to in the current backward pass (see first_write)
+        self._ranges = []         # (key, lo, hi) element ranges of the flat buffers, in layout order (sharding.GradientBuckets)
+        self._buckets = None
         self.P, self.G, off = {}, {}, 0
         for key, shape, parts in self.spec:
             cnt = int(torch.Size(shape).numel())
+            self._ranges.append((key, off, off + cnt))
             self.P[key] = self.flat_p[off:off + cnt].view(shape)
             self.G[key] = self.flat_g[off:off + cnt].view(shape)
             off += cnt
@@ -225,8 +230,27 @@ class GeneratorTrainer(object):
         directly: no temporary, no add launch), else None (the caller accumulates)."""
         if key in self._untouched:
             self._untouched.discard(key)
+            if self._buckets is not None:
+                self._buckets.written(key)
             return self.G[key]
         return None
+
+    def grads_checkpoint(self):
+        """Called by a layer's backward once the kernels that write its gradients are enqueued (see sharding.GradientBuckets)."""
+        if self._buckets is not None:
+            self._buckets.checkpoint()
+
+    def _begin_buckets(self):
+        """Data-parallel job: the gradient all-reduce runs bucket by bucket on a side stream while the backward pass goes on
+        (env LWG_GRAD_BUCKETS=0: one blocking all-reduce of the whole buffer after it; LWG_BUCKET_MB: bucket size, default 32)."""
+        import os
+        if sharding.collectives_active() and os.environ.get("LWG_GRAD_BUCKETS", "1") != "0":
+            if self._buckets is None:
+                self._buckets = sharding.GradientBuckets(self.flat_g, self._ranges,
+                                                         int(float(os.environ.get("LWG_BUCKET_MB", "32")) * (1 << 20)))
+            self._buckets.begin()
+        else:
+            self._buckets = None
 
     # ------------------------------------------------------------------ parameters
     def state_dict(self):
@@ -295,6 +319,7 @@ class GeneratorTrainer(object):
         b, lam = self.b, self.lam
         self.flat_g.zero_()
         self._untouched = set(self.G)
+        self._begin_buckets()
         to_nhwc = lambda t: t.permute(0, 2, 3, 1)
         src_img, src_mask, tsf_img, tsf_mask = self.src.img, self.src.mask, self.tsf.img, self.tsf.mask
         n = src_img.shape[0]
@@ -383,7 +408,9 @@ class GeneratorTrainer(object):
 
     @torch.no_grad()
     def step(self, all_reduce=True):
-        if all_reduce:
+        if all_reduce and self._buckets is not None:
+            self._buckets.finish()          # most buckets were averaged underneath the backward pass; wait for the rest
+        elif all_reduce:
             sharding.average_gradients(self.flat_g)
         self.t += 1
         if self.t_dev is not None:

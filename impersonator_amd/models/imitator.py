@@ -217,6 +217,50 @@ class Imitator(BaseModel):
         front_mask = self.render.encode_front_fim(self.tsf_info['fim'], transpose=True, front_fn=True)
         return (1 - front_mask) * preds + self.tsf_info['tsf_img'] * front_mask * (1 - mask)
 
+    # ------------------------------------------------------------------ one frame per call, as ONE launch (latency form)
+    @torch.no_grad()
+    def frame_graph(self, batch=1, cam_strategy='smooth'):
+        """(extension) `transfer_params_by_smpl` + `forward` for `batch` frames -- the body of the reference's per-frame loop,
+        models/imitator.py:166-171 -- captured once as a HIP graph and replayed per call: at batch 1 the ~70 kernels of a frame are
+        launch-bound when they are issued one by one from Python (about 20 us each on the host), one graph launch is not.
+        Returns `run(tgt_smpl, t=1) -> preds`: the same values as the eager calls, bit for bit (same kernels, same order); `preds`
+        and `self.tsf_info` are the graph's own static tensors, overwritten by the next call.  The source must be personalised
+        first; personalising another source or changing the generator's precision needs a new graph."""
+        if self.src_info is None:
+            raise RuntimeError("frame_graph: personalize a source first")
+        dev = self.src_info['img'].device
+        width = 75 + int(self.src_info['shape'].shape[1])
+        static_smpl = torch.zeros((batch, width), device=dev, dtype=torch.float32)
+        static_first = torch.zeros((1, 3), device=dev, dtype=torch.float32)
+        if self.first_cam is not None:
+            static_first.copy_(self.first_cam.reshape(1, 3))
+        self.first_cam = static_first              # the captured kernels read the camera reference through this pointer
+        self.generator.reserve(batch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # eager passes first: handles, scratch, per-device kernel attributes exist afterwards
+            for _ in range(2):
+                self.forward(self.transfer_params_by_smpl(static_smpl, cam_strategy, t=1), self.tsf_info['T'])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            tsf_inputs = self.transfer_params_by_smpl(static_smpl, cam_strategy, t=1)
+            preds = self.forward(tsf_inputs, self.tsf_info['T'])
+        info = self.tsf_info
+
+        def run(tgt_smpl, t=1):
+            tgt = torch.as_tensor(tgt_smpl, dtype=torch.float32).reshape(batch, width)
+            if t == 0 and cam_strategy == 'smooth':
+                static_first.copy_(tgt[0:1, 0:3], non_blocking=True)
+            static_smpl.copy_(tgt, non_blocking=True)
+            graph.replay()
+            self.tsf_info = info
+            return preds
+
+        run.graph, run.static_smpl, run.preds = graph, static_smpl, preds
+        return run
+
     # ------------------------------------------------------------------ stream pipeline over batches
     lanes = 2   # generator engines (and HIP streams) predict_batches deals consecutive batches to: 1 or 2; env LWG_LANES
     MAX_LANES = 2   # a third lane measured -3 % (profiles/r03_bench_lanes3.json) and is not offered
@@ -231,6 +275,20 @@ class Imitator(BaseModel):
     fuse = 2
     # entries of tsf_info with one row per frame (hmr.get_details + SMPLRenderer.transfer, imitator.py:236-268)
     PER_FRAME_KEYS = ('theta', 'cam', 'pose', 'shape', 'verts', 'j2d', 'j3d', 'fim', 'wim', 'cond', 'tsf_img', 'T')
+
+    @staticmethod
+    def _adjacent_rows(chunks):
+        """`chunks` as one (sum of rows, width) view when they are consecutive row blocks of ONE contiguous tensor, else None."""
+        c0 = chunks[0]
+        if any(c.dim() != 2 or not c.is_contiguous() or c.dtype != torch.float32 or c.device != c0.device or c.shape[1] != c0.shape[1]
+               for c in chunks):
+            return None
+        base, off, width = c0.untyped_storage().data_ptr(), c0.storage_offset(), c0.shape[1]
+        for c in chunks:
+            if c.untyped_storage().data_ptr() != base or c.storage_offset() != off:
+                return None
+            off += c.shape[0] * width
+        return c0.as_strided((sum(c.shape[0] for c in chunks), width), (width, 1), c0.storage_offset())
 
     def _lanes(self, n):
         """n (stream, generator) pairs, each with its own HIP stream; lane 0 drives self.generator, the others an
@@ -289,7 +347,11 @@ class Imitator(BaseModel):
                     # one launch sequence for the whole round (the kernels are latency-bound at these sizes), then
                     # per-batch views of every result; a later chunk with t == 0 would reset the camera reference
                     # mid-way, that (unusual) order takes the chunk-by-chunk path below
-                    whole = torch.cat([c.reshape(n, -1) for (c, _), n in zip(items, sizes)], dim=0)
+                    # consecutive row blocks of one tensor (what _run_batches, sharding.imitate_sharded and bench.py hand over)
+                    # are taken as ONE view: no copy kernel in the per-round sequence; anything else is concatenated
+                    whole = self._adjacent_rows([c.reshape(n, -1) for (c, _), n in zip(items, sizes)])
+                    if whole is None:
+                        whole = torch.cat([c.reshape(n, -1) for (c, _), n in zip(items, sizes)], dim=0)
                     tsf_inputs = self.transfer_params_by_smpl(whole, cam_strategy, t=items[0][1])
                     info, k0 = self.tsf_info, 0
                     whole_inputs, whole_T = tsf_inputs, info['T']

@@ -131,8 +131,9 @@ class Impersonator(BaseModel):
                                           "vgg19(pretrained=True).state_dict(); there is no download here)")
             self._vgg_state = path if isinstance(path, dict) else torch.load(path, map_location='cpu')
         self._g_trainer = None
-        self._graph = self._graph_terms = None   # optimize_parameters_graphed
+        self._graph = self._graph_terms = self._graph_lrs = None   # optimize_parameters_graphed
         self._graph_warm = 0
+        self._graph_failed = False
         self._real_src = self._bg_mask = None
 
     def _generator_trainer(self):
@@ -241,41 +242,73 @@ class Impersonator(BaseModel):
 
     def drop_graph(self):
         """Forget the captured iteration (new batch shape, new learning rate: both are baked into it)."""
+        # the next graphed call warms up again before it captures: a new batch shape picks kernel variants (per-device function
+        # attributes), scratch sizes and handles that must exist BEFORE a capture starts
+        self._graph_warm = 0
         if self._graph is not None:
-            self._graph = self._graph_terms = None
-            self._generator_trainer().use_device_step(False)
-            _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 0, 0.0, 0.0))
+            self._graph = self._graph_terms = self._graph_batch = self._graph_lrs = None
+            self._device_steps(False)
+
+    def _device_steps(self, on):
+        """Adam's step counts of G and D on the device (graph replay) or back on the host."""
+        self._generator_trainer().use_device_step(on)
+        b1, b2 = (float(self._D_betas[0]), float(self._D_betas[1])) if on else (0.0, 0.0)
+        _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 1 if on else 0, b1, b2))
 
     def optimize_parameters_graphed(self, warmup=2):
         """optimize_parameters() as ONE launch (extension): a training iteration is ~1500 kernel launches issued from Python at
-        ~20 us each -- as long as the kernels themselves take.  The first `warmup` calls run eagerly (every lazily allocated
-        buffer and per-device kernel attribute exists afterwards), the next one captures generator pass + update and discriminator
-        update in a HIP graph (torch.cuda.graph; liblwg launches on torch's current stream, which is the capturing one), and
-        every call from then on is a replay.  What a replay cannot re-read from the host lives on the device: the batch
-        (set_input copies into the captured tensors), Adam's step counts (lwg_adam_update_device_step).  The learning rates
-        ARE baked in: whoever changes one calls drop_graph().  Single-process only (the gradient all-reduce of a data-parallel
-        job stays outside a capture here), and not with --use_face (its crops are host-side integers per batch): both fall back to
-        optimize_parameters().  Returns the same loss terms."""
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            return self.optimize_parameters()
-        if self._face_state is not None:
+        ~20 us each -- as long as the kernels themselves take.  The first `warmup` calls (after construction, and again after every
+        drop_graph(): a new batch shape) run eagerly -- every lazily allocated buffer, handle and per-device kernel attribute exists
+        afterwards -- the next one captures generator pass + update and discriminator update in a HIP graph (torch.cuda.graph;
+        liblwg launches on torch's current stream, which is the capturing one), and every call from then on is a replay.
+        What a replay cannot re-read from the host lives on the device: the batch (PRIVATE static tensors the capture reads;
+        set_input copies every new batch into them, the caller's own tensors are never written), Adam's step counts
+        (lwg_adam_update_device_step).  The learning rates are baked into the graph: a changed `_current_lr_D` / generator `lr`
+        is noticed at the next call, which drops the graph and captures again.  Data-parallel jobs: the bucketed gradient
+        all-reduces (sharding.GradientBuckets) and the discriminator's are captured with the iteration (RCCL collectives are
+        graph-capturable; env LWG_GRAPH_COLLECTIVES=0 keeps multi-rank jobs eager).  If a capture fails for any reason the model
+        falls back to eager iterations for good (host step counts restored).  Not with --use_face (its crops are host-side
+        integers per batch).  Returns the same loss terms."""
+        import os
+        from .. import sharding
+        if self._face_state is not None or self._graph_failed:
             return self.optimize_parameters()   # --use_face crops at the batch's head boxes: host integers, different every batch
+        if sharding.collectives_active() and os.environ.get("LWG_GRAPH_COLLECTIVES", "1") == "0":
+            return self.optimize_parameters()
+        tr = self._generator_trainer()
+        if self._graph is not None and self._graph_lrs != (float(self._current_lr_D), float(tr.lr)):
+            self.drop_graph()                   # a learning-rate decay step: the rates are constants of the captured kernels
         if self._graph is None:
             if self._graph_warm < warmup:
                 self._graph_warm += 1
                 return self.optimize_parameters()
-            tr = self._generator_trainer()
-            tr.use_device_step(True)
-            _lib.check(_lib.load().lwg_discriminator_use_device_step(self._D._ensure_handle(), 1, float(self._D_betas[0]),
-                                                                     float(self._D_betas[1])))
-            batch = dict(input_G_bg=self._input_G_bg, input_G_src=self._input_G_src, input_G_tsf=self._input_G_tsf, T=self._T,
-                         real_src=self._real_src, real_tsf=self._real_tsf, bg_mask=self._bg_mask)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                terms, (_, _, fake_tsf_imgs, _) = tr.optimize_G(batch)
-                terms = dict(terms, d_loss=self._optimize_D(fake_tsf_imgs))
+            names = ("_input_G_bg", "_input_G_src", "_input_G_tsf", "_T", "_real_src", "_real_tsf", "_bg_mask")
+            caller = {k: getattr(self, k) for k in names}
+            try:
+                self._device_steps(True)
+                # private static copies: what the graph reads and set_input overwrites
+                for k, v in caller.items():
+                    setattr(self, k, None if v is None else v.detach().clone())
+                batch = dict(input_G_bg=self._input_G_bg, input_G_src=self._input_G_src, input_G_tsf=self._input_G_tsf, T=self._T,
+                             real_src=self._real_src, real_tsf=self._real_tsf, bg_mask=self._bg_mask)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    terms, (_, _, fake_tsf_imgs, _) = tr.optimize_G(batch)
+                    terms = dict(terms, d_loss=self._optimize_D(fake_tsf_imgs))
+            except Exception as e:   # noqa: BLE001 -- whatever broke the capture, training must go on eagerly
+                import warnings
+                warnings.warn("optimize_parameters_graphed: capture failed (%s: %s); continuing with eager iterations"
+                              % (type(e).__name__, e))
+                self._graph = self._graph_terms = None
+                self._graph_failed = True
+                torch.cuda.synchronize()
+                for k, v in caller.items():
+                    setattr(self, k, v)
+                self._device_steps(False)
+                return self.optimize_parameters()
             self._graph, self._graph_terms = graph, terms
+            self._graph_lrs = (float(self._current_lr_D), float(tr.lr))
         self._graph.replay()
         return {k: float(v) for k, v in self._graph_terms.items()}
 

@@ -126,10 +126,12 @@ class SMPL(nn.Module):
         self.register_buffer('parents_t', torch.from_numpy(self.parents.astype(np.int32)))
         # "compensated" mode (lwg_smpl_forward_f64): the same folding, in fp64, of the fp32 tensors the model actually holds
         jreg32 = self.J_regressor.double().numpy().T                               # (24, nv), the fp32 values
-        self.register_buffer('J_template_d', torch.from_numpy(jreg32 @ self.v_template.double().numpy()).contiguous())
+        # non-persistent: derived from the fp32 buffers, so checkpoints keep the reference's keys (strict load_state_dict works)
+        self.register_buffer('J_template_d', torch.from_numpy(jreg32 @ self.v_template.double().numpy()).contiguous(),
+                             persistent=False)
         sd32 = self.shapedirs.double().numpy().reshape(self.num_betas, -1, 3)      # (nb, nv, 3)
         self.register_buffer('J_shapedirs_d', torch.from_numpy(
-            np.einsum('jv,kvc->kjc', jreg32, sd32).reshape(self.num_betas, -1)).contiguous())
+            np.einsum('jv,kvc->kjc', jreg32, sd32).reshape(self.num_betas, -1)).contiguous(), persistent=False)
         self.precision = os.environ.get("LWG_SMPL_PRECISION", self.precision)
         self._ws = None
 
@@ -165,6 +167,16 @@ class SMPL(nn.Module):
         if self.precision not in ("fp32", "compensated"):
             raise ValueError("SMPL.precision must be 'fp32' or 'compensated', not %r" % (self.precision,))
         f64 = self.precision == "compensated"
+        if f64 and (self.J_template_d.dtype != torch.float64 or self.J_shapedirs_d.dtype != torch.float64):
+            # nn.Module.float() / .half() / .to(dtype) casts every floating buffer; the kernel reads these two as double
+            # through raw pointers.  Restore them (exactly: they are functions of the fp32 buffers) instead of reading garbage.
+            jreg = self.J_regressor.double().t()
+            self.J_template_d = (jreg @ self.v_template.double()).contiguous()
+            self.J_shapedirs_d = torch.einsum('jv,kvc->kjc', jreg, self.shapedirs.double().reshape(self.num_betas, -1, 3)) \
+                .reshape(self.num_betas, -1).contiguous()
+        for name in ("v_template", "shapedirs", "posedirs", "J_template", "J_shapedirs", "weights", "joint_regressor"):
+            if getattr(self, name).dtype != torch.float32:
+                raise TypeError("SMPL.%s is %s: the device kernels read fp32 (do not cast the SMPL module)" % (name, getattr(self, name).dtype))
         _lib.check((lib.lwg_smpl_forward_f64 if f64 else lib.lwg_smpl_forward)(
             _lib.ptr(th), n, self.num_betas, nv, joints.shape[1], _lib.ptr(self.v_template), _lib.ptr(self.shapedirs),
             _lib.ptr(self.posedirs), _lib.ptr(self.J_template_d if f64 else self.J_template),

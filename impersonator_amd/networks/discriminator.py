@@ -176,8 +176,7 @@ class PatchDiscriminator(NetworkBase):
         lib = _lib.load()
         loss = torch.empty((), device=real.device, dtype=torch.float32)
         _lib.check(lib.lwg_discriminator_backward(h, _lib.ptr(real), _lib.ptr(fake), bs, _lib.ptr(loss), _lib.stream_ptr()))
-        if all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
+        if all_reduce and sharding.collectives_active():
             sharding.average_gradients(self.flat_buffers()[1])
         _lib.check(lib.lwg_discriminator_adam_step(h, float(lr), float(betas[0]), float(betas[1]), float(eps), _lib.stream_ptr()))
         return loss

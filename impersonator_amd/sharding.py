@@ -56,6 +56,21 @@ def shard_blocks(num_frames, batch, rank, world):
     return [blk for i, blk in enumerate(frame_blocks(num_frames, batch)) if i % world == rank]
 
 
+def local_rows(rows, blocks):
+    """The rows of `blocks` packed into ONE contiguous tensor, plus each block's [a, b) row range inside it."""
+    if not blocks:
+        return rows[0:0], []
+    if all(blocks[i][1] == blocks[i + 1][0] for i in range(len(blocks) - 1)):
+        mine = rows[blocks[0][0]:blocks[-1][1]]          # world 1: already one run, a view
+    else:
+        mine = torch.cat([rows[s:e] for s, e in blocks], dim=0)
+    bounds, a = [], 0
+    for s, e in blocks:
+        bounds.append((a, a + e - s))
+        a += e - s
+    return mine.contiguous(), bounds
+
+
 def barrier(device=None):
     if dist.is_initialized():
         dist.barrier()
@@ -112,22 +127,115 @@ def imitate_sharded(imitator, tgt_smpls, batch, cam_strategy='smooth', rank=0, w
     if cam_strategy == 'smooth' and n:
         imitator.first_cam = smpls[0:1, 0:3].clone()
     blocks = shard_blocks(n, batch, rank, world)
+    # this rank's frames packed once (round-robin blocks are not neighbours in `smpls`): consecutive chunks are then adjacent
+    # row blocks of one tensor and a round's geometry takes them as a view (Imitator._adjacent_rows) -- no per-round copy kernel
+    mine, bounds = local_rows(smpls, blocks)
     # t = 0 would re-derive first_cam from the chunk, which is only right for the block that starts the sequence
-    chunks = ((smpls[s:e], s) for s, e in blocks)
+    chunks = ((mine[a:b], s) for (a, b), (s, _) in zip(bounds, blocks))
     local = []
     for _, preds in imitator.predict_batches(chunks, cam_strategy):
         local += list(preds.permute(0, 2, 3, 1).cpu().numpy())
     return gather_in_frame_order(local, n, batch, rank, world)
 
 
+def collectives_active():
+    """True when gradient averaging really runs a collective: an initialised group with more than one rank, or
+    LWG_FORCE_DIST=1 (the one-GPU test hook).  THE one predicate every data-parallel branch asks (generator and discriminator
+    gradient averaging, the bucketed overlap, the graph-replay path)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def average_gradients(flat_grads):
     """Data-parallel training: averages a flat gradient tensor over the ranks in place (all-reduce SUM
     then divide) -- RCCL over xGMI for CUDA tensors, gloo on CPU.  No-op without an initialised multi-rank group.  The
     reference does this implicitly through nn.DataParallel (models/impersonator_trainer.py:196-214)."""
-    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced()):
+    if collectives_active():
         dist.all_reduce(flat_grads)
         flat_grads.div_(dist.get_world_size())
     return flat_grads
+
+
+class GradientBuckets(object):
+    """Bucketed gradient averaging overlapped with the backward pass (the reference leaves this to
+    nn.DataParallel's reduce, models/impersonator_trainer.py:196-214).
+
+    The flat gradient buffer is cut into contiguous buckets of at least `bucket_bytes` (RCCL rings over xGMI are per-link bound:
+    few, large messages).  The backward pass writes every parameter's gradient exactly once; `written(key)` counts a bucket's
+    keys down and `checkpoint()` -- called by the backward pass AFTER it has enqueued the kernels that write them -- hands every
+    complete bucket to a side stream: event on the compute stream, all-reduce + 1/world scaling of that slice there, while the
+    compute stream goes on with the layers in front.  `finish()` launches what is left and makes the compute stream wait; the
+    optimiser step comes after it.  The hand-written backward runs transfer stream -> source stream -> BGNet, and the flat buffer
+    is laid out BGNet, source, transfer: it fills back to front, so the last third of the bytes is on the wire while two thirds of
+    the backward pass are still to run.  Results equal `average_gradients(flat)` bit for bit (the same all-reduce per element,
+    only cut into pieces).  Capturable in a HIP graph: fork and join are events on the capturing stream."""
+
+    def __init__(self, flat, ranges, bucket_bytes=32 << 20):
+        """ranges: [(key, lo, hi)] element ranges of `flat`, ascending and contiguous."""
+        self.flat = flat
+        self.buckets = []          # [lo, hi, set(keys)]
+        cur = None
+        for key, lo, hi in ranges:
+            if cur is None:
+                cur = [lo, hi, {key}]
+            else:
+                cur[1] = hi
+                cur[2].add(key)
+            if (cur[1] - cur[0]) * flat.element_size() >= bucket_bytes:
+                self.buckets.append(cur)
+                cur = None
+        if cur is not None:
+            if self.buckets:       # a small tail joins its neighbour
+                self.buckets[-1][1] = cur[1]
+                self.buckets[-1][2] |= cur[2]
+            else:
+                self.buckets.append(cur)
+        self.of_key = {k: i for i, b in enumerate(self.buckets) for k in b[2]}
+        self.stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+        self.launched_log = []     # (bucket index, number of keys still unwritten elsewhere) per launch of the last pass: tests read it
+        self.begin()
+
+    def begin(self):
+        """start of a backward pass"""
+        self.left = [len(b[2]) for b in self.buckets]
+        self.ready, self.done = [], [False] * len(self.buckets)
+        self.launched_log = []
+
+    def written(self, key):
+        i = self.of_key[key]
+        self.left[i] -= 1
+        if self.left[i] == 0:
+            self.ready.append(i)
+
+    def _launch(self, i):
+        lo, hi, _ = self.buckets[i]
+        view = self.flat[lo:hi]
+        world = dist.get_world_size()
+        self.launched_log.append((i, sum(self.left)))
+        if self.stream is None:
+            dist.all_reduce(view)
+            view.div_(world)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                dist.all_reduce(view)
+                view.div_(world)
+        self.done[i] = True
+
+    def checkpoint(self):
+        """the kernels writing every key reported so far are enqueued: complete buckets go on the wire"""
+        ready, self.ready = self.ready, []
+        for i in ready:
+            self._launch(i)
+
+    def finish(self):
+        self.checkpoint()
+        for i, d in enumerate(self.done):
+            if not d:                      # keys nobody reported (a layer without a gradient this pass): still averaged
+                self._launch(i)
+        if self.stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
 
 
 def collective_info(device=None):

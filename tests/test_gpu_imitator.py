@@ -230,3 +230,54 @@ def test_lane_pipeline_stress(imi, depth):
                 assert torch.equal(p, q)
     finally:
         imitator.round_depth = keep
+
+
+def test_predict_batches_launches_no_framework_kernel():
+    """The timed step of bench.py (Imitator.predict_batches over adjacent row blocks of one SMPL tensor) under the torch profiler:
+    every device record is a liblwg kernel -- no ATen kernel (`torch.cat` of the round's chunks used to be one), no runtime
+    fill / copy kernel (zero-fills belong to the first writer, not to a hipMemsetAsync)."""
+    from torch.autograd import DeviceType
+    from torch.profiler import ProfilerActivity, profile
+    imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=8, seed=0, image_size=256)
+    imitator.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+    smpls = torch.from_numpy(demo.synthetic_smpls(256, seed=0)).cuda()
+    imitator.first_cam = smpls[0:1, 0:3].clone()
+    chunks = lambda: ((smpls[s:s + 8], s) for s in range(8, 8 + 16 * 8, 8))     # 16 batches = two rounds of two lanes x depth 4
+    for _ in imitator.predict_batches(chunks()):          # first pass: lanes, replicas, scratch, lazy kernel attributes
+        pass
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        n = 0
+        for _, preds in imitator.predict_batches(chunks()):
+            n += preds.shape[0]
+        torch.cuda.synchronize()
+    assert n == 128
+    records = [e.name for e in prof.events() if e.device_type == DeviceType.CUDA]
+    ours = [k for k in records if "lwg" in k]
+    foreign = sorted({k for k in records if "lwg" not in k})
+    print("%d device records, %d liblwg kernels; others: %s" % (len(records), len(ours), foreign))
+    assert len(ours) >= 16 * 20, "the profiler saw too few liblwg kernels: %s" % sorted(set(records))[:10]
+    assert not [k for k in foreign if "at::" in k or "elementwise" in k or "Cat" in k], foreign
+    assert not [k for k in foreign if "fill" in k.lower() or "memset" in k.lower() or "copy" in k.lower()], foreign
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_frame_graph_replay_equals_the_eager_frame_loop(batch):
+    """Imitator.frame_graph (one HIP-graph launch per call, the latency form of the reference's per-frame loop,
+    models/imitator.py:166-171) returns what transfer_params_by_smpl + forward return, bit for bit, frame after frame,
+    including the camera reference taken at t == 0."""
+    imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=batch, seed=0, image_size=256)
+    imitator.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+    smpls = torch.from_numpy(demo.synthetic_smpls(64, seed=0)).cuda()
+    eager = []
+    for t in range(0, 6 * batch, batch):
+        x = imitator.transfer_params_by_smpl(smpls[t:t + batch], "smooth", t=t)
+        eager.append((imitator.forward(x, imitator.tsf_info["T"]).clone(), imitator.tsf_info["fim"].clone(),
+                      imitator.tsf_info["T"].clone()))
+    imitator.first_cam = None
+    run = imitator.frame_graph(batch=batch)
+    for i, t in enumerate(range(0, 6 * batch, batch)):
+        p = run(smpls[t:t + batch], t=t)
+        torch.cuda.synchronize()
+        assert torch.equal(p, eager[i][0]), "frame %d" % t
+        assert torch.equal(imitator.tsf_info["fim"], eager[i][1]) and torch.equal(imitator.tsf_info["T"], eager[i][2])

@@ -1,8 +1,9 @@
 """The multi-rank code paths BASELINE.json's configs 3 and 5 depend on, executed on the ONE visible GPU:
 two processes with a gloo rendezvous (RCCL wants a GPU per rank; on a multi-GPU node the same code takes "nccl").
 
-  * `bench.py --gpus 2` under `python -m torch.distributed.run` -- exactly the driver's launch line -- prints ONE JSON
-    line with n_gpus 2, weak scaling, a finite value and the roofline block;
+  * `bench.py --gpus 2` -- BARE (it starts its own ranks) and under `python -m torch.distributed.run`, exactly the driver's
+    launch line -- prints ONE JSON line with n_gpus 2, weak scaling, a finite value, the roofline block and the per-rank block
+    that proves the two ranks; with fewer GPUs than ranks and no test hook it exits 1;
   * a data-parallel training iteration: two ranks run `Impersonator.optimize_parameters` on half a batch each with the
     gradient all-reduce on; the averaged gradients and the updated parameters of G and D equal the single-process step
     on the whole batch (the reference gets the same thing from nn.DataParallel, models/impersonator_trainer.py:196-214,
@@ -45,17 +46,63 @@ def _torchrun(script_args, nproc=2, timeout=900):
     return lines
 
 
-def test_bench_two_ranks_under_torchrun():
-    lines = _torchrun(["bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-fp32-mode",
-                       "--no-secondary"])
-    assert len(lines) == 1, lines          # rank 0 only
-    line = json.loads(lines[0])
+def _bare(script_args, env_extra, timeout=900):
+    """`python <script> ...` with NO torch.distributed environment (how the driver starts `bench.py --gpus 1`)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, **env_extra)
+    return subprocess.run([sys.executable] + script_args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout, text=True)
+
+
+def _check_two_rank_line(line):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 6 and line["warmup"] == 2
     assert np.isfinite(line["value"]) and line["value"] > 0
     assert abs(line["value"] - 2 * 8 * 6 / (line["ms_per_step"] * 6e-3)) <= 1e-2 * line["value"]   # whole-job frames / max-over-ranks time
     assert line["roofline"]["kernel"].startswith("conv") and 0 < line["roofline"]["frac"] < 1
     assert line["config"]["parallelism"] == "frame-sharded replicas x2"
     assert "cpu_baseline" not in line      # rank 0 at N = 1 only
+    # the N-rank line proves itself: communicator size, per-rank rates and devices, the single-rank rate of the same run
+    assert line["rccl"]["ranks"] == 2 and line["rccl"]["allreduce_of_ones"] == 2.0
+    rk = line["ranks"]
+    assert len(rk["per_rank"]) == 2 and sorted(r["rank"] for r in rk["per_rank"]) == [0, 1]
+    assert all(r["fps"] > 0 and r["device"]["name"] for r in rk["per_rank"])
+    assert rk["fps_min"] <= rk["fps_median"] <= rk["fps_max"] and rk["single_rank_fps"] > 0
+    assert abs(rk["linear_frac"] - line["value"] / (2 * rk["single_rank_fps"])) <= 1e-3
+    assert line["repeats"] == 3 and line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
+    assert len(line["ms_per_step_windows"]) == 3
+
+
+def test_bench_two_ranks_bare_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (the way the driver starts --gpus 1): bench.py re-executes itself under
+    torch.distributed.run with two ranks (gloo hook: they share the one GPU) and the line says n_gpus 2 -- never a silent n_gpus 1."""
+    p = _bare(["bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline", "--no-fp32-mode",
+               "--no-secondary"], {"LWG_DIST_BACKEND": "gloo"})
+    assert p.returncode == 0, "bare bench.py --gpus 2 failed (%d)\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines          # rank 0 only
+    _check_two_rank_line(json.loads(lines[0]))
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """On a box with ONE GPU `python bench.py --gpus 2` (no gloo hook) must exit 1 with a message, not print n_gpus 1."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    p = _bare(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], {}, timeout=300)
+    assert p.returncode == 1, (p.returncode, p.stdout[-500:], p.stderr[-500:])
+    assert "refusing" in p.stderr and "--gpus 2" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    # and a WORLD_SIZE that disagrees with --gpus is refused as well
+    q = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, text=True,
+                       env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", PYTHONPATH=ROOT), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert q.returncode != 0 and "WORLD_SIZE" in q.stderr and not [l for l in q.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_two_ranks_under_torchrun():
+    lines = _torchrun(["bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline",
+                       "--no-fp32-mode", "--no-secondary"])
+    assert len(lines) == 1, lines          # rank 0 only
+    _check_two_rank_line(json.loads(lines[0]))
 
 
 def _opt(batch):
