@@ -84,6 +84,9 @@ _PROTOS = {
     "lwg_instance_norm_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "lwg_instance_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lwg_grid_sample_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lwg_grid_sample_plan_bytes": (_c.c_size_t, [_i, _i, _i, _i, _i, _i]),
+    "lwg_grid_sample_plan": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _c.c_size_t, _vp]),
+    "lwg_grid_sample_backward_planned": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _c.c_size_t, _vp, _vp]),
     "lwg_adam_update": (_i, [_vp, _vp, _vp, _vp, _c.c_size_t, _c.c_long, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
     "lwg_adam_update_device_step": (_i, [_vp, _vp, _vp, _vp, _c.c_size_t, _vp, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
     "lwg_discriminator_use_device_step": (_i, [_vp, _i, _c.c_float, _c.c_float]),

@@ -34,6 +34,7 @@ SOURCES = [
     ("generator.hip", []),
     ("inpaint.hip", []),
     ("train.hip", []),
+    ("scatter.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
 

@@ -155,16 +155,48 @@ def instance_norm_backward(x, y, dy, stats, gamma, out_dgamma=None, out_dbeta=No
     return dx, dgamma, dbeta
 
 
+class GridSamplePlan(object):
+    """The scatter of one flow field turned into per-texel contribution lists in a fixed order (lwg_grid_sample_plan): built once
+    per (grid, source shape), applied to any number of gradient tensors of that shape (any channel count)."""
+
+    def __init__(self, grid, x_shape, align_corners=False):
+        _chk(grid)
+        lib = _lib.load()
+        self.xn, self.h, self.w = int(x_shape[0]), int(x_shape[1]), int(x_shape[2])
+        self.n, self.ho, self.wo = int(grid.shape[0]), int(grid.shape[1]), int(grid.shape[2])
+        nbytes = lib.lwg_grid_sample_plan_bytes(self.xn, self.h, self.w, self.n, self.ho, self.wo)
+        if not nbytes:
+            raise ValueError("grid_sample plan: bad dimensions %s for a grid of %s" % (tuple(x_shape), tuple(grid.shape)))
+        self.buf = torch.empty(nbytes // 4, device=grid.device, dtype=torch.int32)
+        self.nbytes = nbytes
+        _lib.check(lib.lwg_grid_sample_plan(_lib.ptr(grid), self.xn, self.h, self.w, self.n, self.ho, self.wo, int(align_corners),
+                                            _lib.ptr(self.buf), nbytes, _lib.stream_ptr()))
+
+    def matches(self, x_shape, dy_shape):
+        return (int(x_shape[0]), int(x_shape[1]), int(x_shape[2])) == (self.xn, self.h, self.w) and \
+            tuple(int(v) for v in dy_shape[:3]) == (self.n, self.ho, self.wo)
+
+
 @torch.no_grad()
-def grid_sample_backward(dy, grid, x_shape, align_corners=False):
+def grid_sample_backward(dy, grid, x_shape, align_corners=False, plan=None, deterministic=True):
     """Gradient of F.grid_sample(x, grid) (bilinear, zeros) wrt x: dy (n,Ho,Wo,C) NHWC, grid (n,Ho,Wo,2) -> dx of NHWC
-    shape x_shape (xn,H,W,C), xn in {1, n} (1: one source shared by the batch, gradients summed)."""
+    shape x_shape (xn,H,W,C), xn in {1, n} (1: one source shared by the batch, gradients summed).  Deterministic (default): a
+    gather over a GridSamplePlan (pass `plan` to share one between the warps of a pyramid level), contributions added in a fixed
+    order -- bit-reproducible; deterministic=False: one scatter kernel with float atomics (what torch does)."""
     _chk(dy, grid)
     xn, h, w, c = x_shape
     n, ho, wo, _ = dy.shape
     dx = torch.zeros(tuple(x_shape), device=dy.device, dtype=torch.float32)
-    _lib.check(_lib.load().lwg_grid_sample_backward(_lib.ptr(dy), _lib.ptr(grid), xn, c, h, w, n, ho, wo, int(align_corners),
-                                                    _lib.ptr(dx), _lib.stream_ptr()))
+    if not deterministic:
+        _lib.check(_lib.load().lwg_grid_sample_backward(_lib.ptr(dy), _lib.ptr(grid), xn, c, h, w, n, ho, wo, int(align_corners),
+                                                        _lib.ptr(dx), _lib.stream_ptr()))
+        return dx
+    if plan is None:
+        plan = GridSamplePlan(grid, x_shape, align_corners)
+    elif not plan.matches(x_shape, dy.shape):
+        raise ValueError("grid_sample_backward: the plan was built for other dimensions")
+    _lib.check(_lib.load().lwg_grid_sample_backward_planned(_lib.ptr(dy), c, xn, h, w, n, ho, wo, _lib.ptr(plan.buf), plan.nbytes,
+                                                            _lib.ptr(dx), _lib.stream_ptr()))
     return dx
 
 

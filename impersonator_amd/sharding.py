@@ -172,21 +172,21 @@ class GradientBuckets(object):
     def __init__(self, flat, ranges, bucket_bytes=32 << 20):
         """ranges: [(key, lo, hi)] element ranges of `flat`, ascending and contiguous."""
         self.flat = flat
-        self.buckets = []          # [lo, hi, set(keys)]
+        self.buckets = []          # [lo, hi, set(keys)], ascending
         cur = None
-        for key, lo, hi in ranges:
+        for key, lo, hi in reversed(list(ranges)):   # cut from the BACK: the buffer fills back to front, full-size buckets first
             if cur is None:
                 cur = [lo, hi, {key}]
             else:
-                cur[1] = hi
+                cur[0] = lo
                 cur[2].add(key)
             if (cur[1] - cur[0]) * flat.element_size() >= bucket_bytes:
-                self.buckets.append(cur)
+                self.buckets.insert(0, cur)
                 cur = None
         if cur is not None:
-            if self.buckets:       # a small tail joins its neighbour
-                self.buckets[-1][1] = cur[1]
-                self.buckets[-1][2] |= cur[2]
+            if self.buckets:       # a small remainder at the front joins its neighbour (the last bucket to complete anyway)
+                self.buckets[0][0] = cur[0]
+                self.buckets[0][2] |= cur[2]
             else:
                 self.buckets.append(cur)
         self.of_key = {k: i for i, b in enumerate(self.buckets) for k in b[2]}

@@ -355,6 +355,19 @@ LWG_API int lwg_instance_norm_backward(const float *x, const float *y, const flo
  * dx (xn,H,W,C) ACCUMULATED (zero it first), xn in {1, n}.  Atomic fp32 adds (not bit-reproducible, as torch's). */
 LWG_API int lwg_grid_sample_backward(const float *dy, const float *grid, int xn, int C, int H, int W, int n, int Ho, int Wo,
                                      int align_corners, float *dx, lwg_stream_t stream);
+/* The same gradient, DETERMINISTIC (what the training step uses; replaces torch's grid_sampler_2d_backward behind
+ * networks/generator.py:312-315 in `loss_G.backward()`, models/impersonator_trainer.py:355-356): the scatter is planned once per
+ * flow field -- every source texel gets the list of (output pixel, tap, bilinear weight) that reach it, sorted by pixel -- and
+ * applied per tensor as a gather that adds the contributions in that fixed order (bit-reproducible; same zeros-padding taps and
+ * weights as lwg_grid_sample_nhwc).  plan: caller-owned device memory of lwg_grid_sample_plan_bytes() bytes (4-byte aligned),
+ * written by lwg_grid_sample_plan, read by any number of lwg_grid_sample_backward_planned calls with the SAME dimensions
+ * (one plan serves every warp of a pyramid level: the Liquid Warping Block warps seven feature maps with one flow).
+ * dx (xn,H,W,C) is ACCUMULATED (zero it first); C a multiple of 4. */
+LWG_API size_t lwg_grid_sample_plan_bytes(int xn, int H, int W, int n, int Ho, int Wo);
+LWG_API int lwg_grid_sample_plan(const float *grid, int xn, int H, int W, int n, int Ho, int Wo, int align_corners, void *plan,
+                                 size_t plan_bytes, lwg_stream_t stream);
+LWG_API int lwg_grid_sample_backward_planned(const float *dy, int C, int xn, int H, int W, int n, int Ho, int Wo, const void *plan,
+                                             size_t plan_bytes, float *dx, lwg_stream_t stream);
 /* torch.optim.Adam step (no weight decay, no amsgrad) on a flat fp32 device tensor; step counts from 1 */
 LWG_API int lwg_adam_update(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, long step, float lr,
                             float beta1, float beta2, float eps, lwg_stream_t stream);

@@ -248,6 +248,41 @@ def test_grid_sample_backward(shared):
     assert _rel(dx.cpu().permute(0, 3, 1, 2), xr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("shared", [False, True])
+def test_grid_sample_backward_is_bit_reproducible_also_on_crowded_texels(shared):
+    """The deterministic gradient (csrc/scatter.hip: per-texel contribution lists in pixel order, gathered): identical bits run
+    after run where the atomic scatter is not, also when a whole image samples ONE location (lists of 48 x 48 entries: the
+    dense-scan path) and when a 3x magnification packs ~9 pixels per texel (the per-thread sort path); one plan serves several
+    tensors; values against float64 autograd."""
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(21)
+    n, C, H, Ho = 3, 32, 16, 48
+    x = torch.randn(1 if shared else n, C, H, H, generator=g)
+    grid = (torch.rand(n, Ho, Ho, 2, generator=g) * 2 - 1) * 0.33           # every output pixel lands in the central third
+    grid[1] = torch.tensor([0.113, -0.271])                                   # image 1: one location for all 2304 pixels
+    grid[2, :, :24] = -2                                                      # sentinel half: samples nothing
+    dy = torch.randn(n, C, Ho, Ho, generator=g)
+    xr = x.double().clone().requires_grad_(True)
+    F.grid_sample(xr.expand(n, -1, -1, -1) if shared else xr, grid.double(), align_corners=False).backward(dy.double())
+    dyd, gd = dy.permute(0, 2, 3, 1).contiguous().cuda(), grid.cuda()
+    shape = (x.shape[0], H, H, C)
+    plan = ops.GridSamplePlan(gd, shape, False)
+    runs = [ops.grid_sample_backward(dyd, gd, shape, False, plan=plan) for _ in range(3)]
+    runs.append(ops.grid_sample_backward(dyd, gd, shape, False))              # a plan of its own
+    torch.cuda.synchronize()
+    assert all(torch.equal(r, runs[0]) for r in runs[1:])
+    assert _rel(runs[0].cpu().permute(0, 3, 1, 2).double(), xr.grad) < 2e-6
+    atomic = ops.grid_sample_backward(dyd, gd, shape, False, deterministic=False)
+    assert _rel(atomic.cpu().permute(0, 3, 1, 2).double(), xr.grad) < 1e-5
+    # the same plan, another channel count
+    dy2 = torch.randn(n, Ho, Ho, 8, generator=g)
+    a = ops.grid_sample_backward(dy2.cuda(), gd, (x.shape[0], H, H, 8), False, plan=plan)
+    b = ops.grid_sample_backward(dy2.cuda(), gd, (x.shape[0], H, H, 8), False, deterministic=False)
+    assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max())
+    with pytest.raises(ValueError):
+        ops.grid_sample_backward(dyd, gd, (x.shape[0], H + 1, H, C), False, plan=plan)
+
+
 def test_adam_update():
     from impersonator_amd import ops
     g = torch.Generator().manual_seed(13)
