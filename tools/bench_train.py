@@ -94,8 +94,10 @@ def measure(batch, image_size, steps=5, warmup=1, precision="bf16x3", script_los
     for _ in range(steps):
         losses = iterate()
     sharding.barrier(dev)
-    dt = sharding.max_over_ranks((time.perf_counter() - t0) / steps, "cpu")
-    out = {"ms_per_iteration": round(dt * 1e3, 2), "launch": "one HIP graph replay per iteration" if graph and world == 1 else "eager", "images_per_s": round(world * batch / dt, 2), "batch_per_rank": batch,
+    import torch.distributed as dist
+    rdev = dev if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"   # RCCL reduces device tensors
+    dt = sharding.max_over_ranks((time.perf_counter() - t0) / steps, rdev)
+    out = {"ms_per_iteration": round(dt * 1e3, 2), "launch": "one HIP graph replay per iteration" if graph and model._graph is not None else "eager", "images_per_s": round(world * batch / dt, 2), "batch_per_rank": batch,
            "world": world, "image_size": image_size,
            "dtype": "f32" if precision == "fp32" else "bf16x3 convs of generator and discriminator (forward, data and weight gradient) + f32",
            "loss": "train_iPER.sh (mask_bce, vgg, face)" if script_loss else "adv + L1 + mask",
@@ -117,7 +119,7 @@ def measure(batch, image_size, steps=5, warmup=1, precision="bf16x3", script_los
             for _ in range(3):
                 sharding.average_gradients(buf)
             torch.cuda.synchronize(dev)
-            ms[name] = sharding.max_over_ranks((time.perf_counter() - t0) / 3, "cpu") * 1e3
+            ms[name] = sharding.max_over_ranks((time.perf_counter() - t0) / 3, rdev) * 1e3
         fg.copy_(keep_g)
         dg.copy_(keep_d)
         import torch.distributed as dist

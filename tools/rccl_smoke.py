@@ -73,6 +73,51 @@ def main():
         torch.cuda.synchronize(dev)
         times[name] = {"bytes": n * 4, "ms": round((time.perf_counter() - t0) / reps * 1e3, 4), "max_abs_err": err}
     out["average_gradients"] = times
+    m._D.release()
+    m._G.release()
+    del m, tr, g_grad, d_grad
+    torch.cuda.empty_cache()
+
+    if os.environ.get("LWG_RCCL_SMOKE_TRAIN", "1") != "0":
+        # the data-parallel training iteration on this process group: gradient buckets all-reduced on a side stream underneath
+        # the backward pass (sharding.GradientBuckets), and the whole iteration -- collectives included -- captured in a HIP graph
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train
+        eager, graphed = bench_train.build(2, 64, "bf16x3", seed=3), bench_train.build(2, 64, "bf16x3", seed=3)
+        same_terms = True
+        for it in range(5):
+            if it == 2:
+                eager._device_steps(True)
+            a, b = eager.optimize_parameters(), graphed.optimize_parameters_graphed()
+            same_terms = same_terms and a == b
+        te, tg = eager._generator_trainer(), graphed._generator_trainer()
+        log = te._buckets.launched_log if te._buckets is not None else []
+        out["train"] = {"bucket_count": len(te._buckets.buckets) if te._buckets is not None else 0,
+                        "bucket_mbytes": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi, _ in te._buckets.buckets] if te._buckets else [],
+                        "launched_while_gradients_were_open": sum(1 for _, left in log if left > 0), "launches": len(log),
+                        "graph_captured_with_collectives": graphed._graph is not None, "graph_failed": graphed._graph_failed,
+                        "replay_equals_eager_terms": bool(same_terms),
+                        "replay_equals_eager_parameters": bool(torch.equal(te.flat_p, tg.flat_p)) and
+                        bool(torch.equal(eager._D.flat_buffers()[0], graphed._D.flat_buffers()[0]))}
+        for mdl in (eager, graphed):
+            mdl._D.release()
+            mdl._G.release()
+        del eager, graphed, te, tg
+        torch.cuda.empty_cache()
+        # what the collectives cost an iteration (256x256, batch 4, graph replay): bucketed + overlapped, one blocking all-reduce
+        # after the backward pass, and no collective at all
+        timing = {}
+        active = sharding.collectives_active
+        for name, env, off in (("bucketed_overlapped", "1", False), ("blocking_after_backward", "0", False), ("no_collective", "1", True)):
+            os.environ["LWG_GRAD_BUCKETS"] = env
+            sharding.collectives_active = (lambda: False) if off else active
+            r = bench_train.measure(4, 256, steps=6, warmup=2, precision="bf16x3", graph=True)
+            timing[name] = r["ms_per_iteration"]
+            torch.cuda.empty_cache()
+        sharding.collectives_active = active
+        os.environ.pop("LWG_GRAD_BUCKETS", None)
+        timing["overlapped_over_none"] = round(timing["bucketed_overlapped"] / timing["no_collective"], 4)
+        out["train"]["ms_per_iteration_256_b4"] = timing
     sharding.barrier(dev)
     if rank == 0:
         print(json.dumps(out))
