@@ -559,7 +559,7 @@ def main():
     imitator.first_cam = smpls[0:1, 0:3].clone()
     blocks = sharding.shard_blocks(args.frames, BATCH, rank, world)
     # this rank's frames packed once, before anything is timed: consecutive chunks are adjacent rows of one tensor
-    mine, bounds = sharding.local_rows(smpls, blocks)
+    my_rows, bounds = sharding.local_rows(smpls, blocks)
 
     def step(i):
         s, e = blocks[i % len(blocks)]
@@ -574,7 +574,7 @@ def main():
         step's work is inside the loop."""
         out = None
         idx = [(first + i) % len(blocks) for i in range(n)]
-        chunks = ((mine[bounds[k][0]:bounds[k][1]], blocks[k][0]) for k in idx)
+        chunks = ((my_rows[bounds[k][0]:bounds[k][1]], blocks[k][0]) for k in idx)
         for _, out in imitator.predict_batches(chunks, "smooth", lanes=lanes):
             pass
         return out

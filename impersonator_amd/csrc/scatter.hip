@@ -71,6 +71,14 @@ __device__ __forceinline__ Taps4 pixel_taps(const float *__restrict__ grid, long
     return o;
 }
 
+// count, fill, cursor, heavy_count <- 0 (a kernel, not hipMemsetAsync: the plan is built inside captured training iterations, and a
+// runtime fill kernel has no place in a step whose every launch is liblwg's)
+__global__ __launch_bounds__(256) void gs_plan_zero_kernel(int *__restrict__ p, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void gs_plan_count_kernel(const float *__restrict__ grid, PlanDims d, PlanView v)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,7 +275,9 @@ int lwg_grid_sample_plan(const float *grid, int xn, int H, int W, int n, int Ho,
                  plan_words(d.T, d.P) * sizeof(int));
     const PlanView v = plan_view(plan, d.T, d.P);
     hipStream_t st = as_stream(stream);
-    LWG_HIP(hipMemsetAsync(v.count, 0, (size_t)(2 * d.T + 2) * sizeof(int), st));   // count, fill, cursor, heavy_count
+    const long nz = 2 * d.T + 2;   // count, fill, cursor, heavy_count
+    gs_plan_zero_kernel<<<(unsigned)((nz + 255) / 256), 256, 0, st>>>(v.count, nz);
+    LWG_LAUNCH_CHECK("gs_plan_zero_kernel");
     const unsigned pb = (unsigned)((d.P + 255) / 256), tb = (unsigned)((d.T + 255) / 256);
     gs_plan_count_kernel<<<pb, 256, 0, st>>>(grid, d, v);
     LWG_LAUNCH_CHECK("gs_plan_count_kernel");

@@ -379,16 +379,21 @@ class GeneratorTrainer(object):
         d, d_skips = self.tsf.decode_regress_backward(d_tsf_img, d_tsf_mask)
         g_res = [None] * self.repeat
         # one deterministic scatter plan per pyramid level (the trunk's seven warps share the 1/8-resolution flow)
-        plans = {l: ops.GridSamplePlan(self.Ts[l], tuple(self.src_enc[l].shape), self.align) for l in range(1, N_DOWN + 1)}
+        # (env LWG_GS_ATOMIC=1: the float-atomic scatter instead, an A/B switch)
+        import os
+        atomic = os.environ.get("LWG_GS_ATOMIC", "0") == "1"
+        plans = {l: None if atomic else ops.GridSamplePlan(self.Ts[l], tuple(self.src_enc[l].shape), self.align)
+                 for l in range(1, N_DOWN + 1)}
         for i in reversed(range(self.repeat)):
             g_res[i] = ops.grid_sample_backward(d.contiguous(), self.Ts[N_DOWN], tuple(self.src_res[i].shape), self.align,
-                                                plan=plans[N_DOWN])
+                                                plan=plans[N_DOWN], deterministic=not atomic)
             d = self.tsf.res[i].backward(d)
         g_enc = [None] * (N_DOWN + 1)
         for i in reversed(range(1, N_DOWN + 1)):
             if i < N_DOWN:
                 d = d + d_skips[i]
-            g_enc[i] = ops.grid_sample_backward(d.contiguous(), self.Ts[i], tuple(self.src_enc[i].shape), self.align, plan=plans[i])
+            g_enc[i] = ops.grid_sample_backward(d.contiguous(), self.Ts[i], tuple(self.src_enc[i].shape), self.align, plan=plans[i],
+                                                deterministic=not atomic)
             d = self.tsf.enc[i].backward(d)
         self.tsf.enc[0].backward(d + d_skips[0], need_dx=False)
         # --- source stream: its own decoder/heads plus the Liquid Warping Block gradients
