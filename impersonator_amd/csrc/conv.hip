@@ -1613,6 +1613,61 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs a)
     }
 }
 
+// The same pass with EIGHT channels per thread, for the split-bf16 format (C % 32 == 0): per lane two 16-byte raw loads, 16 + 16
+// bytes of residual, two 16-byte loads per Liquid-Warping-Block tap, and the hi / lo terms of the eight results leave as two
+// 16-byte stores (apply_kernel: four 8-byte ones per eight channels); the flow sample and its bilinear taps are computed once
+// per eight channels instead of once per four.  Every value goes through exactly apply_kernel's operations in apply_kernel's
+// order: bit-identical output (tests/test_gpu_generator.py), A/B switch LWG_APPLY8=0.
+__global__ __launch_bounds__(256) void apply8_kernel(const ApplyArgs a)
+{
+    const int c8n = a.C >> 3;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.N * a.H * a.W * c8n;
+    if (i >= total) return;
+    const long pix = i / c8n;
+    const int c = (int)(i - pix * c8n) * 8;
+    const int hw = a.H * a.W;
+    const int n = (int)(pix / hw);
+
+    const float4 v0 = ld4(a.raw + pix * a.C + c), v1 = ld4(a.raw + pix * a.C + c + 4);
+    const float *ssp = reinterpret_cast<const float *>(a.scale_shift + (size_t)n * a.C + c);
+    const float4 s0 = ld4(ssp), s1 = ld4(ssp + 4), s2 = ld4(ssp + 8), s3 = ld4(ssp + 12);
+    float y[8];
+    y[0] = v0.x * s0.x + s0.y; y[1] = v0.y * s0.z + s0.w; y[2] = v0.z * s1.x + s1.y; y[3] = v0.w * s1.z + s1.w;
+    y[4] = v1.x * s2.x + s2.y; y[5] = v1.y * s2.z + s2.w; y[6] = v1.z * s3.x + s3.y; y[7] = v1.w * s3.z + s3.w;
+    if (a.relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = fmaxf(y[k], 0.f);
+    }
+    // split-bf16 format: channels c..c+7 of a 32-channel group are 16 bytes of hi at 2*(c&31) and 16 of lo 64 B further
+    const int soff = (c >> 5) * 32 + ((c & 31) >> 1);   // float (4-byte) units
+    if (a.res) {
+        const bf16x8_t h = *reinterpret_cast<const bf16x8_t *>(a.res + pix * a.ld_res + soff);
+        const bf16x8_t l = *reinterpret_cast<const bf16x8_t *>(a.res + pix * a.ld_res + soff + 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] += (float)h[k] + (float)l[k];
+    }
+    for (int k = 0; k < a.nwarp; ++k) {
+        const float2 g = *reinterpret_cast<const float2 *>(a.warp_T[k] + pix * 2);
+        const GridTaps t = grid_taps(g.x, g.y, a.W, a.H, a.align_corners);
+        const float *src = a.warp_src[k] + (size_t)(a.warp_n[k] > 1 ? n : 0) * hw * a.C + c;
+        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+        if (t.vnw) { const float *q = src + (size_t)(t.y0 * a.W + t.x0) * a.C; fma4(w0, ld4(q), t.wnw); fma4(w1, ld4(q + 4), t.wnw); }
+        if (t.vne) { const float *q = src + (size_t)(t.y0 * a.W + t.x0 + 1) * a.C; fma4(w0, ld4(q), t.wne); fma4(w1, ld4(q + 4), t.wne); }
+        if (t.vsw) { const float *q = src + (size_t)((t.y0 + 1) * a.W + t.x0) * a.C; fma4(w0, ld4(q), t.wsw); fma4(w1, ld4(q + 4), t.wsw); }
+        if (t.vse) { const float *q = src + (size_t)((t.y0 + 1) * a.W + t.x0 + 1) * a.C; fma4(w0, ld4(q), t.wse); fma4(w1, ld4(q + 4), t.wse); }
+        y[0] += w0.x; y[1] += w0.y; y[2] += w0.z; y[3] += w0.w; y[4] += w1.x; y[5] += w1.y; y[6] += w1.z; y[7] += w1.w;
+    }
+    bf16x8_t h, l;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h[k] = (__bf16)y[k];
+        l[k] = (__bf16)(y[k] - (float)h[k]);
+    }
+    *reinterpret_cast<bf16x8_t *>(a.dst + pix * a.ld_dst + soff) = h;
+    *reinterpret_cast<bf16x8_t *>(a.dst + pix * a.ld_dst + soff + 16) = l;
+}
+
 // one thread per 32-value group, in place: [hi x32 | lo x32] bf16 -> 32 floats
 __global__ __launch_bounds__(256) void unsplit_kernel(float *buf, size_t ngroups)
 {
@@ -2254,6 +2309,13 @@ int launch_apply(const ApplyArgs &a, hipStream_t st)
     if (a.split && ((a.C & 31) || (a.ld_dst & 31) || ((uintptr_t)a.dst & 127) ||
                     (a.res && ((a.ld_res & 31) || ((uintptr_t)a.res & 127)))))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "apply: split-bf16 buffers need 32-channel granularity (C=%d)", a.C);
+    static const char *a8_env = getenv("LWG_APPLY8");   // "0": four channels per thread everywhere (A/B switch)
+    if (a.split && !(a8_env && a8_env[0] == '0')) {
+        const long total8 = (long)a.N * a.H * a.W * (a.C >> 3);
+        apply8_kernel<<<ceil_div(total8, 256), 256, 0, st>>>(a);
+        LWG_LAUNCH_CHECK("apply8_kernel");
+        return LWG_OK;
+    }
     const long total = (long)a.N * a.H * a.W * (a.C >> 2);
     apply_kernel<<<ceil_div(total, 256), 256, 0, st>>>(a);
     LWG_LAUNCH_CHECK("apply_kernel");

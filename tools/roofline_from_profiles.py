@@ -144,20 +144,65 @@ def main():
     t_lo, t_hi = good[0][0][0], good[-1][-1][0] + good[-1][-1][1]
     total_frames = sum(k * v for k, v in frames_seen.items())
     s2 = scale * scale
-    # apply, per frame: raw read + activation write of every layer output but the last skipper's (folded into the heads), the
-    # residual read of every second trunk conv, the 27.3 MB of cached source features through the Liquid Warping Block gathers
-    act_frame = sum((edge * scale * (2 if kind == "convT" else 1)) ** 2 * cout * 4 for _, _, cout, _, edge, kind in LAYERS[:-1])
-    apply_frame = 2 * act_frame + 6 * (32 * scale) ** 2 * 512 * 4 + 27.3e6 * s2
+    # The InstanceNorm-apply passes that still EXIST as launches (the others are folded into the consumer conv's halo,
+    # ConvArgs::raw_in): after the stem and the three stride-2 encoders (raw read + activation write; the encoders' also gather the
+    # cached source features of their level through the Liquid Warping Block), and after the SECOND conv of each residual block
+    # (raw read + residual read + write + source-feature gather).  A launch is identified by its POSITION in the pass (the conv
+    # launch it follows) and priced with the bytes of that layer only: frames x per-frame bytes + the shared source features once.
+    def apply_bytes(after_conv, frames):
+        name, _, cout, _, edge, kind = LAYERS[after_conv]
+        act = (edge * scale) ** 2 * cout * 4.0                  # one activation map of that layer, bytes per frame
+        if after_conv == 0:
+            return frames * 2 * act, 0.0                        # stem: raw in, activation out
+        if after_conv <= 3:
+            return frames * 2 * act, act                        # encoder: + the level's source features (shared by the batch)
+        return frames * 3 * act, act                            # trunk second conv: + residual in, + source features
+    apply_rows = collections.OrderedDict()
+    for p in good:
+        frames = p[4][3] * tile_rows(p[4][2]) / (32 * scale) ** 2
+        for i in range(len(p) - 1):     # (the last conv of a pass, skipper.2, feeds the heads: no apply launch follows it)
+            lo = p[i][0]
+            hi = p[i + 1][0]
+            for r in rows:
+                if lo < r[0] < hi and r[2].startswith(("apply_kernel", "apply8_kernel")):
+                    key = LAYERS[i][0] if not LAYERS[i][0].startswith("trunk") else "trunk second convs (each)"
+                    per_frames, shared = apply_bytes(i, frames)
+                    a = apply_rows.setdefault(key, dict(n=0, ns=0, bytes=0.0, kn=r[2]))
+                    a["n"] += 1
+                    a["ns"] += r[1]
+                    a["bytes"] += per_frames + shared
+                    break
+    w("## HBM-side kernels\n")
+    w("### The apply passes that remain (InstanceNorm + ReLU [+ residual] [+ Liquid-Warping-Block gather] + split), by position\n")
+    w("Algorithmic bytes of THAT launch (raw read + activation write [+ residual read], per frame, + the level's cached source "
+      "features once per launch: they are shared by the batch) / its rocprofv3 duration.\n")
+    w("| apply after | kernel | launches | avg us | algorithmic MB per launch | GB/s | of 8.0 TB/s spec | of 6.29 TB/s measured copy |")
+    w("|---|---|---|---|---|---|---|---|")
+    tot_b = tot_ns = 0.0
+    for k, a in apply_rows.items():
+        gbs = a["bytes"] / a["ns"]
+        tot_b += a["bytes"]
+        tot_ns += a["ns"]
+        w("| %s | `%s` | %d | %.1f | %.1f | %.0f | %.3f | %.3f |" % (k, a["kn"], a["n"], a["ns"] / a["n"] / 1e3, a["bytes"] / a["n"] / 1e6, gbs,
+                                                              gbs / HBM_SPEC, gbs / HBM_COPY))
+    if tot_ns:
+        w("| **all %d apply launches of a pass** | | %d | %.1f (sum per pass) | %.1f (per pass) | %.0f | %.3f | %.3f |\n" % (
+            sum(a["n"] for a in apply_rows.values()) // len(good), sum(a["n"] for a in apply_rows.values()),
+            tot_ns / len(good) / 1e3, tot_b / len(good) / 1e6, tot_b / tot_ns, tot_b / tot_ns / HBM_SPEC, tot_b / tot_ns / HBM_COPY))
+    fin = [r for r in rows if r[2].startswith("in_finalize_kernel") and t_lo <= r[0] <= t_hi]
+    if fin:
+        w("`in_finalize_kernel`: %d launches in the attributed window, %.1f us each, %.1f us per pass: KBs of data, pure dependency "
+          "latency.\n" % (len(fin), sum(r[1] for r in fin) / len(fin) / 1e3, sum(r[1] for r in fin) / len(good) / 1e3))
     # raster (setup + tiles, fused outputs): faces 0.50 MB in; fim 0.26 + wim 0.79 + cond 0.79 + T 0.52 + tsf_img 0.79 + NHWC8 input 2.10 MB
     # out, source face vertices 0.33 + source image 0.79 MB in
     raster_frame = 495936 + 330624 + (0.262144 + 0.786432 + 0.786432 + 0.524288 + 0.786432 + 2.097152 + 0.786432) * 1e6 * s2
     nv3 = 6890 * 3
     smpl_frame = 207 * nv3 * 4 / 4.0 + nv3 * 4      # the pose-blend table once per four frames + the vertices written
-    w("## HBM-side kernels\n")
+    w("### Geometry kernels\n")
     w("Over the attributed passes (%d frames): algorithmic bytes per frame x frames / summed launch durations.\n" % total_frames)
     w("| kernel | launches | avg us | algorithmic MB per frame | GB/s | of 8.0 TB/s spec | of 6.29 TB/s measured copy |")
     w("|---|---|---|---|---|---|---|")
-    for kname, per_frame in (("apply_kernel", apply_frame), ("raster_tile_kernel", raster_frame), ("smpl_verts_kernel", smpl_frame)):
+    for kname, per_frame in (("raster_tile_kernel", raster_frame), ("smpl_verts_kernel", smpl_frame)):
         sel = [r for r in rows if r[2].startswith(kname) and t_lo <= r[0] <= t_hi]
         if not sel:
             continue
@@ -165,9 +210,8 @@ def main():
         gbs = per_frame * total_frames / ns
         w("| `%s` | %d | %.1f | %.2f | %.0f | %.3f | %.3f |" % (kname, len(sel), ns / len(sel) / 1e3, per_frame / 1e6, gbs, gbs / HBM_SPEC,
                                                           gbs / HBM_COPY))
-    w("\n(`apply_kernel` is the one streaming pass of a step: %d launches per pass.  `raster_tile_kernel` and `smpl_verts_kernel` are "
-      "latency-bound launches of a few dozen microseconds over the frames of a whole round: their byte rate says how far from a bandwidth "
-      "problem they are, not how well they run.)" % (len(LAYERS) - 1))
+    w("\n(`raster_tile_kernel` and `smpl_verts_kernel` are latency-bound launches of a few dozen microseconds over the frames of a "
+      "whole round: their byte rate says how far from a bandwidth problem they are, not how well they run.)")
     text = "\n".join(lines) + "\n"
     if args.out:
         open(args.out, "w").write(text)
