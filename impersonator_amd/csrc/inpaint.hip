@@ -8,6 +8,7 @@
 // filters followed by the gate filters, then one elementwise pass (bias, activation, gate, folded BatchNorm, optional
 // x2 replication, channel padding for the next layer).  The attention is a streaming (online-softmax) kernel.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -166,6 +167,159 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     for (int c = 0; c < CG; ++c) out[o + c] = gamma * (acc[c] * inv) + x[o + c];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same attention on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-for-bit fmaf chains): flash-style, transposed.
+//   workgroup = 8 waves x 32 queries = 256 queries, one of KS key chunks (N / KS keys, 32 per tile); grid (N / 256, KS).
+//   S^T tile = K_tile Q^T  (32 keys x 32 queries, 8 MFMAs over d = 16): lane (q = lane & 31, h = lane >> 5) ends up holding, for
+//       ITS query, the scores of keys (r & 3) + 8 (r >> 2) + 4 h, r = 0..15 -- a whole column: the running max / sum of the online
+//       softmax are per-lane scalars, completed with one exchange between the two half-waves;
+//   O^T += V^T P^T  (128 channels x 32 queries, 4 x 16 MFMAs over the 32 keys): the B operand of step r is exactly the lane's own
+//       p[r] (keys paired (k, k + 4) across the half-waves, as the accumulator layout has them) -- probabilities never leave their
+//       registers; the A operand V[key][channel] is read from an LDS tile the eight waves share (32 consecutive channels per
+//       half-wave: conflict-free 4-byte reads), double-buffered, staged through registers one tile ahead.  K rows come straight
+//       from L1/L2 (2 KiB per tile).
+//   Each workgroup leaves un-normalised O, the running max m and sum l of its key chunk; attention_combine_kernel merges the KS
+//   chunks (softmax is associative under (m, l, O) pairs) and applies out = gamma * (O / l + b_v) + x.
+// 4096 tokens: 4.8 GFLOP on 256 workgroups of 8 tiles instead of a VALU loop at 5 TFLOP/s.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int AM_Q = 256, AM_T = 32, AM_C = 128;   // queries per workgroup, keys per tile, value channels
+
+__global__ __launch_bounds__(512, 2) void attention_mfma_kernel(const float *__restrict__ qkv, int ld, const float *__restrict__ bias,
+                                                             int N, int keys_per_chunk, float *__restrict__ o_part,
+                                                             float2 *__restrict__ ml_part)
+{
+    __shared__ __attribute__((aligned(16))) float Vs[2][AM_T][AM_C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qlane = lane & 31, half = lane >> 5;
+    const int q = blockIdx.x * AM_Q + wave * 32 + qlane;
+    const int chunk = blockIdx.y, key_lo = chunk * keys_per_chunk, ntiles = keys_per_chunk / AM_T;
+
+    // B operand of the score MFMAs: Q[q][2 s + half] (+ bias), s = 0..7
+    float qv[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) qv[s2] = qkv[(size_t)q * ld + 2 * s2 + half] + bias[2 * s2 + half];
+    float bk[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) bk[s2] = bias[AT_D + 2 * s2 + half];
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    // staging geometry of a V tile: 32 x 128 floats = 1024 float4, two per thread (rows tid / 32 and 16 + tid / 32); the K rows of a
+    // tile: the lane's own key row, 16 floats (the even or odd components are picked when the tile is used).  Named registers, not
+    // arrays: everything fetched for tile t + 1 must stay in flight underneath tile t's MFMAs.
+    const int vrow = tid >> 5, vc4 = (tid & 31) * 4;
+    const float *vsrc = qkv + ((size_t)key_lo + vrow) * ld + 2 * AT_D + vc4;
+    const float *ksrc = qkv + ((size_t)key_lo + qlane) * ld + AT_D;
+    const size_t tile_stride = (size_t)AM_T * ld;
+    float4 vp0 = *reinterpret_cast<const float4 *>(vsrc), vp1 = *reinterpret_cast<const float4 *>(vsrc + (size_t)16 * ld);
+    float4 k0 = *reinterpret_cast<const float4 *>(ksrc), k1 = *reinterpret_cast<const float4 *>(ksrc + 4);
+    float4 k2 = *reinterpret_cast<const float4 *>(ksrc + 8), k3 = *reinterpret_cast<const float4 *>(ksrc + 12);
+    *reinterpret_cast<float4 *>(&Vs[0][vrow][vc4]) = vp0;
+    *reinterpret_cast<float4 *>(&Vs[0][vrow + 16][vc4]) = vp1;
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        // A operand of the score MFMAs: K[key0 + qlane][2 s + half] (+ bias)
+        float kc[8];
+        kc[0] = (half ? k0.y : k0.x) + bk[0]; kc[1] = (half ? k0.w : k0.z) + bk[1];
+        kc[2] = (half ? k1.y : k1.x) + bk[2]; kc[3] = (half ? k1.w : k1.z) + bk[3];
+        kc[4] = (half ? k2.y : k2.x) + bk[4]; kc[5] = (half ? k2.w : k2.z) + bk[5];
+        kc[6] = (half ? k3.y : k3.x) + bk[6]; kc[7] = (half ? k3.w : k3.z) + bk[7];
+        if (t + 1 < ntiles) {        // next tile on its way while this one computes
+            vsrc += tile_stride;
+            ksrc += tile_stride;
+            vp0 = *reinterpret_cast<const float4 *>(vsrc);
+            vp1 = *reinterpret_cast<const float4 *>(vsrc + (size_t)16 * ld);
+            k0 = *reinterpret_cast<const float4 *>(ksrc);
+            k1 = *reinterpret_cast<const float4 *>(ksrc + 4);
+            k2 = *reinterpret_cast<const float4 *>(ksrc + 8);
+            k3 = *reinterpret_cast<const float4 *>(ksrc + 12);
+        }
+        // ---- scores: S^T = K_tile Q^T
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[s2], qv[s2], sc, 0, 0, 0);
+        // ---- online softmax of this lane's query over the tile's 32 keys (16 here, 16 in the other half-wave)
+        float tmax = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        const float f = expf(m - mn);      // exp(-inf) = 0 on the first tile
+        float p[16], psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = expf(sc[r] - mn);
+            psum += p[r];
+        }
+        psum += __shfl_xor(psum, 32);
+        l = l * f + psum;
+        m = mn;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] *= f;
+        // ---- O^T += V^T P^T: step r pairs keys (r & 3) + 8 (r >> 2) [half 0] and + 4 [half 1]: the lane's own p[r]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float *vr = &Vs[buf][(r & 3) + 8 * (r >> 2) + 4 * half][qlane];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[cb * 32], p[r], acc[cb], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) {
+            *reinterpret_cast<float4 *>(&Vs[buf ^ 1][vrow][vc4]) = vp0;
+            *reinterpret_cast<float4 *>(&Vs[buf ^ 1][vrow + 16][vc4]) = vp1;
+        }
+        __syncthreads();
+    }
+    // ---- un-normalised partial output of this key chunk: lane (q, half) holds channels cb*32 + 8 g + 4 half + 0..3 in acc[cb][4g..4g+3]
+    float *op = o_part + ((size_t)chunk * N + q) * AM_C;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<float4 *>(op + cb * 32 + 8 * g4 + 4 * half) =
+                make_float4(acc[cb][4 * g4], acc[cb][4 * g4 + 1], acc[cb][4 * g4 + 2], acc[cb][4 * g4 + 3]);
+    if (half == 0) ml_part[(size_t)chunk * N + q] = make_float2(m, l);
+}
+
+// merges the key chunks of a query: m = max m_s, O = sum O_s exp(m_s - m), l = sum l_s exp(m_s - m); out = gamma (O / l + b_v) + x
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float *__restrict__ o_part, const float2 *__restrict__ ml_part,
+                                                                int KS, int N, const float *__restrict__ bias_v,
+                                                                const float *__restrict__ x, float gamma, float *__restrict__ out)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (query, 4 channels)
+    if (e >= (long)N * (AM_C / 4)) return;
+    const int q = (int)(e / (AM_C / 4)), c = (int)(e - (long)q * (AM_C / 4)) * 4;
+    float m = -INFINITY;
+    for (int s2 = 0; s2 < KS; ++s2) m = fmaxf(m, ml_part[(size_t)s2 * N + q].x);
+    float l = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s2 = 0; s2 < KS; ++s2) {
+        const float2 ml = ml_part[(size_t)s2 * N + q];
+        const float w = expf(ml.x - m);
+        const float4 v = *reinterpret_cast<const float4 *>(o_part + ((size_t)s2 * N + q) * AM_C + c);
+        l += ml.y * w;
+        o.x += v.x * w; o.y += v.y * w; o.z += v.z * w; o.w += v.w * w;
+    }
+    const float inv = 1.f / l;
+    const float4 b = *reinterpret_cast<const float4 *>(bias_v + c);
+    const float4 xr = *reinterpret_cast<const float4 *>(x + (size_t)q * AM_C + c);
+    float4 r;
+    r.x = gamma * (o.x * inv + b.x) + xr.x;
+    r.y = gamma * (o.y * inv + b.y) + xr.y;
+    r.z = gamma * (o.z * inv + b.z) + xr.z;
+    r.w = gamma * (o.w * inv + b.w) + xr.w;
+    *reinterpret_cast<float4 *>(out + (size_t)q * AM_C + c) = r;
+}
+
 struct GLayer {
     int cin, cin_pad, cout, cp, k, stride, dil, pad, up, act;
     float *w = nullptr, *bias = nullptr, *bn_scale = nullptr, *bn_shift = nullptr;
@@ -189,6 +343,9 @@ struct lwg_inpaint {
     bool got_q[2] = {false, false}, got_k[2] = {false, false}, got_v[2] = {false, false}, got_gamma = false;
     // scratch
     float *in8 = nullptr, *act[2] = {nullptr, nullptr}, *raw = nullptr, *coarse = nullptr, *zeros = nullptr;
+    // attention on the matrix cores: key chunks per query block, their partial (O, m, l) results
+    int attn_ks = 0;
+    float *attn_o = nullptr, *attn_ml = nullptr;
 };
 
 namespace lwg {
@@ -377,6 +534,21 @@ int lwg_inpaint_create(lwg_inpaint **out, int c_dim, int image_size)
     if (rc == LWG_OK) rc = dalloc(&g->raw, P * 64);
     if (rc == LWG_OK) rc = dalloc(&g->coarse, P * 3);
     if (rc == LWG_OK) rc = dalloc(&g->zeros, 64);
+    {
+        // attention_mfma_kernel: 256 queries per workgroup, KS key chunks so that every CU gets a workgroup; a chunk is whole
+        // 32-key tiles.  Token counts it does not divide stay on attention_kernel (attn_ks = 0).
+        const int N = hq * hq;
+        int ks = 0;
+        if (N % AM_Q == 0) {
+            ks = 256 / (N / AM_Q);
+            ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
+            while (ks > 1 && N % (ks * AM_T) != 0) --ks;
+            if (N % (ks * AM_T) != 0) ks = 0;
+        }
+        g->attn_ks = ks;
+        if (ks && rc == LWG_OK) rc = dalloc(&g->attn_o, (size_t)ks * N * AM_C, false);
+        if (ks && rc == LWG_OK) rc = dalloc(&g->attn_ml, (size_t)ks * N * 2, false);
+    }
     if (rc != LWG_OK) {
         lwg_inpaint_destroy(g);
         return rc;
@@ -392,6 +564,7 @@ void lwg_inpaint_destroy(lwg_inpaint *g)
     for (auto &net : g->net)
         for (auto &L : net) { fr(L.w); fr(L.bias); fr(L.bn_scale); fr(L.bn_shift); }
     fr(g->wqkv); fr(g->bqkv); fr(g->in8); fr(g->act[0]); fr(g->act[1]); fr(g->raw); fr(g->coarse); fr(g->zeros);
+    fr(g->attn_o); fr(g->attn_ml);
     delete g;
 }
 
@@ -499,8 +672,19 @@ int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, f
         a.ph[0].KH = a.ph[0].KW = 1; a.ph[0].ntaps = 1; a.ph[0].Kpad = kAttnC; a.ph[0].w_off = 0;
         if ((rc = launch_conv_igemm(a, 64, st)) != LWG_OK) return rc;
         float *dst = const_cast<float *>(feat) == g->act[0] ? g->act[1] : g->act[0];
-        attention_kernel<kAttnC><<<H * H / AT_Q, 256, 0, st>>>(g->raw, kQkvN, g->bqkv, feat, g->gamma, H * H, dst);
-        LWG_LAUNCH_CHECK("attention_kernel");
+        static const char *attn_env = getenv("LWG_ATTN");   // "valu": the streaming vector-ALU kernel (A/B switch)
+        const int N = H * H;
+        if (g->attn_ks && !(attn_env && attn_env[0] == 'v')) {
+            attention_mfma_kernel<<<dim3(N / AM_Q, g->attn_ks), 512, 0, st>>>(g->raw, kQkvN, g->bqkv, N, N / g->attn_ks, g->attn_o,
+                                                                           reinterpret_cast<float2 *>(g->attn_ml));
+            LWG_LAUNCH_CHECK("attention_mfma_kernel");
+            attention_combine_kernel<<<ceil_div((long)N * (AM_C / 4), 256), 256, 0, st>>>(
+                g->attn_o, reinterpret_cast<const float2 *>(g->attn_ml), g->attn_ks, N, g->bqkv + 2 * AT_D, feat, g->gamma, dst);
+            LWG_LAUNCH_CHECK("attention_combine_kernel");
+        } else {
+            attention_kernel<kAttnC><<<N / AT_Q, 256, 0, st>>>(g->raw, kQkvN, g->bqkv, feat, g->gamma, N, dst);
+            LWG_LAUNCH_CHECK("attention_kernel");
+        }
         feat = dst;
     }
     // run_net alternates act[0]/act[1] starting with act[0]: keep its first output away from `feat`

@@ -47,3 +47,44 @@ def test_imitator_personalize_with_inpaintor():
         bg_mask = torch_ref.morph(si["cond"][:, -1:].cpu(), imitator._opt.bg_ks, "erode")
         _, ox, _ = torch_ref.inpaint_forward(sd, torch.from_numpy(src_img)[None], 1 - bg_mask)
     assert float((si["bg"].cpu() - ox).abs().max()) <= 1e-3
+
+
+def test_mfma_attention_equals_the_vector_alu_attention(tmp_path):
+    """The 4096-token self-attention (networks/inpaintor.py:85-103) on the exact-fp32 matrix cores (attention_mfma_kernel: key
+    chunks + combine) against the streaming vector-ALU kernel it replaces (LWG_ATTN=valu, read once per process: two runs): the
+    same softmax and the same products, summed in another order -- the refined image agrees to 1e-5, and both sit within 2e-5 of
+    the CPU oracle (bound of the whole network: 1e-3)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from tests.test_gpu_inpaintor import _net_and_sd\n"
+            "from impersonator_amd.utils import synthetic\n"
+            "net, sd = _net_and_sd(0)\n"
+            "img = torch.from_numpy(synthetic.smooth_image(5))\n"
+            "yy, xx = np.mgrid[0:256, 0:256]\n"
+            "mask = torch.from_numpy((((yy - 120) / 90.0) ** 2 + ((xx - 128) / 50.0) ** 2 < 1).astype(np.float32))[None, None]\n"
+            "coarse, x, comp = net(img.cuda(), mask.cuda())\n"
+            "np.save(sys.argv[1], x.cpu().numpy())\n" % root)
+    outs = {}
+    for mode in ("mfma", "valu"):
+        path = str(tmp_path / (mode + ".npy"))
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("LWG_ATTN", None)
+        if mode == "valu":
+            env["LWG_ATTN"] = "valu"
+        p = subprocess.run([sys.executable, "-c", code, path], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[mode] = np.load(path)
+    d = float(np.abs(outs["mfma"] - outs["valu"]).max())
+    _, sd = _net_and_sd(0)
+    img = torch.from_numpy(synthetic.smooth_image(5))
+    yy, xx = np.mgrid[0:256, 0:256]
+    mask = torch.from_numpy((((yy - 120) / 90.0) ** 2 + ((xx - 128) / 50.0) ** 2 < 1).astype(np.float32))[None, None]
+    with torch.no_grad():
+        _, ox, _ = torch_ref.inpaint_forward(sd, img, mask)
+    e_m, e_v = float(np.abs(outs["mfma"] - ox.numpy()).max()), float(np.abs(outs["valu"] - ox.numpy()).max())
+    print("attention: mfma vs valu %.3g; vs oracle: mfma %.3g, valu %.3g" % (d, e_m, e_v))
+    assert d <= 1e-5 and e_m <= 2e-5 and e_v <= 2e-5, (d, e_m, e_v)
