@@ -264,3 +264,24 @@ def test_generator_at_other_image_sizes(size, bs):
         err = float((a.cpu() - b).abs().max())
         assert err <= TOL_IMAGE, (size, name, err)
     G.release()
+
+
+def test_apply8_is_bit_identical_to_the_four_channel_apply(tmp_path):
+    """apply8_kernel (eight channels per lane: 16-byte loads and stores of the split-bf16 terms, one flow sample per eight channels)
+    performs apply_kernel's operations in apply_kernel's order: 24 frames of the two-lane pipeline are equal bit for bit with
+    LWG_APPLY8=0 (the switch is read once per process: two runs)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for val in ("1", "0"):
+        path = str(tmp_path / ("apply8_%s.npy" % val))
+        env = dict(os.environ, PYTHONPATH=root, LWG_APPLY8=val)
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "dump_preds.py"), path, "24"], env=env, cwd=root,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(path))
+    assert outs[0].shape == (24, 256, 256, 3) and np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
