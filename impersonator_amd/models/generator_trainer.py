@@ -242,12 +242,14 @@ class GeneratorTrainer(object):
 
     def _begin_buckets(self):
         """Data-parallel job: the gradient all-reduce runs bucket by bucket on a side stream while the backward pass goes on
-        (env LWG_GRAD_BUCKETS=0: one blocking all-reduce of the whole buffer after it; LWG_BUCKET_MB: bucket size, default 32)."""
+        (env LWG_GRAD_BUCKETS=0: one blocking all-reduce of the whole buffer after it; LWG_BUCKET_MB: bucket size, default 64)."""
         import os
         if sharding.collectives_active() and os.environ.get("LWG_GRAD_BUCKETS", "1") != "0":
-            if self._buckets is None:
+            mb = os.environ.get("LWG_BUCKET_MB", "64")
+            if self._buckets is None or self._bucket_mb != mb:
+                self._bucket_mb = mb
                 self._buckets = sharding.GradientBuckets(self.flat_g, self._ranges,
-                                                         int(float(os.environ.get("LWG_BUCKET_MB", "32")) * (1 << 20)))
+                                                         int(float(os.environ.get("LWG_BUCKET_MB", "64")) * (1 << 20)))
             self._buckets.begin()
         else:
             self._buckets = None

@@ -150,17 +150,26 @@ def average_gradients(flat_grads):
     then divide) -- RCCL over xGMI for CUDA tensors, gloo on CPU.  No-op without an initialised multi-rank group.  The
     reference does this implicitly through nn.DataParallel (models/impersonator_trainer.py:196-214)."""
     if collectives_active():
-        dist.all_reduce(flat_grads)
-        flat_grads.div_(dist.get_world_size())
+        _all_reduce_mean(flat_grads)
     return flat_grads
+
+
+def _all_reduce_mean(t):
+    """In-place mean over the ranks.  RCCL: one collective with the averaging folded in (ReduceOp.AVG: no second pass over the
+    buffer; for a power-of-two number of ranks the same bits as sum-then-divide); gloo has no AVG: sum, then divide."""
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(t)
+        t.div_(dist.get_world_size())
 
 
 class GradientBuckets(object):
     """Bucketed gradient averaging overlapped with the backward pass (the reference leaves this to
     nn.DataParallel's reduce, models/impersonator_trainer.py:196-214).
 
-    The flat gradient buffer is cut into contiguous buckets of at least `bucket_bytes` (RCCL rings over xGMI are per-link bound:
-    few, large messages).  The backward pass writes every parameter's gradient exactly once; `written(key)` counts a bucket's
+    The flat gradient buffer is cut into contiguous buckets of at least `bucket_bytes` (default 64 MB; RCCL rings over xGMI are
+    per-link bound -- few, large messages -- and every bucket is a fork / join of the compute stream, which a captured graph pays for).  The backward pass writes every parameter's gradient exactly once; `written(key)` counts a bucket's
     keys down and `checkpoint()` -- called by the backward pass AFTER it has enqueued the kernels that write them -- hands every
     complete bucket to a side stream: event on the compute stream, all-reduce + 1/world scaling of that slice there, while the
     compute stream goes on with the layers in front.  `finish()` launches what is left and makes the compute stream wait; the
@@ -169,7 +178,7 @@ class GradientBuckets(object):
     the backward pass are still to run.  Results equal `average_gradients(flat)` bit for bit (the same all-reduce per element,
     only cut into pieces).  Capturable in a HIP graph: fork and join are events on the capturing stream."""
 
-    def __init__(self, flat, ranges, bucket_bytes=32 << 20):
+    def __init__(self, flat, ranges, bucket_bytes=64 << 20):
         """ranges: [(key, lo, hi)] element ranges of `flat`, ascending and contiguous."""
         self.flat = flat
         self.buckets = []          # [lo, hi, set(keys)], ascending
@@ -209,18 +218,15 @@ class GradientBuckets(object):
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
         view = self.flat[lo:hi]
-        world = dist.get_world_size()
         self.launched_log.append((i, sum(self.left)))
         if self.stream is None:
-            dist.all_reduce(view)
-            view.div_(world)
+            _all_reduce_mean(view)
         else:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                dist.all_reduce(view)
-                view.div_(world)
+                _all_reduce_mean(view)
         self.done[i] = True
 
     def checkpoint(self):

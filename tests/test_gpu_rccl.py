@@ -45,10 +45,10 @@ def test_rccl_collectives_on_one_rank():
     ag = out["average_gradients"]
     assert ag["G"]["bytes"] > 3.8e8 and 2.7e7 < ag["D"]["bytes"] < 3.1e7
     assert ag["G"]["max_abs_err"] <= 1e-6 and ag["D"]["max_abs_err"] <= 1e-6 and ag["G"]["ms"] > 0
-    # the training iteration on RCCL: buckets of >= 32 MB go on the wire while later layers' gradients are still open, the
+    # the training iteration on RCCL: buckets of >= 64 MB go on the wire while later layers' gradients are still open, the
     # iteration is captured WITH its collectives and replays the eager iteration exactly, and the collectives cost <= 3 %
     t = out["train"]
-    assert t["bucket_count"] >= 8 and min(t["bucket_mbytes"]) >= 32.0
+    assert t["bucket_count"] >= 4 and min(t["bucket_mbytes"]) >= 64.0
     assert t["launches"] == t["bucket_count"] and t["launched_while_gradients_were_open"] >= t["bucket_count"] - 2
     assert t["graph_captured_with_collectives"] and not t["graph_failed"]
     assert t["replay_equals_eager_terms"] and t["replay_equals_eager_parameters"]
