@@ -751,8 +751,9 @@ def main():
                                    "%d-frame synthetic reference sequence" % args.frames,
                        "batch_per_gpu": BATCH, "image_size": IMAGE_SIZE, "parallelism": "frame-sharded replicas x%d" % world,
                        "grid_sample_align_corners": False,
-                       "streams": "%d generator lane(s) + 1 geometry stream per GPU; consecutive batches fused in pairs per "
-                                  "generator launch sequence: %s" % (lanes, os.environ.get("LWG_FUSE", str(imitator.fuse))),
+                       "streams": "%d generator lane(s) + 1 geometry stream per GPU; %s consecutive batches of %d per generator "
+                                  "launch sequence (frames of one source are independent: bit-identical to one batch at a time)"
+                                  % (lanes, os.environ.get("LWG_FUSE", str(imitator.fuse)), BATCH),
                        "precision": precision + (" (fp32 operands carried as 2 bf16 terms, 3 MFMA products, fp32 "
                                                  "accumulate; 8e-5 L-inf on the image vs fp32, bound 1e-3)"
                                                  if precision == "bf16x3" else " (exact fp32 MFMA)")},

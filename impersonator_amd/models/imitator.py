@@ -272,7 +272,10 @@ class Imitator(BaseModel):
     # Two batches of 8 = 16 frames give the trunk convolutions 256 tiles of 8 x 32 pixels (eight waves sharing a weight
     # stage): conv kernels 0.42 -> 0.48 of the matrix-pipe peak, +2.5..4.5 % frames/s (profiles/r03_conv_experiments.md).
     # Results are bit-identical to unfused batches (every kernel is batch-invariant; tests/test_gpu_bench_config.py).
-    fuse = 2
+    # Round 5: four batches of 8 per launch sequence (32 frames: every layer's grid is a multiple of two full rounds of the chip, the
+    # dependent launch chain -- conv, statistics, apply -- is paid once per 32 frames): +2.3..2.8 % frames/s over pairs on the same
+    # box (profiles/r05_fuse_ab.md); with two lanes and round_depth 4 a round is exactly one sequence per lane.
+    fuse = 4
     # entries of tsf_info with one row per frame (hmr.get_details + SMPLRenderer.transfer, imitator.py:236-268)
     PER_FRAME_KEYS = ('theta', 'cam', 'pose', 'shape', 'verts', 'j2d', 'j3d', 'fim', 'wim', 'cond', 'tsf_img', 'T')
 
