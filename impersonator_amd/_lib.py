@@ -70,6 +70,7 @@ _PROTOS = {
     "lwg_inpaint_destroy": (None, [_vp]),
     "lwg_inpaint_load_weight": (_i, [_vp, _c.c_char_p, _vp, _c.POINTER(_c.c_int64), _i]),
     "lwg_inpaint_missing_weights": (_i, [_vp]),
+    "lwg_inpaint_set_precision": (_i, [_vp, _i]),
     "lwg_inpaint_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lwg_conv2d_workspace_bytes": (_c.c_size_t, [_vp]),
     "lwg_conv2d_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "conv.h"
+#include "split.h"
 
 namespace lwg {
 namespace {
@@ -27,6 +28,7 @@ struct GatedArgs {
     int H, W;                        // raw resolution
     int up;                          // 1: replicate every pixel 2x2 (nearest upsampling feeding the next conv)
     float *dst; int Cdst;            // NHWC output, Cdst >= Cout channels (extra ones zeroed)
+    int split;                       // 1: dst in the split-bf16 format of conv.h (Cdst % 32 == 0): the consumer is a bf16x3 conv
 };
 
 __device__ __forceinline__ float gated_value(const GatedArgs &a, const float *px, int c)
@@ -49,16 +51,27 @@ __global__ __launch_bounds__(256) void gated_apply_kernel(const GatedArgs a)
     y.y = c + 1 < a.Cout ? gated_value(a, px, c + 1) : 0.f;
     y.z = c + 2 < a.Cout ? gated_value(a, px, c + 2) : 0.f;
     y.w = c + 3 < a.Cout ? gated_value(a, px, c + 3) : 0.f;
+    // split-bf16 format: channels c..c+3 of a 32-channel group are 8 bytes of hi at 2*(c&31) and 8 of lo 64 B further
+    const int soff = (c >> 5) * 32 + ((c & 31) >> 1);   // float (4-byte) units
+    bf16x4_t h, l;
+    h[0] = (__bf16)y.x; h[1] = (__bf16)y.y; h[2] = (__bf16)y.z; h[3] = (__bf16)y.w;
+    l[0] = (__bf16)(y.x - (float)h[0]); l[1] = (__bf16)(y.y - (float)h[1]);
+    l[2] = (__bf16)(y.z - (float)h[2]); l[3] = (__bf16)(y.w - (float)h[3]);
+    auto put = [&](size_t o) {
+        if (a.split) {
+            *reinterpret_cast<bf16x4_t *>(a.dst + o * a.Cdst + soff) = h;
+            *reinterpret_cast<bf16x4_t *>(a.dst + o * a.Cdst + soff + 16) = l;
+        } else {
+            *reinterpret_cast<float4 *>(a.dst + o * a.Cdst + c) = y;
+        }
+    };
     if (!a.up) {
-        *reinterpret_cast<float4 *>(a.dst + (size_t)pix * a.Cdst + c) = y;
+        put((size_t)pix);
     } else {
         const int yy = pix / a.W, xx = pix - yy * a.W;
         const int W2 = 2 * a.W;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const size_t o = (size_t)(2 * yy + (d >> 1)) * W2 + 2 * xx + (d & 1);
-            *reinterpret_cast<float4 *>(a.dst + o * a.Cdst + c) = y;
-        }
+        for (int d = 0; d < 4; ++d) put((size_t)(2 * yy + (d >> 1)) * W2 + 2 * xx + (d & 1));
     }
 }
 
@@ -293,7 +306,8 @@ __global__ __launch_bounds__(512, 2) void attention_mfma_kernel(const float *__r
 // merges the key chunks of a query: m = max m_s, O = sum O_s exp(m_s - m), l = sum l_s exp(m_s - m); out = gamma (O / l + b_v) + x
 __global__ __launch_bounds__(256) void attention_combine_kernel(const float *__restrict__ o_part, const float2 *__restrict__ ml_part,
                                                                 int KS, int N, const float *__restrict__ bias_v,
-                                                                const float *__restrict__ x, float gamma, float *__restrict__ out)
+                                                                const float *__restrict__ x, float gamma, float *__restrict__ out,
+                                                                int split_out)
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (query, 4 channels)
     if (e >= (long)N * (AM_C / 4)) return;
@@ -317,12 +331,23 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float *__r
     r.y = gamma * (o.y * inv + b.y) + xr.y;
     r.z = gamma * (o.z * inv + b.z) + xr.z;
     r.w = gamma * (o.w * inv + b.w) + xr.w;
-    *reinterpret_cast<float4 *>(out + (size_t)q * AM_C + c) = r;
+    if (!split_out) {
+        *reinterpret_cast<float4 *>(out + (size_t)q * AM_C + c) = r;
+        return;
+    }
+    const int soff = (c >> 5) * 32 + ((c & 31) >> 1);
+    bf16x4_t hi4, lo4;
+    hi4[0] = (__bf16)r.x; hi4[1] = (__bf16)r.y; hi4[2] = (__bf16)r.z; hi4[3] = (__bf16)r.w;
+    lo4[0] = (__bf16)(r.x - (float)hi4[0]); lo4[1] = (__bf16)(r.y - (float)hi4[1]);
+    lo4[2] = (__bf16)(r.z - (float)hi4[2]); lo4[3] = (__bf16)(r.w - (float)hi4[3]);
+    *reinterpret_cast<bf16x4_t *>(out + (size_t)q * AM_C + soff) = hi4;
+    *reinterpret_cast<bf16x4_t *>(out + (size_t)q * AM_C + soff + 16) = lo4;
 }
 
 struct GLayer {
     int cin, cin_pad, cout, cp, k, stride, dil, pad, up, act;
     float *w = nullptr, *bias = nullptr, *bn_scale = nullptr, *bn_shift = nullptr;
+    float *w_split = nullptr;        // w in the split-bf16 format (layers whose input has whole 32-channel groups), else null
     int kpad = 0;
     // host staging of BatchNorm parameters until all four arrived
     std::vector<float> bn[4];   // weight, bias, running_mean, running_var
@@ -346,6 +371,8 @@ struct lwg_inpaint {
     // attention on the matrix cores: key chunks per query block, their partial (O, m, l) results
     int attn_ks = 0;
     float *attn_o = nullptr, *attn_ml = nullptr;
+    int precision = 1;               // 1: gated convs with >= 32 input channels on the bf16x3 kernels (split operands); 0: exact fp32
+    size_t act_floats = 0;           // size of act[0] / act[1] (a zero run for the DMA kernels' padding taps sits behind each)
 };
 
 namespace lwg {
@@ -404,6 +431,11 @@ int upload_half(GLayer &L, int row0, const float *w, const int64_t *shape, int n
         for (int ci = 0; ci < L.cin; ++ci)
             for (int t = 0; t < kk; ++t) h[(size_t)co * L.kpad + (size_t)t * L.cin_pad + ci] = w[((size_t)co * L.cin + ci) * kk + t];
     LWG_HIP(hipMemcpy(L.w + (size_t)row0 * L.kpad, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (L.w_split) {   // the same rows as [hi x32 | lo x32] bf16 per 32 reduction entries (conv.h): same offsets
+        std::vector<float> sp(h.size());
+        split_bf16_groups(h.data(), h.size(), sp.data());
+        LWG_HIP(hipMemcpy(L.w_split + (size_t)row0 * L.kpad, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return LWG_OK;
 }
 
@@ -430,13 +462,27 @@ int fold_bn(GLayer &L)
     return LWG_OK;
 }
 
-int run_gated_conv(lwg_inpaint *g, const GLayer &L, const float *x, int H, hipStream_t st, int *Ho)
+// does layer L take its input in the split-bf16 format (and run on the bf16x3 kernels)?
+bool layer_split(const lwg_inpaint *g, const GLayer &L) { return g->precision == 1 && L.w_split != nullptr; }
+
+int run_gated_conv(lwg_inpaint *g, const GLayer &L, const float *x, bool x_split, int H, hipStream_t st, int *Ho)
 {
     ConvArgs a = {};
     a.x = x; a.ldx = L.cin_pad; a.N = 1; a.H = H; a.W = H; a.Cin = L.cin_pad;
     a.cin_log2 = 0;
     while ((1 << a.cin_log2) < L.cin_pad) ++a.cin_log2;
     a.w = L.w; a.zeros = g->zeros; a.y = g->raw; a.ldy = 2 * L.cp; a.Cout = 2 * L.cp;
+    if (x_split) {
+        // bf16x3: three bf16 MFMA products per multiply-add on split operands, fp32 accumulate (conv.h); the padding taps read the
+        // zero run behind the activation buffer x lives in
+        if (!L.w_split) LWG_FAIL(LWG_ERR_STATE, "inpaint: split input for a layer without split weights");
+        a.precision = 1;
+        a.w_split = L.w_split;
+        a.tap_inner = 1;
+        a.zeros = (x >= g->act[0] && x < g->act[0] + g->act_floats) ? g->act[0] + g->act_floats
+                  : (x >= g->act[1] && x < g->act[1] + g->act_floats) ? g->act[1] + g->act_floats : nullptr;
+        if (!a.zeros) LWG_FAIL(LWG_ERR_STATE, "inpaint: bf16x3 conv input is not one of the handle's activation buffers");
+    }
     a.Hm = (H + 2 * L.pad - L.dil * (L.k - 1) - 1) / L.stride + 1;
     a.Wm = a.Hm; a.Ho = a.Hm; a.Wo = a.Hm;
     a.stride = L.stride; a.pad = L.pad; a.os = 1; a.dil = L.dil;
@@ -455,20 +501,20 @@ GatedArgs gated_args(const lwg_inpaint *g, const GLayer &L, int H, float *dst, i
     GatedArgs a = {};
     a.raw = g->raw; a.C2 = 2 * L.cp; a.Cp = L.cp; a.Cout = L.cout; a.bias = L.bias;
     a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.act = L.act; a.H = H; a.W = H; a.up = 0;
-    a.dst = dst; a.Cdst = cdst;
+    a.dst = dst; a.Cdst = cdst; a.split = 0;
     return a;
 }
 
 // runs net[n] starting from `x` (NHWC, net's first cin_pad channels) at resolution H; layers alternate between the two
 // activation buffers; the last layer is left in g->raw for the caller when `keep_last_raw`
-int run_net(lwg_inpaint *g, int n, const float *x, int *H, bool keep_last_raw, const float **out, hipStream_t st)
+int run_net(lwg_inpaint *g, int n, const float *x, bool x_split, int *H, bool keep_last_raw, const float **out, hipStream_t st)
 {
     std::vector<GLayer> &net = g->net[n];
     int cur = 0;
     for (size_t i = 0; i < net.size(); ++i) {
         const GLayer &L = net[i];
         int Ho = 0;
-        int rc = run_gated_conv(g, L, x, *H, st, &Ho);
+        int rc = run_gated_conv(g, L, x, x_split, *H, st, &Ho);
         if (rc != LWG_OK) return rc;
         *H = Ho;
         if (i + 1 == net.size() && keep_last_raw) break;
@@ -477,6 +523,9 @@ int run_net(lwg_inpaint *g, int n, const float *x, int *H, bool keep_last_raw, c
         const int cdst = i + 1 < net.size() ? net[i + 1].cin_pad : (int)align_up((size_t)L.cout, 4);
         GatedArgs a = gated_args(g, L, Ho, g->act[cur], cdst);
         a.up = next_up ? 1 : 0;
+        // the next layer of this net decides the format of what is written (the last layer's consumers read fp32)
+        x_split = i + 1 < net.size() && layer_split(g, net[i + 1]);
+        a.split = x_split ? 1 : 0;
         gated_apply_kernel<<<ceil_div((long)Ho * Ho * (cdst >> 2), 256), 256, 0, st>>>(a);
         LWG_LAUNCH_CHECK("gated_apply_kernel");
         if (next_up) *H = 2 * Ho;
@@ -520,6 +569,9 @@ int lwg_inpaint_create(lwg_inpaint **out, int c_dim, int image_size)
     for (auto &net : g->net)
         for (auto &L : net) {
             if (rc == LWG_OK) rc = dalloc(&L.w, (size_t)2 * L.cp * L.kpad);
+            // layers whose input has whole 32-channel groups can run on the bf16x3 kernels (split operands)
+            if (rc == LWG_OK && L.cin_pad % 32 == 0 && L.kpad == L.k * L.k * L.cin_pad && L.k * L.k <= 32)
+                rc = dalloc(&L.w_split, (size_t)2 * L.cp * L.kpad);
             if (rc == LWG_OK) rc = dalloc(&L.bias, (size_t)2 * L.cp);
             if (rc == LWG_OK) rc = dalloc(&L.bn_scale, L.cout);
             if (rc == LWG_OK) rc = dalloc(&L.bn_shift, L.cout);
@@ -529,8 +581,10 @@ int lwg_inpaint_create(lwg_inpaint **out, int c_dim, int image_size)
     if (rc == LWG_OK) rc = dalloc(&g->bqkv, kQkvN);
     if (rc == LWG_OK) rc = dalloc(&g->in8, P * 8);
     // largest activation: 64 channels replicated to full resolution in front of the last up-sampling conv
-    if (rc == LWG_OK) rc = dalloc(&g->act[0], P * 64);
-    if (rc == LWG_OK) rc = dalloc(&g->act[1], P * 64);
+    // (+ 1024 zeros behind each: where the bf16x3 kernels' out-of-image taps point, never written)
+    g->act_floats = P * 64;
+    if (rc == LWG_OK) rc = dalloc(&g->act[0], P * 64 + 1024);
+    if (rc == LWG_OK) rc = dalloc(&g->act[1], P * 64 + 1024);
     if (rc == LWG_OK) rc = dalloc(&g->raw, P * 64);
     if (rc == LWG_OK) rc = dalloc(&g->coarse, P * 3);
     if (rc == LWG_OK) rc = dalloc(&g->zeros, 64);
@@ -562,7 +616,7 @@ void lwg_inpaint_destroy(lwg_inpaint *g)
     if (!g) return;
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     for (auto &net : g->net)
-        for (auto &L : net) { fr(L.w); fr(L.bias); fr(L.bn_scale); fr(L.bn_shift); }
+        for (auto &L : net) { fr(L.w); fr(L.w_split); fr(L.bias); fr(L.bn_scale); fr(L.bn_shift); }
     fr(g->wqkv); fr(g->bqkv); fr(g->in8); fr(g->act[0]); fr(g->act[1]); fr(g->raw); fr(g->coarse); fr(g->zeros);
     fr(g->attn_o); fr(g->attn_ml);
     delete g;
@@ -635,6 +689,14 @@ int lwg_inpaint_load_weight(lwg_inpaint *g, const char *key, const float *data_h
 
 int lwg_inpaint_missing_weights(const lwg_inpaint *g) { return g ? missing(g) : -1; }
 
+int lwg_inpaint_set_precision(lwg_inpaint *g, int precision)
+{
+    LWG_REQUIRE(g, "inpaint_set_precision: NULL handle");
+    if (precision != 0 && precision != 1) LWG_FAIL(LWG_ERR_INVALID_ARG, "inpaint_set_precision: 0 (fp32) or 1 (bf16x3)");
+    g->precision = precision;
+    return LWG_OK;
+}
+
 int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, float *coarse_x, float *x, float *comp,
                         lwg_stream_t stream)
 {
@@ -650,7 +712,7 @@ int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, f
     inpaint_input_kernel<<<ceil_div(P, 256), 256, 0, st>>>(imgs, masks, nullptr, P, g->in8);
     LWG_LAUNCH_CHECK("inpaint_input_kernel");
     int H = S;
-    int rc = run_net(g, 0, g->in8, &H, true, nullptr, st);
+    int rc = run_net(g, 0, g->in8, false, &H, true, nullptr, st);
     if (rc != LWG_OK) return rc;
     {
         const GatedArgs a = gated_args(g, g->net[0].back(), H, nullptr, 4);
@@ -662,7 +724,8 @@ int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, f
     LWG_LAUNCH_CHECK("inpaint_input_kernel");
     H = S;
     const float *feat = nullptr;
-    if ((rc = run_net(g, 1, g->in8, &H, false, &feat, st)) != LWG_OK) return rc;
+    if ((rc = run_net(g, 1, g->in8, false, &H, false, &feat, st)) != LWG_OK) return rc;
+    bool feat_split = false;   // format of what the attention leaves for refine_upsample_net
     {   // self attention on (H*H) tokens of 128 channels: q/k/v as one 1x1 implicit GEMM, then the streaming softmax
         ConvArgs a = {};
         a.x = feat; a.ldx = kAttnC; a.N = 1; a.H = H; a.W = H; a.Cin = kAttnC; a.cin_log2 = 7;
@@ -678,8 +741,10 @@ int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, f
             attention_mfma_kernel<<<dim3(N / AM_Q, g->attn_ks), 512, 0, st>>>(g->raw, kQkvN, g->bqkv, N, N / g->attn_ks, g->attn_o,
                                                                            reinterpret_cast<float2 *>(g->attn_ml));
             LWG_LAUNCH_CHECK("attention_mfma_kernel");
+            feat_split = layer_split(g, g->net[2][0]);   // written in the format refine_upsample_net's first layer reads
             attention_combine_kernel<<<ceil_div((long)N * (AM_C / 4), 256), 256, 0, st>>>(
-                g->attn_o, reinterpret_cast<const float2 *>(g->attn_ml), g->attn_ks, N, g->bqkv + 2 * AT_D, feat, g->gamma, dst);
+                g->attn_o, reinterpret_cast<const float2 *>(g->attn_ml), g->attn_ks, N, g->bqkv + 2 * AT_D, feat, g->gamma, dst,
+                feat_split ? 1 : 0);
             LWG_LAUNCH_CHECK("attention_combine_kernel");
         } else {
             attention_kernel<kAttnC><<<N / AT_Q, 256, 0, st>>>(g->raw, kQkvN, g->bqkv, feat, g->gamma, N, dst);
@@ -692,7 +757,7 @@ int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, f
         LWG_HIP(hipMemcpyAsync(g->act[1], feat, (size_t)H * H * kAttnC * sizeof(float), hipMemcpyDeviceToDevice, st));
         feat = g->act[1];
     }
-    if ((rc = run_net(g, 2, feat, &H, true, nullptr, st)) != LWG_OK) return rc;
+    if ((rc = run_net(g, 2, feat, feat_split, &H, true, nullptr, st)) != LWG_OK) return rc;
     {
         const GatedArgs a = gated_args(g, g->net[2].back(), H, nullptr, 4);
         inpaint_output_kernel<<<ceil_div(P, 256), 256, 0, st>>>(a, imgs, masks, x, comp);

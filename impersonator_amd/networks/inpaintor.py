@@ -81,6 +81,10 @@ class InpaintSANet(nn.Module):
              (c // 2, 3, 3, 1, 1, 0, 0)])
         self._handle = None
         self._uploaded = None
+        # conv arithmetic (extension, as ImpersonatorGenerator.precision): "bf16x3" = the split-operand MFMA kernels for the gated
+        # convs with >= 32 input channels, "fp32" = exact fp32 MFMA everywhere.  Env LWG_INPAINT_PRECISION overrides.
+        import os
+        self.precision = os.environ.get("LWG_INPAINT_PRECISION", "bf16x3")
 
     def _version(self):
         return tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
@@ -105,6 +109,9 @@ class InpaintSANet(nn.Module):
             if missing:
                 raise _lib.LwgError(-5, "%d inpaintor weights missing after upload" % missing)
             self._uploaded = ver
+        if self.precision not in ("fp32", "bf16x3"):
+            raise ValueError("InpaintSANet.precision must be 'fp32' or 'bf16x3'")
+        _lib.check(lib.lwg_inpaint_set_precision(self._handle, 1 if self.precision == "bf16x3" else 0))
         return self._handle
 
     def release(self):

@@ -256,6 +256,10 @@ LWG_API void lwg_inpaint_destroy(lwg_inpaint *g);
 LWG_API int lwg_inpaint_load_weight(lwg_inpaint *g, const char *key, const float *data_host, const int64_t *shape,
                                     int ndim);
 LWG_API int lwg_inpaint_missing_weights(const lwg_inpaint *g);
+/* Arithmetic of the gated convolutions with >= 32 input channels (31 of the 35; the 5x5 entry layers, the 16 -> 3 exit layers and
+ * the attention's projections and products always run in exact fp32): 1 (default) = bf16x3, the split-operand kernels of the
+ * generator (three bf16 MFMA products per multiply-add, fp32 accumulate); 0 = exact fp32 MFMA everywhere. */
+LWG_API int lwg_inpaint_set_precision(lwg_inpaint *g, int precision);
 /* InpaintSANet.forward(imgs, masks) (inpaintor.py:178-202): imgs (1,3,is,is), masks (1,1,is,is) ->
  * coarse_x [optional], x (refined, clamped), comp_imgs = x*masks + imgs*(1-masks) [optional], all (1,3,is,is). */
 LWG_API int lwg_inpaint_forward(lwg_inpaint *g, const float *imgs, const float *masks, float *coarse_x, float *x,
