@@ -1693,42 +1693,6 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(const float *__restr
     }
 }
 
-// Modes 0 and 1 of weight_layout_kernel through an LDS tile of 32 a x 32 b x taps entries: the tensor is READ in runs of
-// 32 * taps contiguous floats (the one-thread-per-output form reads with a stride of `taps` floats: 18 cache lines per wave load)
-// and WRITTEN in 128-byte runs; pitch 32 * taps + 1 in LDS: both transposed walks are bank-conflict free (taps, the pitch: odd).
-// Same values, same destination addresses: a drop-in for A % 32 == B % 32 == 0 (every 3x3 / 4x4 layer of the three streams,
-// re-laid-out twice per training iteration: forward matrix and data-gradient matrix).
-template <int MODE>
-__global__ __launch_bounds__(256) void weight_layout_tiled_kernel(const float *__restrict__ w, float *__restrict__ dst, int A, int B,
-                                                                  int taps, int pitch, int split)
-{
-    extern __shared__ float wl_tile[];
-    const int tid = threadIdx.x, a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
-    const int rowlen = 32 * taps, lp = rowlen + 1;
-    for (int i = tid; i < 32 * rowlen; i += 256) {
-        const int a = i / rowlen, j = i - a * rowlen;
-        wl_tile[a * lp + j] = w[((size_t)(a0 + a) * B + b0) * taps + j];
-    }
-    __syncthreads();
-    auto put = [&](size_t d, float v) {
-        if (!split) {
-            dst[d] = v;
-            return;
-        }
-        __bf16 *o = reinterpret_cast<__bf16 *>(dst) + (d >> 5) * 64 + (d & 31);
-        const __bf16 hi = (__bf16)v;
-        o[0] = hi;
-        o[32] = (__bf16)(v - (float)hi);
-    };
-    for (int i = tid; i < 32 * rowlen; i += 256) {
-        const int fast = i & 31, t = (i >> 5) % taps, slow = i / rowlen;
-        if (MODE == 0)      // dst[a][t][b] = w[a][b][t]
-            put((size_t)(a0 + slow) * pitch + (size_t)t * B + b0 + fast, wl_tile[slow * lp + fast * taps + t]);
-        else                // dst[b][t][a] = w[a][b][taps - 1 - t]
-            put((size_t)(b0 + slow) * pitch + (size_t)t * A + a0 + fast, wl_tile[fast * lp + slow * taps + (taps - 1 - t)]);
-    }
-}
-
 // sums the `KS` reduction-split slices of a general-mode conv (ConvArgs::ksplit) in order and adds the bias: y[i] = bias[i % C] + sum_k part[k][i]
 __global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float4 *__restrict__ part, int KS, size_t stride4, long n4, int C,
                                                             const float *__restrict__ bias, float4 *__restrict__ y)
@@ -2376,16 +2340,8 @@ int relayout(const float *w, float *dst, int mode, int A, int B, int taps, long 
     const int rows = mode == 1 ? B : A, dense = taps * (mode == 1 ? A : B);
     if (split && pitch && pitch != dense) LWG_FAIL(LWG_ERR_STATE, "relayout: split matrices have no row padding");
     if (pitch && pitch != dense) LWG_HIP(hipMemsetAsync(dst, 0, (size_t)rows * pitch * sizeof(float), st));
-    static const char *tiled_env = getenv("LWG_LAYOUT_TILED");   // "0": the one-thread-per-output kernel everywhere (A/B switch)
-    if ((mode == 0 || mode == 1) && A % 32 == 0 && B % 32 == 0 && taps <= 16 && total == (long)A * B * taps &&
-        !(tiled_env && tiled_env[0] == '0')) {
-        const dim3 grid(B / 32, A / 32);
-        const size_t lds = (size_t)32 * (32 * taps + 1) * sizeof(float);
-        if (mode == 0) weight_layout_tiled_kernel<0><<<grid, 256, lds, st>>>(w, dst, A, B, taps, pitch ? pitch : dense, split ? 1 : 0);
-        else weight_layout_tiled_kernel<1><<<grid, 256, lds, st>>>(w, dst, A, B, taps, pitch ? pitch : dense, split ? 1 : 0);
-        LWG_LAUNCH_CHECK("weight_layout_tiled_kernel");
-        return LWG_OK;
-    }
+    // (an LDS-tiled transpose -- 32 x 32 x taps tiles, contiguous reads, 128-byte writes -- measured SLOWER in the training iteration:
+    // 25.3 vs 24.3 ms at 256x256 batch 4, profiles/r05_train_ab.md: 256 workgroups of 36 serial passes against 9216 independent ones)
     weight_layout_kernel<<<ceil_div(total, 256), 256, 0, st>>>(w, dst, mode, A, B, taps, total, pitch ? pitch : dense, split ? 1 : 0);
     LWG_LAUNCH_CHECK("weight_layout_kernel");
     return LWG_OK;

@@ -256,7 +256,8 @@ def test_predict_batches_launches_no_framework_kernel():
     ours = [k for k in records if "lwg" in k]
     foreign = sorted({k for k in records if "lwg" not in k})
     print("%d device records, %d liblwg kernels; others: %s" % (len(records), len(ours), foreign))
-    assert len(ours) >= 16 * 20, "the profiler saw too few liblwg kernels: %s" % sorted(set(records))[:10]
+    # 16 batches = four generator launch sequences of 32 frames (Imitator.fuse = 4, ~55 launches each) + two rounds of geometry
+    assert len(ours) >= 4 * 50, "the profiler saw too few liblwg kernels: %s" % sorted(set(records))[:10]
     assert not [k for k in foreign if "at::" in k or "elementwise" in k or "Cat" in k], foreign
     assert not [k for k in foreign if "fill" in k.lower() or "memset" in k.lower() or "copy" in k.lower()], foreign
 
