@@ -547,7 +547,8 @@ def secondary_train(steps=3):
         # captured once and replayed (what a training loop on one GPU would call)
         for mode in ("eager", "graph"):
             r = bench_train.measure(n, s, steps=steps, warmup=2, precision="bf16x3", graph=mode == "graph")
-            out[name][mode] = {"ms_per_iteration": r["ms_per_iteration"], "images_per_s": r["images_per_s"], "conv_tflops": r["conv_tflops"]}
+            out[name][mode] = {"ms_per_iteration": r["ms_per_iteration"], "images_per_s": r["images_per_s"], "conv_tflops": r["conv_tflops"],
+                               "roofline": r["roofline"]}
             torch.cuda.empty_cache()
         out[name]["conv_gflop_per_iteration"] = r["conv_gflop_per_iteration"]
     out["what"] = ("G update (three streams forward, losses adv + L1 + mask, hand-written backward, Adam) + D update; "

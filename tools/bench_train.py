@@ -107,6 +107,13 @@ def measure(batch, image_size, steps=5, warmup=1, precision="bf16x3", script_los
                                "discriminator update and the adversarial term) / iteration time; the bf16x3 kernels' ceiling is "
                                "833 TFLOP/s algorithmic (three products per multiply-add), fp32's 157",
            "losses": {k: round(v, 6) for k, v in losses.items()}}
+    peak = 2500.0 / 3.0 if precision != "fp32" else 157.3
+    out["roofline"] = {"bound": "mfma", "achieved": out["conv_tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
+                       "frac": round(out["conv_tflops"] / peak, 4),
+                       "what": "algorithmic conv FLOP of the whole iteration / iteration time, against the matrix pipe's ceiling for "
+                               "this arithmetic (bf16x3: 2500 / 3); everything that is not a convolution (norms, losses, Adam, "
+                               "re-layouts, launch gaps) counts against it",
+                       "per_kernel": "profiles/r05_train_kernel_stats.md (rocprofv3 --kernel-trace --stats of tools/bench_train.py)"}
     if world > 1:
         # the two collectives of an iteration on their own: the same buffers, the same call
         fg, dg = model._generator_trainer().flat_g, model._D.flat_buffers()[1]
