@@ -66,7 +66,7 @@ def kernel_peak(name):
 
 BATCH = 8
 IMAGE_SIZE = 256
-TRAFFIC_FILE = "r04_traffic.json"
+TRAFFIC_FILE = "r05_traffic.json"
 
 
 # sources of the kernels the timed step launches (the training and inpainting kernels are not among them)
@@ -696,7 +696,7 @@ def main():
                  "flop_per_launch": kfl / max(kn, 1),
                  "measured": "HIP events around each launch, steps re-run on one lane (kernels not overlapped).  An event pair spans "
                              "the launch's dispatch latency too (~10 us on a dependent chain): rocprofv3's kernel durations "
-                             "(profiles/r04_kernel_stats.md) are that much shorter, the fractions here that much lower",
+                             "(profiles/r05_kernel_stats.md) are that much shorter, the fractions here that much lower",
                  "frac_note": ("achieved = ALGORITHMIC flops (2*M*Cout*taps*Cin, real taps and channels) / launch time; "
                                "frac = frac_algorithmic = achieved / peak of the MFMA instruction used (bf16 dense 2500, "
                                "fp32 157.3).  A bf16x3 kernel executes 3 bf16 MFMA products per algorithmic multiply-add: "
