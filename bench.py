@@ -710,7 +710,7 @@ def main():
                                                         "frac_pipe": round(v[2] / (v[1] * 1e-3) / 1e12 / kernel_peak(k), 4)}
                                                     for k, v in table.items()}}}
         # bytes per launch of the dominant kernel from the committed PMC passes of the same command
-        # (tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md
+        # (tools/r05_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md
         # prescribes); bench.py cannot collect counters itself.  The file carries the digest of the kernel sources it
         # was measured on: a stale measurement is dropped, not attached.
         tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
