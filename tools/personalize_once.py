@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One Imitator.personalize of the synthetic configuration with an InpaintSANet background model and --only_vis (the variant with the
-most glue), for `rocprofv3 --kernel-trace --stats`: every kernel of the call must be liblwg's (tools/r04_profile.sh; the GPU test
+most glue), for `rocprofv3 --kernel-trace --stats`: every kernel of the call must be liblwg's (tools/r05_profile.sh; the GPU test
 tests/test_gpu_personalize_glue.py checks the same through the torch profiler).  Module construction and the weight uploads of the
 first call are in the trace too (copyBuffer rows); ATen kernels (at::native::...) must not be."""
 import os
