@@ -457,8 +457,18 @@ def secondary_latency(dev, frames=40):
         torch.cuda.synchronize(dev)
         if i >= 4:
             ms.append((time.perf_counter() - t0) * 1e3)
-    out["swap_one_pair_ms"] = dict(_stats(ms), what="Swapper.swap at batch 1 awaited (eager; its mask bookkeeping indexes with a boolean "
-                                                     "mask, which reads the device: not capturable as a graph)")
+    out["swap_one_pair_ms"] = dict(_stats(ms), what="Swapper.swap at batch 1 awaited, eager launches (liblwg kernels only)")
+    run = sw.swap_graph(sw.src_info, sw.tsf_info, target_part="body")
+    gms = []
+    for i in range(4 + 20):
+        t0 = time.perf_counter()
+        q = run()
+        torch.cuda.synchronize(dev)
+        if i >= 4:
+            gms.append((time.perf_counter() - t0) * 1e3)
+    out["swap_one_pair_graph_ms"] = dict(_stats(gms), what="the same swap captured once (Swapper.swap_graph) and replayed as one HIP graph",
+                                         graph_equals_eager=bool(torch.equal(p, q)))
+    del run
     sw.generator.release()
     return out
 

@@ -110,12 +110,109 @@ __global__ __launch_bounds__(256) void vis_select_kernel(const float *__restrict
     out[o] = vis ? f2pts[o] : -2.f;
 }
 
+// ---- appearance transfer glue (models/swapper.py:198-253): the mask bookkeeping of Swapper.swap as kernels, so that a swap launches
+// no framework kernel, copies no index list to the device and never reads the device back (the boolean-mask assignment of the
+// reference's calculate_trans does) -- which also makes the whole swap capturable as one HIP graph.
+//   swap_masks_kernel   part map (nparts, H, W) of the source -> part_mask = (sum of the selected parts != 0), left_mask = (sum of the
+//                       kept parts != 0) as {0,1} floats (:206-207, the sums taken in channel order), and T11 = the identity grid where
+//                       left_mask, else -2 (:243-245)
+//   mask_faces_kernel   tsf_f2p = p2verts.clone(); tsf_f2p[0, left_faces] = -2 (:246-247) with the face set as a byte per face
+//   swap_compose_kernel cat([tsf21 * part_mask + tsf11 * left_mask, cond]) (:213-216): products rounded separately, then added
+//   clamp_kernel        T21.clamp_(-2, 2) (:249)
+__global__ __launch_bounds__(256) void swap_masks_kernel(const float *__restrict__ part, int nparts, int HW, unsigned sel_bits,
+                                                         unsigned left_bits, const float *__restrict__ grid,
+                                                         float *__restrict__ part_mask, float *__restrict__ left_mask,
+                                                         float *__restrict__ T11)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float s = 0.f, l = 0.f;
+    for (int c = 0; c < nparts; ++c) {
+        const float v = part[(size_t)c * HW + p];
+        if ((sel_bits >> c) & 1u) s += v;
+        if ((left_bits >> c) & 1u) l += v;
+    }
+    const bool keep = l != 0.f;
+    part_mask[p] = s != 0.f ? 1.f : 0.f;
+    left_mask[p] = keep ? 1.f : 0.f;
+    const float2 g = *reinterpret_cast<const float2 *>(grid + (size_t)p * 2);
+    *reinterpret_cast<float2 *>(T11 + (size_t)p * 2) = keep ? g : make_float2(-2.f, -2.f);
+}
+
+__global__ __launch_bounds__(256) void mask_faces_kernel(const float *__restrict__ f2pts, const unsigned char *__restrict__ drop, int nf,
+                                                         int per_face, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf * per_face) return;
+    out[i] = drop[i / per_face] ? -2.f : f2pts[i];
+}
+
+__global__ __launch_bounds__(256) void swap_compose_kernel(const float *__restrict__ tsf21, const float *__restrict__ tsf11,
+                                                           const float *__restrict__ part_mask, const float *__restrict__ left_mask,
+                                                           const float *__restrict__ cond, int nc, int HW, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)(3 + nc) * HW) return;
+    const int c = (int)(i / HW), p = (int)(i - (long)c * HW);
+    if (c < 3) {
+        const float a = tsf21[i] * part_mask[p], b = tsf11[i] * left_mask[p];   // (built with -ffp-contract=off: two roundings, then the sum)
+        out[i] = a + b;
+    } else {
+        out[i] = cond[(size_t)(c - 3) * HW + p];
+    }
+}
+
+__global__ __launch_bounds__(256) void clamp_kernel(float *__restrict__ x, long n, float lo, float hi)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
 }  // namespace
 }  // namespace lwg
 
 using namespace lwg;
 
 extern "C" {
+
+int lwg_swap_masks(const float *part, int nparts, int H, int W, unsigned selected_bits, unsigned left_bits, const float *grid,
+                   float *part_mask, float *left_mask, float *T11, lwg_stream_t stream)
+{
+    LWG_REQUIRE(part && grid && part_mask && left_mask && T11, "swap_masks: NULL argument");
+    LWG_REQUIRE(nparts > 0 && nparts <= 32 && H > 0 && W > 0, "swap_masks: 1..32 parts, positive image size");
+    swap_masks_kernel<<<ceil_div((long)H * W, 256), 256, 0, as_stream(stream)>>>(part, nparts, H * W, selected_bits, left_bits, grid,
+                                                                                part_mask, left_mask, T11);
+    LWG_LAUNCH_CHECK("swap_masks_kernel");
+    return LWG_OK;
+}
+
+int lwg_mask_faces(const float *f2pts, const unsigned char *drop, int nf, int per_face, float *out, lwg_stream_t stream)
+{
+    LWG_REQUIRE(f2pts && drop && out && nf > 0 && per_face > 0, "mask_faces: bad arguments");
+    mask_faces_kernel<<<ceil_div((long)nf * per_face, 256), 256, 0, as_stream(stream)>>>(f2pts, drop, nf, per_face, out);
+    LWG_LAUNCH_CHECK("mask_faces_kernel");
+    return LWG_OK;
+}
+
+int lwg_swap_compose(const float *tsf21, const float *tsf11, const float *part_mask, const float *left_mask, const float *cond, int nc,
+                     int H, int W, float *out, lwg_stream_t stream)
+{
+    LWG_REQUIRE(tsf21 && tsf11 && part_mask && left_mask && out && (cond || nc == 0), "swap_compose: NULL argument");
+    LWG_REQUIRE(nc >= 0 && H > 0 && W > 0, "swap_compose: bad sizes");
+    swap_compose_kernel<<<ceil_div((long)(3 + nc) * H * W, 256), 256, 0, as_stream(stream)>>>(tsf21, tsf11, part_mask, left_mask, cond, nc,
+                                                                                             H * W, out);
+    LWG_LAUNCH_CHECK("swap_compose_kernel");
+    return LWG_OK;
+}
+
+int lwg_clamp(float *x, size_t n, float lo, float hi, lwg_stream_t stream)
+{
+    LWG_REQUIRE(x && lo <= hi, "clamp: bad arguments");
+    if (!n) return LWG_OK;
+    clamp_kernel<<<ceil_div((long)n, 256), 256, 0, as_stream(stream)>>>(x, (long)n, lo, hi);
+    LWG_LAUNCH_CHECK("clamp_kernel");
+    return LWG_OK;
+}
 
 int lwg_morph(const float *mask, int n, int H, int W, long batch_stride, int ks, int mode, int complement, float *out,
               lwg_stream_t stream)

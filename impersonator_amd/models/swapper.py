@@ -4,8 +4,8 @@
 swapper.py:128-129); `swap` builds the two flow fields (T11 = identity grid with the non-kept pixels sent to -2,
 T21 = barycentric flow from the target's visible faces, clamped; swapper.py:242-253), warps the two images and
 runs the two-stream Liquid Warping Block generator (generator.py:245-275) with the blend fused.
-All per-pixel device work is liblwg; the mask bookkeeping around it (a handful of elementwise ops, once per swap)
-stays in torch.
+All device work is liblwg, the mask bookkeeping included (personalize.hip: lwg_swap_masks, lwg_mask_faces, lwg_swap_compose,
+lwg_clamp): a swap launches no framework kernel and can be replayed as one HIP graph (`swap_graph`).
 """
 import numpy as np
 import torch
@@ -58,23 +58,47 @@ class Swapper(Imitator):
         self.src_info = self.personalize(src_path, src_smpl, bg_img=src_bg)
         self.tsf_info = self.personalize(tgt_path, tgt_smpl, bg_img=tgt_bg)
 
+    def _part_sets(self, target_part):
+        """(selected bits, kept bits, device byte-per-face flags of the kept parts' faces) of `target_part`, built once."""
+        cache = getattr(self, '_part_cache', None)
+        if cache is None:
+            cache = self._part_cache = {}
+        if target_part not in cache:
+            selected_ids = self.PART_IDS[target_part]
+            left_ids = [i for i in self.PART_IDS['all'] if i not in selected_ids]
+            drop = np.zeros(self.render.nf, np.uint8)
+            for i in left_ids:                                   # left_faces of swapper.py:208, as one byte per face
+                drop[np.asarray(self.part_faces[i], np.int64)] = 1
+            bits = lambda ids: int(sum(1 << i for i in ids))
+            cache[target_part] = (bits(selected_ids), bits(left_ids), torch.from_numpy(drop).cuda())
+        return cache[target_part]
+
     @torch.no_grad()
     def swap(self, src_info, tgt_info, target_part='body', visualizer=None):
-        """swapper.py:198-239."""
+        """swapper.py:198-239.  Every device step is a liblwg launch (lwg_swap_masks, lwg_mask_faces, lwg_cal_bc_transform, lwg_clamp,
+        the two image warps, lwg_swap_compose, the two-stream generator with the blend fused): no framework kernel, no index list
+        copied to the device, no read-back -- the call can be captured in a HIP graph (`swap_graph`)."""
+        from .. import _lib
         assert target_part in self.PART_IDS.keys()
-        selected_ids = self.PART_IDS[target_part]
-        left_ids = [i for i in self.PART_IDS['all'] if i not in selected_ids]
-        src_part_mask = (torch.sum(src_info['part'][:, selected_ids, ...], dim=1) != 0).bool()
-        src_left_mask = torch.sum(src_info['part'][:, left_ids, ...], dim=1).bool()
-        left_faces = sorted(set(f for i in left_ids for f in self.part_faces[i]))
-
-        T11, T21 = self.calculate_trans(src_left_mask, left_faces)
+        lib = _lib.load()
+        sel_bits, left_bits, drop = self._part_sets(target_part)
+        part = src_info['part'].float().contiguous()
+        if part.shape[0] != 1:
+            raise ValueError("Swapper.swap transfers ONE source / target pair per call, as the reference does")
+        _, nparts, h, w = part.shape
+        dev = part.device
+        part_mask = torch.empty((1, 1, h, w), device=dev)
+        left_mask = torch.empty((1, 1, h, w), device=dev)
+        T11 = torch.empty((1, h, w, 2), device=dev)
+        _lib.check(lib.lwg_swap_masks(_lib.ptr(part), nparts, h, w, sel_bits, left_bits, _lib.ptr(self.grid), _lib.ptr(part_mask),
+                                      _lib.ptr(left_mask), _lib.ptr(T11), _lib.stream_ptr()))
+        T21 = self._flow_through_kept_faces(drop)
         tsf21 = self.generator.transform(tgt_info['img'], T21)
         tsf11 = self.generator.transform(src_info['img'], T11)
-        src_part_mask = src_part_mask[:, None, :, :].float()
-        src_left_mask = src_left_mask[:, None, :, :].float()
-        tsf_img = tsf21 * src_part_mask + tsf11 * src_left_mask
-        tsf_inputs = torch.cat([tsf_img, src_info['cond']], dim=1)
+        cond = src_info['cond'].float().contiguous()
+        tsf_inputs = torch.empty((1, 3 + cond.shape[1], h, w), device=dev)
+        _lib.check(lib.lwg_swap_compose(_lib.ptr(tsf21), _lib.ptr(tsf11), _lib.ptr(part_mask), _lib.ptr(left_mask), _lib.ptr(cond),
+                                        cond.shape[1], h, w, _lib.ptr(tsf_inputs), _lib.stream_ptr()))
 
         preds, tsf_mask = self.forward(tsf_inputs, tgt_info['feats'], T21, src_info['feats'], T11, src_info['bg'])
         if self._opt.front_warp:
@@ -84,16 +108,58 @@ class Swapper(Imitator):
         self.T12, self.T21 = T11, T21
         return preds
 
-    def calculate_trans(self, src_left_mask, left_faces):
-        """swapper.py:242-253."""
-        T11 = self.grid.clone()
-        T11[~src_left_mask[0]] = -2
-        T11 = T11.unsqueeze(0)
-        tsf_f2p = self.tsf_info['p2verts'].clone()
-        tsf_f2p[0, left_faces] = -2
+    def _flow_through_kept_faces(self, drop_faces):
+        """swapper.py:246-251, the T21 half of calculate_trans: the target's face vertices with the kept parts' faces sent to -2
+        (`drop_faces`: one byte per face on the device, `_part_sets`), the barycentric flow of the source's visible faces through
+        them, clamped to [-2, 2]."""
+        from .. import _lib
+        lib = _lib.load()
+        p2v = self.tsf_info.get('p2verts_c')
+        if p2v is None:
+            p2v = self.tsf_info['p2verts'].float().contiguous()
+        tsf_f2p = torch.empty_like(p2v)
+        _lib.check(lib.lwg_mask_faces(_lib.ptr(p2v), _lib.ptr(drop_faces), p2v.shape[1], 6, _lib.ptr(tsf_f2p), _lib.stream_ptr()))
         T21 = self.render.cal_bc_transform(tsf_f2p, self.src_info['fim'], self.src_info['wim'])
-        T21.clamp_(-2, 2)
-        return T11, T21
+        _lib.check(lib.lwg_clamp(_lib.ptr(T21), T21.numel(), -2.0, 2.0, _lib.stream_ptr()))
+        return T21
+
+    @torch.no_grad()
+    def calculate_trans(self, src_left_mask, left_faces):
+        """swapper.py:242-253 with the reference's signature: src_left_mask (1, H, W) bool, left_faces a list of face ids
+        -> (T11, T21).  `swap` itself takes the same two kernels with the face set cached on the device (`_part_sets`)."""
+        from .. import _lib
+        lib = _lib.load()
+        m = src_left_mask.reshape(1, *src_left_mask.shape[-2:]).float().contiguous().cuda()
+        _, h, w = m.shape
+        scratch = torch.empty((2, h, w), device=m.device)
+        T11 = torch.empty((1, h, w, 2), device=m.device)
+        _lib.check(lib.lwg_swap_masks(_lib.ptr(m), 1, h, w, 0, 1, _lib.ptr(self.grid), _lib.ptr(scratch[0]), _lib.ptr(scratch[1]),
+                                      _lib.ptr(T11), _lib.stream_ptr()))
+        drop = np.zeros(self.render.nf, np.uint8)
+        drop[np.asarray(sorted(set(left_faces)), np.int64)] = 1
+        return T11, self._flow_through_kept_faces(torch.from_numpy(drop).cuda())
+
+    @torch.no_grad()
+    def swap_graph(self, src_info, tgt_info, target_part='body'):
+        """(extension) `swap(src_info, tgt_info, target_part)` captured once as a HIP graph: returns `run() -> preds` that replays it
+        (the two personalised subjects are the graph's inputs: personalise again -> capture again).  Same values as `swap`."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.swap(src_info, tgt_info, target_part)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            preds = self.swap(src_info, tgt_info, target_part)
+
+        def run():
+            graph.replay()
+            return preds
+
+        run.graph, run.preds = graph, preds
+        return run
 
     def warp(self, preds, tsf, fim, fake_tsf_mask):
         """swapper.py:255-259."""

@@ -139,6 +139,21 @@ LWG_API int lwg_smpl_forward_f64(const float *theta, int bs, int num_betas, int 
                                  const float *weights, const float *joint_regressor, float *verts, float *joints,
                                  float *Rs, void *workspace, size_t workspace_bytes, lwg_stream_t stream);
 
+/* The mask bookkeeping of appearance transfer, models/swapper.py:198-253 (Swapper.swap / calculate_trans), batch 1 as the reference
+ * runs it, NCHW fp32.  With these a swap launches no framework kernel and never reads the device back (the reference's
+ * `T11[~src_left_mask[0]] = -2` does), so the whole call can be captured in a HIP graph.
+ *   lwg_swap_masks  : part (nparts,H,W) = source part map (encode_fim with the 'par' table); bit c of selected_bits / left_bits = part c
+ *                     belongs to the swapped / the kept set.  -> part_mask, left_mask (H,W) in {0,1} = (channel sum != 0), and
+ *                     T11 (H,W,2) = grid where left_mask else -2 (grid: the identity sampling grid, utils/nmr.py:490-504).
+ *   lwg_mask_faces  : out = f2pts with the faces flagged in `drop` (one byte per face) set to -2 (tsf_f2p[0, left_faces] = -2).
+ *   lwg_swap_compose: out (3+nc,H,W) = cat([tsf21 * part_mask + tsf11 * left_mask, cond]).
+ *   lwg_clamp       : x = min(max(x, lo), hi) in place (T21.clamp_(-2, 2)). */
+LWG_API int lwg_swap_masks(const float *part, int nparts, int H, int W, unsigned selected_bits, unsigned left_bits, const float *grid,
+                           float *part_mask, float *left_mask, float *T11, lwg_stream_t stream);
+LWG_API int lwg_mask_faces(const float *f2pts, const unsigned char *drop, int nf, int per_face, float *out, lwg_stream_t stream);
+LWG_API int lwg_swap_compose(const float *tsf21, const float *tsf11, const float *part_mask, const float *left_mask, const float *cond,
+                             int nc, int H, int W, float *out, lwg_stream_t stream);
+LWG_API int lwg_clamp(float *x, size_t n, float lo, float hi, lwg_stream_t stream);
 /* ---- Once-per-source glue of Imitator.personalize (models/imitator.py:82-155), so that `personalize` launches no
  * framework kernel.
  * morph: utils/util.py:73-89 -- erode (mode 0: pad with 1, count == ks*ks) / dilate (mode 1: pad with 0, count >= 1) of a

@@ -113,3 +113,44 @@ def test_generator_forward_and_infer_front(precision):
     outs2 = G.infer_front(src.flip(0).cuda(), tsf.cuda(), T.cuda())
     assert float((outs2[2] - outs[3]).abs().max()) > 1e-3
     G.release()
+
+
+def test_swap_launches_no_framework_kernel_and_replays_as_one_graph():
+    """Swapper.swap (models/swapper.py:198-239) with its mask bookkeeping as liblwg kernels (lwg_swap_masks, lwg_mask_faces,
+    lwg_swap_compose, lwg_clamp): under the torch profiler every device record of a swap is liblwg's (no ATen elementwise / index /
+    cat kernel, no copy of an index list, no read-back); the same call captured once (`swap_graph`) replays to the same bits; and
+    `calculate_trans` with the reference's own signature (bool mask, face-id list) returns the fields `swap` used."""
+    from torch.autograd import DeviceType
+    from torch.profiler import ProfilerActivity, profile
+    from impersonator_amd.utils import synthetic
+    sw, smpl_a, img_a, bg_a = demo.build_synthetic_imitator(batch_size=1, seed=0, image_size=256, model="swapper")
+    smpl_b = demo.synthetic_smpls(8, seed=3)[5]
+    img_b = synthetic.smooth_image(77, (1, 3, 256, 256))[0]
+    sw.swap_setup(img_a, img_b, src_smpl=smpl_a, tgt_smpl=smpl_b, src_bg=bg_a, tgt_bg=synthetic.smooth_image(78, (1, 3, 256, 256))[0])
+    A, B = sw.src_info, sw.tsf_info
+    eager = sw.swap(A, B, target_part="body").clone()
+    T11, T21 = sw.T12.clone(), sw.T21.clone()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        again = sw.swap(A, B, target_part="body")
+        torch.cuda.synchronize()
+    assert torch.equal(again, eager)
+    records = [e.name for e in prof.events() if e.device_type == DeviceType.CUDA]
+    foreign = sorted({k for k in records if "lwg" not in k})
+    print("swap: %d device records, others: %s" % (len(records), foreign))
+    assert len(records) >= 40 and not foreign, foreign
+    # the reference-signature entry point gives the same two fields
+    left_ids = [i for i in sw.PART_IDS['all'] if i not in sw.PART_IDS['body']]
+    left_mask = torch.sum(A['part'][:, left_ids], dim=1).bool()
+    left_faces = sorted(set(f for i in left_ids for f in sw.part_faces[i]))
+    t11, t21 = sw.calculate_trans(left_mask, left_faces)
+    assert torch.equal(t11, T11) and torch.equal(t21, T21)
+    ref11 = sw.grid.clone()
+    ref11[~left_mask[0]] = -2
+    assert torch.equal(T11[0], ref11)
+    # one HIP graph launch per swap
+    run = sw.swap_graph(A, B, target_part="body")
+    for _ in range(3):
+        out = run()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
