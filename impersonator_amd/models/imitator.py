@@ -127,11 +127,27 @@ class Imitator(BaseModel):
 
         # masks and network inputs of imitator.py:116-135 as liblwg launches (lwg_morph, lwg_mask_compose): bg is 1, ft is 0
         bg_cond = src_info['cond'][:, -1:, :, :]
+        bg_done = None
         if bg_img is not None:
             src_info['bg'] = torch.as_tensor(bg_img, dtype=torch.float32).cuda().reshape(1, 3, opt.image_size, opt.image_size)
         elif getattr(opt, 'bg_model', 'ORIGINAL') != 'ORIGINAL' or self.bgnet is not self.generator.bg_model:
             body_mask = util.morph(bg_cond, ks=opt.bg_ks, mode='erode', complement=True)   # 1 - bg_mask
-            src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)          # imitator.py:124-125
+            # imitator.py:124-125.  The inpaintor has its own device handle (own scratch) and, at batch 1, launches of 64-128
+            # workgroups: it runs on a side stream UNDERNEATH the source-stream encoder below (equally small launches) instead of in
+            # front of it -- same kernels, same values; the streams meet again before personalize returns
+            main = torch.cuda.current_stream()
+            if getattr(self, '_bg_stream', None) is None:
+                self._bg_stream = torch.cuda.Stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(self._bg_stream):
+                self._bg_stream.wait_event(fork)
+                src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)
+                bg_done = torch.cuda.Event()
+                bg_done.record(self._bg_stream)
+            for t in (img, body_mask):
+                t.record_stream(self._bg_stream)
+            src_info['bg'].record_stream(main)
         else:
             # imitator.py:126-132: BGNet on the masked image + mask
             bg_mask = util.morph(bg_cond, ks=opt.bg_ks, mode='erode')
@@ -142,6 +158,8 @@ class Imitator(BaseModel):
         src_inputs = self.render.mask_compose(img, ft_erode, src_info['cond'], invert=True)
         src_info['feats'] = self.generator.encode_src(src_inputs)
         src_info['p2verts_c'] = p2verts_c
+        if bg_done is not None:
+            torch.cuda.current_stream().wait_event(bg_done)     # the background is complete for whoever uses src_info next
         self.src_info = src_info
 
         if visualizer is not None:
