@@ -262,7 +262,7 @@ class Imitator(BaseModel):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             tsf_inputs = self.transfer_params_by_smpl(static_smpl, cam_strategy, t=1)
             preds = self.forward(tsf_inputs, self.tsf_info['T'])
         info = self.tsf_info

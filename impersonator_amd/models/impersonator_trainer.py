@@ -293,7 +293,9 @@ class Impersonator(BaseModel):
                              real_src=self._real_src, real_tsf=self._real_tsf, bg_mask=self._bg_mask)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: ProcessGroupNCCL's watchdog thread polls the events of earlier collectives; under the default
+                # (global) mode such a call from ANOTHER thread while this one captures is an error that kills the process
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     terms, (_, _, fake_tsf_imgs, _) = tr.optimize_G(batch)
                     terms = dict(terms, d_loss=self._optimize_D(fake_tsf_imgs))
             except Exception as e:   # noqa: BLE001 -- whatever broke the capture, training must go on eagerly

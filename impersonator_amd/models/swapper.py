@@ -151,7 +151,7 @@ class Swapper(Imitator):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             preds = self.swap(src_info, tgt_info, target_part)
 
         def run():
