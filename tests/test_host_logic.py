@@ -100,3 +100,34 @@ def test_adam_step_state_words():
     s7 = ops.adam_step_state(7, (0.5, 0.999), device="cpu")
     assert int(s7[0]) == 7
     assert np.array_equal(s7.numpy()[1:].view(np.float64), np.array([0.5 ** 7, 0.999 ** 7]))
+
+
+def test_adjacent_row_blocks_are_taken_as_one_view():
+    """Imitator._adjacent_rows: consecutive row blocks of ONE contiguous tensor become a view of it (no copy kernel in a round's launch
+    sequence); anything else -- a gap, another tensor, another width, a strided block -- is refused (the caller concatenates)."""
+    from impersonator_amd.models.imitator import Imitator
+    base = torch.arange(40 * 85, dtype=torch.float32).reshape(40, 85)
+    blocks = [base[8:16], base[16:24], base[24:29]]
+    whole = Imitator._adjacent_rows(blocks)
+    assert whole is not None and whole.shape == (21, 85) and whole.data_ptr() == base[8:].data_ptr()
+    assert torch.equal(whole, base[8:29])
+    assert Imitator._adjacent_rows([base[0:8]]).data_ptr() == base.data_ptr()
+    assert Imitator._adjacent_rows([base[0:8], base[16:24]]) is None                 # a gap
+    assert Imitator._adjacent_rows([base[8:16], base[0:8]]) is None                  # out of order
+    assert Imitator._adjacent_rows([base[0:8], base.clone()[8:16]]) is None          # another tensor
+    assert Imitator._adjacent_rows([base[0:8], base[8:16, :80]]) is None             # another width / not contiguous
+    assert Imitator._adjacent_rows([base[0:8].double()]) is None                     # not fp32
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """bench.py's launch guard is pure host logic up to its first device call; on a box without a GPU the refusal it prints is the
+    'needs an MI355X' one -- the N-rank guards themselves are exercised on the GPU box (tests/test_gpu_multirank.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by tests/test_gpu_multirank.py")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
+    assert p.returncode != 0 and "MI355X" in p.stderr and not p.stdout.strip()
