@@ -391,10 +391,13 @@ class Imitator(BaseModel):
             # generator calls: `fuse` consecutive batches of the round as ONE launch sequence (their inputs are adjacent
             # slices of the round's tensors): the trunk convolutions of 16 frames are 256 tiles of 8 x 32 pixels -- twice
             # the MFMAs per weight stage of the 4 x 32 tiles 8 frames leave room for (conv3x3_halo_bf16x3)
+            # (a short round -- the tail of a sequence, or a timed window that is not a multiple of the round -- is still dealt to
+            # EVERY lane: four batches left are two sequences of two, not one of four on one lane with the other idle)
+            per = max(1, min(fuse, -(-len(prepared) // nl)))
             groups, k = [], 0
             while k < len(prepared):
                 g = [k]
-                while whole_inputs is not None and not self._opt.front_warp and len(g) < fuse and k + len(g) < len(prepared):
+                while whole_inputs is not None and not self._opt.front_warp and len(g) < per and k + len(g) < len(prepared):
                     g.append(k + len(g))
                 groups.append(g)
                 k += len(g)
