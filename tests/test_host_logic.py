@@ -131,3 +131,39 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], cwd=root, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
     assert p.returncode != 0 and "MI355X" in p.stderr and not p.stdout.strip()
+
+
+def test_bench_self_launch_builds_the_torchrun_command_or_refuses(monkeypatch, capsys):
+    """bench.self_launch (what `python bench.py --gpus N` does without a torch.distributed environment), with the device count and
+    the exec mocked: enough devices -> re-execution under `python -m torch.distributed.run --nproc-per-node N` with the original
+    arguments; too few -> exit 1 and a message, unless the gloo test hook lets the ranks share a device."""
+    import os
+    import sys
+    import types as _types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    calls = []
+    monkeypatch.setattr(bench.os, "execve", lambda exe, cmd, env: calls.append((exe, cmd, env)))
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    args = _types.SimpleNamespace(gpus=8)
+    monkeypatch.delenv("LWG_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    bench.self_launch(args)
+    exe, cmd, env = calls.pop()
+    assert exe == sys.executable and cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == [os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one GPU, eight ranks: refused
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(args)
+    assert e.value.code == 1 and not calls
+    err = capsys.readouterr().err
+    assert "refusing" in err and "--gpus 8" in err and "1 GPU(s)" in err
+    # ... unless the test hook lets the ranks share the visible device
+    monkeypatch.setenv("LWG_DIST_BACKEND", "gloo")
+    bench.self_launch(args)
+    assert calls and calls[0][1][calls[0][1].index("--nproc-per-node") + 1] == "8"
