@@ -66,7 +66,10 @@ def kernel_peak(name):
 
 BATCH = 8
 IMAGE_SIZE = 256
-TRAFFIC_FILE = "r05_traffic.json"
+TRAFFIC_FILE = "r06_traffic.json"
+# speed of the CPU port (oracle/) relative to the reference's own modules on the same cores, same inputs, bit-identical outputs:
+# tools/port_vs_reference.py, measured where /root/reference exists (profiles/r06_port_vs_reference.md)
+PORT_VS_REFERENCE = 0.90
 
 
 # sources of the kernels the timed step launches (the training and inpainting kernels are not among them)
@@ -102,6 +105,7 @@ def parse():
     p.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
                    help="conv arithmetic of the per-frame stream (default: the library default, bf16x3)")
     p.add_argument("--no-fp32-mode", action="store_true", help="skip the extra timed pass in exact-fp32 mode")
+    p.add_argument("--no-strict", action="store_true", help="skip the strict one-batch-per-launch-sequence windows")
     p.add_argument("--no-secondary", action="store_true",
                    help="skip the `secondary` block (appearance transfer = BASELINE config 4, training iteration = config 5)")
     p.add_argument("--lanes", type=int, default=None,
@@ -278,11 +282,8 @@ def cpu_baseline(seed=0, batches=2):
         kept = [one_batch(b) for b in range(1, batches + 1)]
         dt = time.perf_counter() - t0
     line = {"value": round(batches * BATCH / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d batches of %d frames (256x256) after warm-up, best of 16/32/64 intra-op threads on a box with %d "
-                      "logical cores, torch %s CPU fp32 + OpenMP C rasteriser" % (batches, BATCH, os.cpu_count(), torch.__version__),
-            "port_vs_reference": "calibration where /root/reference exists (8-core build container, 5 batches each): the "
-                                 "port runs at 0.90x the speed of the reference's own modules (median; per-batch spread "
-                                 "0.76-1.06x) with bit-identical outputs -- profiles/r02_port_vs_reference.md"}
+            "sample": "%d batches of %d frames 256x256 after warm-up; best of 16/32/64 threads, %d logical cores" % (batches, BATCH, os.cpu_count()),
+            "port_vs_reference": PORT_VS_REFERENCE, "torch": torch.__version__}
     return line, {"fim": torch.cat([k[0] for k in kept]), "pred": torch.cat([k[1] for k in kept]), "first_batch": 1, "src_fim": sfim}
 
 
@@ -319,20 +320,13 @@ def parity_block(imitator, src_img, bg_img, smpls, lanes, theta_chain):
     smpl_mode = imitator.hmr.smpl.precision
     chain_fim = int((~agree).sum()) + int((si["fim"].cpu() != theta_chain["src_fim"]).sum())
     chain_ok = (chain_fim == 0 and float(d_chain.max()) <= 1e-3) if smpl_mode == "compensated" else True
-    return {"ok": bool(linf <= 1e-3 and fim_mismatch == 0 and chain_ok),
-            "frames": int(pred.shape[0]), "linf": round(linf, 7), "fim_mismatch": fim_mismatch,
-            "T_linf": round(float((torch.cat(Ts) - fr["T"]).abs().max()), 9),
-            "bound": 1e-3, "oracle": "same_vertices: oracle/torch_ref.py + raster_ref.c restarted from the device's posed "
-                                     "vertices; pipeline = the timed one (%d lanes)" % lanes,
-            "theta_chain": {"ok": bool(chain_ok), "smpl_precision": smpl_mode, "fim_mismatch_pixels": chain_fim,
-                            "frames_with_identical_fim": int(frames_agree.sum()),
-                            "linf_on_those_frames": (round(float(d_chain[frames_agree].max()), 7)
-                                                     if bool(frames_agree.any()) else None),
-                            "linf_all": round(float(d_chain.max()), 7),
-                            "note": "oracle's own SMPL from the same theta in fp64, rounded (= the reference's SMPL.forward on float64 "
-                                    "tensors); device SMPL in its `compensated` mode (fp64 intermediates, one rounding): part of `ok`.  "
-                                    "Against ONE fp32 evaluation there is no 1e-3 answer: the reference's own SMPL moves the image by "
-                                    "1.2e-3..3e-3 with the thread count / frames per call (profiles/r04_theta_chain_reference_self.md)"}}
+    # flat numbers only (what every field means: DESIGN.md section 5.2).  `linf` / `fim_mismatch` / `T_linf`: oracle restarted from the
+    # device's posed vertices.  `theta_*`: the oracle's own SMPL from the same theta (fp64, rounded); `theta_linf_all` is over ALL
+    # pixels of ALL frames (no exclusions), `theta_fim_mismatch_pixels` counts face-index pixels that differ.
+    return {"ok": bool(linf <= 1e-3 and fim_mismatch == 0 and chain_ok), "bound": 1e-3, "frames": int(pred.shape[0]), "lanes": lanes,
+            "linf": round(linf, 7), "fim_mismatch": fim_mismatch, "T_linf": round(float((torch.cat(Ts) - fr["T"]).abs().max()), 9),
+            "theta_ok": bool(chain_ok), "theta_smpl_precision": smpl_mode, "theta_fim_mismatch_pixels": chain_fim,
+            "theta_frames_with_identical_fim": int(frames_agree.sum()), "theta_linf_all": round(float(d_chain.max()), 7)}
 
 
 def conv_roofline(generator, run, steps=1):
@@ -348,11 +342,9 @@ def conv_roofline(generator, run, steps=1):
     x3 = "bf16x3" in name
     peak = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
     ideal_ms = sum(v[2] / (kernel_peak(k) * 1e12) * 1e3 for k, v in table.items())
-    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "frac_pipe": round(achieved * (3.0 if x3 else 1.0) / peak, 4),
-            "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
-            "all_conv_kernels": {"achieved": round(flops / (ms * 1e-3) / 1e12, 3), "frac_pipe": round(ideal_ms / ms, 4),
-                                 "launches": n, "ms": round(ms / steps, 4)}}
+    return {"kernel": name, "achieved": round(achieved, 1), "peak": round(peak, 1), "frac": round(achieved / peak, 4),
+            "frac_pipe": round(achieved * (3.0 if x3 else 1.0) / peak, 4), "all_conv_frac_pipe": round(ideal_ms / ms, 4),
+            "all_conv_ms": round(ms / steps, 4)}
 
 
 def secondary_swap(dev, steps=30):
@@ -393,18 +385,15 @@ def secondary_swap(dev, steps=30):
     eight_ms = timed(eight, steps)
     roof = conv_roofline(sw.generator, lambda: [eight() for _ in range(4)], steps=4)
     sw.generator.release()
-    return {"workload": "Swapper.swap, two synthetic subjects, 256x256, swap_part='body' (BASELINE config 4)",
-            "one_pair": {"ms": round(one_ms, 4), "swaps_per_s": round(1e3 / one_ms, 2),
-                         "what": "the whole Swapper.swap call at batch 1 (masks, T11/T21, 2 image warps, generator.swap, blend)"},
-            "eight_pairs": {"ms": round(eight_ms, 4), "swaps_per_s": round(BATCH * 1e3 / eight_ms, 2),
-                            "what": "Swapper.forward on 8 prepared inputs: one launch sequence of the two-stream generator",
-                            "roofline": roof},
+    # one_pair: the whole Swapper.swap call at batch 1; eight_pairs: Swapper.forward on 8 prepared inputs as one launch sequence
+    return {"one_pair_ms": round(one_ms, 4), "swaps_per_s": round(1e3 / one_ms, 1), "eight_pairs_ms": round(eight_ms, 4),
+            "eight_pairs_swaps_per_s": round(BATCH * 1e3 / eight_ms, 1), "eight_pairs_roofline": roof,
             "dtype": "bf16x3" if sw.generator.precision != "fp32" else "f32"}
 
 
 def _stats(ms):
     v = sorted(ms)
-    return {"median": round(v[len(v) // 2], 4), "min": round(v[0], 4), "max": round(v[-1], 4), "calls": len(v)}
+    return {"median": round(v[len(v) // 2], 3), "min": round(v[0], 3), "max": round(v[-1], 3)}
 
 
 def secondary_latency(dev, frames=40):
@@ -413,8 +402,7 @@ def secondary_latency(dev, frames=40):
     lanes.  `eager`: the ~70 liblwg launches of a frame issued from Python; `graph`: the same launches captured once
     (Imitator.frame_graph) and replayed as one launch.  Both precisions; and one Swapper.swap (models/swapper.py:198-239) awaited."""
     from impersonator_amd.utils import synthetic
-    out = {"workload": "1 frame per call (batch 1), 256x256, device synchronised after every frame; ms per frame",
-           "reference_loop": "models/imitator.py:166-171"}
+    out = {}
     for precision in ("bf16x3", "fp32"):
         imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=1, seed=0, image_size=IMAGE_SIZE)
         imitator.generator.precision = precision
@@ -442,8 +430,8 @@ def secondary_latency(dev, frames=40):
         run = imitator.frame_graph(batch=1)
         g_ms, g_last = timed(lambda t: run(smpls[t:t + 1], t=t))
         out["f32" if precision == "fp32" else "bf16x3"] = {
-            "eager_ms": e_ms, "graph_ms": g_ms, "frames_per_s_graph": round(1e3 / g_ms["median"], 1),
-            "graph_equals_eager": bool(torch.equal(e_last, g_last))}
+            "eager_ms": e_ms["median"], "graph_ms": g_ms["median"], "graph_ms_min": g_ms["min"], "graph_ms_max": g_ms["max"],
+            "frames_per_s_graph": round(1e3 / g_ms["median"], 1), "graph_equals_eager": bool(torch.equal(e_last, g_last))}
         del run
         imitator.generator.release()
     sw, smpl_a, img_a, bg_a = demo.build_synthetic_imitator(batch_size=1, seed=0, image_size=IMAGE_SIZE, model="swapper")
@@ -457,7 +445,7 @@ def secondary_latency(dev, frames=40):
         torch.cuda.synchronize(dev)
         if i >= 4:
             ms.append((time.perf_counter() - t0) * 1e3)
-    out["swap_one_pair_ms"] = dict(_stats(ms), what="Swapper.swap at batch 1 awaited, eager launches (liblwg kernels only)")
+    out["swap_one_pair_ms"] = _stats(ms)["median"]
     run = sw.swap_graph(sw.src_info, sw.tsf_info, target_part="body")
     gms = []
     for i in range(4 + 20):
@@ -466,8 +454,8 @@ def secondary_latency(dev, frames=40):
         torch.cuda.synchronize(dev)
         if i >= 4:
             gms.append((time.perf_counter() - t0) * 1e3)
-    out["swap_one_pair_graph_ms"] = dict(_stats(gms), what="the same swap captured once (Swapper.swap_graph) and replayed as one HIP graph",
-                                         graph_equals_eager=bool(torch.equal(p, q)))
+    out["swap_one_pair_graph_ms"] = _stats(gms)["median"]
+    out["swap_graph_equals_eager"] = bool(torch.equal(p, q))
     del run
     sw.generator.release()
     return out
@@ -481,7 +469,7 @@ def secondary_personalize(dev, reps=5):
     from oracle import torch_ref
     from impersonator_amd.networks.inpaintor import InpaintSANet
     from impersonator_amd.utils import synthetic
-    out = {"workload": "Imitator.personalize of one 256x256 source (synthetic SMPL + random-init networks), awaited"}
+    out = {}
     for variant in ("ORIGINAL", "deepfillv2"):
         imitator, src_smpl, src_img, _ = demo.build_synthetic_imitator(batch_size=1, seed=0, image_size=IMAGE_SIZE)
         bg_sd = None
@@ -531,17 +519,15 @@ def secondary_personalize(dev, reps=5):
                 t0 = time.perf_counter()
                 torch_ref.inpaint_forward(bg_sd, img_t, body)
                 inp_cpu = (time.perf_counter() - t0) * 1e3
-            extra = {"inpaintor_forward": {"gpu_ms": _stats(fw), "cpu_oracle_ms": round(inp_cpu, 1), "precision": imitator.bgnet.precision,
-                                           "what": "35 gated convs (31 on the bf16x3 kernels), 4096-token self-attention on the fp32 "
-                                                   "matrix cores, mask compositing; wall time of the awaited call (31 + 37 launches)"}}
-        out[variant] = {"gpu_ms": _stats(ms), "cpu_oracle_ms": round(cpu_ms, 1), "cpu_threads": torch.get_num_threads(), **extra,
-                        "speedup": round(cpu_ms / _stats(ms)["median"], 1),
-                        "parity": {"fim_equal": bool(torch.equal(ref["fim"], si["fim"].cpu())), "bg_linf": round(bg_err, 7),
-                                   "src_feature_linf": round(feat_err, 7)}}
+            extra = {"inpaintor_forward_ms": _stats(fw)["median"], "inpaintor_cpu_oracle_ms": round(inp_cpu, 1),
+                     "inpaintor_precision": imitator.bgnet.precision}
+        out[variant] = {"gpu_ms": _stats(ms)["median"], "gpu_ms_min": _stats(ms)["min"], "cpu_oracle_ms": round(cpu_ms, 1),
+                        "cpu_threads": torch.get_num_threads(), **extra,
+                        "fim_equal": bool(torch.equal(ref["fim"], si["fim"].cpu())), "bg_linf": round(bg_err, 7),
+                        "src_feature_linf": round(feat_err, 7)}
         imitator.generator.release()
         if variant == "deepfillv2":
             imitator.bgnet.release() if hasattr(imitator.bgnet, "release") else None
-    out["kernel_table"] = "profiles/r05_personalize_kernel_stats.md (rocprofv3 --kernel-trace --stats -- python tools/personalize_once.py)"
     return out
 
 
@@ -552,17 +538,15 @@ def secondary_train(steps=3):
     import bench_train
     out = {}
     for name, (n, s) in (("512x512_batch1", (1, 512)), ("256x256_batch4", (4, 256)), ("512x512_batch4", (4, 512))):
-        out[name] = {}
         # eager: ~1500 launches per iteration from Python; graph: Impersonator.optimize_parameters_graphed, the same iteration
-        # captured once and replayed (what a training loop on one GPU would call)
-        for mode in ("eager", "graph"):
-            r = bench_train.measure(n, s, steps=steps, warmup=2, precision="bf16x3", graph=mode == "graph")
-            out[name][mode] = {"ms_per_iteration": r["ms_per_iteration"], "images_per_s": r["images_per_s"], "conv_tflops": r["conv_tflops"],
-                               "roofline": r["roofline"]}
-            torch.cuda.empty_cache()
-        out[name]["conv_gflop_per_iteration"] = r["conv_gflop_per_iteration"]
-    out["what"] = ("G update (three streams forward, losses adv + L1 + mask, hand-written backward, Adam) + D update; "
-                   "bf16x3 convolutions of generator and discriminator, fp32 elsewhere; 1 GPU, no all-reduce")
+        # captured once and replayed (what a training loop on one GPU would call).  frac = algorithmic conv FLOP of the WHOLE
+        # iteration / its time, against the bf16x3 ceiling 2500 / 3 TFLOP/s
+        e = bench_train.measure(n, s, steps=steps, warmup=2, precision="bf16x3", graph=False)
+        torch.cuda.empty_cache()
+        g = bench_train.measure(n, s, steps=steps, warmup=2, precision="bf16x3", graph=True)
+        torch.cuda.empty_cache()
+        out[name] = {"eager_ms": e["ms_per_iteration"], "graph_ms": g["ms_per_iteration"], "images_per_s": g["images_per_s"],
+                     "conv_tflops": g["conv_tflops"], "frac": g["roofline"]["frac"], "conv_gflop": g["conv_gflop_per_iteration"]}
     return out
 
 
@@ -694,28 +678,17 @@ def main():
         x3 = "bf16x3" in name
         peak = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
         ideal_ms = sum(v[2] / (kernel_peak(k) * 1e12) * 1e3 for k, v in table.items())
+        # flat numbers (definitions: DESIGN.md section 5.1).  achieved = ALGORITHMIC flops / launch time of the dominant kernel;
+        # frac = achieved / dense peak of the MFMA instruction used; frac_pipe = executed products / peak (bf16x3: 3 per multiply-add)
         block = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": round(peak, 1),
                  "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                 "frac_algorithmic": round(achieved / peak, 4),
                  "frac_pipe": round(achieved * (3.0 if x3 else 1.0) / peak, 4),
-                 "executed_tflops": round(achieved * (3.0 if x3 else 1.0), 2),
                  "traffic": None, "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
-                 "flop_per_launch": kfl / max(kn, 1),
-                 "measured": "HIP events around each launch, steps re-run on one lane (kernels not overlapped).  An event pair spans "
-                             "the launch's dispatch latency too (~10 us on a dependent chain): rocprofv3's kernel durations "
-                             "(profiles/r05_kernel_stats.md) are that much shorter, the fractions here that much lower",
-                 "frac_note": ("achieved = ALGORITHMIC flops (2*M*Cout*taps*Cin, real taps and channels) / launch time; "
-                               "frac = frac_algorithmic = achieved / peak of the MFMA instruction used (bf16 dense 2500, "
-                               "fp32 157.3).  A bf16x3 kernel executes 3 bf16 MFMA products per algorithmic multiply-add: "
-                               "frac_pipe = 3 * achieved / 2500 is the matrix-pipe utilisation (what the PMC pass in "
-                               "profiles/ measures as MFMA busy)"),
-                 "all_conv_kernels": {"achieved": round(flops / (ms * 1e-3) / 1e12, 3),
-                                      "frac_pipe": round(ideal_ms / ms, 4),
-                                      "launches": n, "ms_per_step": round(ms / args.steps, 4),
-                                      "by_kernel": {k: {"launches": v[0], "avg_launch_ms": round(v[1] / v[0], 5),
-                                                        "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2),
-                                                        "frac_pipe": round(v[2] / (v[1] * 1e-3) / 1e12 / kernel_peak(k), 4)}
-                                                    for k, v in table.items()}}}
+                 "flop_per_launch": round(kfl / max(kn, 1)), "timer": "HIP events on the launch stream, one lane",
+                 "all_conv_tflops": round(flops / (ms * 1e-3) / 1e12, 2), "all_conv_frac_pipe": round(ideal_ms / ms, 4),
+                 "all_conv_launches": n, "all_conv_ms_per_step": round(ms / args.steps, 4),
+                 "by_kernel": {k: [v[0], round(v[1] / v[0] * 1e3, 1), round(v[2] / (v[1] * 1e-3) / 1e12 / kernel_peak(k), 3)]
+                               for k, v in table.items()}}   # kernel -> [launches, avg us, pipe fraction]
         # bytes per launch of the dominant kernel from the committed PMC passes of the same command
         # (tools/r05_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md
         # prescribes); bench.py cannot collect counters itself.  The file carries the digest of the kernel sources it
@@ -734,59 +707,79 @@ def main():
                 t = {"fetch_bytes_per_launch": sum(v["launches"] * v["fetch_bytes_per_launch"] for v in rows) / nl,
                      "write_bytes_per_launch": sum(v["launches"] * v["write_bytes_per_launch"] for v in rows) / nl}
             if stamp.get("csrc_sha256") != csrc_digest():
-                block["traffic_note"] = ("profiles/%s was measured on other kernel sources (stamp %s..., now %s...): "
-                                         "not attached" % (TRAFFIC_FILE, str(stamp.get("csrc_sha256"))[:10], csrc_digest()[:10]))
-            elif t and "fetch_bytes_per_launch" in t and "write_bytes_per_launch" in t:
+                block["traffic_note"] = "profiles/%s is stamped with other kernel sources: not attached" % TRAFFIC_FILE
+            elif t:
                 block["traffic"] = round(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
-                block["traffic_note"] = ("fabric-side bytes per launch (profiles/%s, commit %s): %.0f MB read + %.0f MB "
-                                         "written; Infinity-Cache hits included" % (TRAFFIC_FILE, stamp.get("commit", "?"),
-                                                          t["fetch_bytes_per_launch"] / 1e6, t["write_bytes_per_launch"] / 1e6))
+                block["traffic_read"] = round(t["fetch_bytes_per_launch"])
+                block["traffic_written"] = round(t["write_bytes_per_launch"])
+                block["traffic_note"] = "fabric-side bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/%s" % TRAFFIC_FILE
         return block
 
     roofline = roofline_pass() if not args.no_roofline else None
     # what carried the barrier / max-over-ranks above (every rank takes part in its one-element all-reduce)
     rccl = sharding.collective_info(dev) if torch.distributed.is_initialized() else None
 
+    def median_window(n_windows):
+        w = sorted(timed_window(args.warmup + r * args.steps)[0] for r in range(n_windows))
+        return w[len(w) // 2], w
+
     fp32_mode = None
     if precision != "fp32" and not args.no_fp32_mode:
-        # the same steps with the convolutions on the exact-fp32 MFMA path, for the record
+        # the same steps with the convolutions on the exact-fp32 MFMA path: the reference's own arithmetic (like for like)
         imitator.generator.precision = "fp32"
         run_steps(0, args.warmup)
-        w32 = sorted(timed_window(args.warmup + r * args.steps)[0] for r in range(max(1, min(3, args.repeats))))
-        dt32 = w32[len(w32) // 2]
+        dt32, w32 = median_window(max(1, min(3, args.repeats)))
         fp32_mode = {"value": round(world * BATCH * args.steps / dt32, 3), "unit": "frames/s",
                      "ms_per_step": round(dt32 / args.steps * 1e3, 4), "repeats": len(w32),
                      "ms_per_step_min": round(w32[0] / args.steps * 1e3, 4), "ms_per_step_max": round(w32[-1] / args.steps * 1e3, 4),
-                     "dtype": "f32",
-                     "note": "same workload, precision='fp32' (v_mfma_f32_32x32x2_f32, bit-exact fmaf chains)"}
+                     "dtype": "f32"}
         if not args.no_roofline:
             fp32_mode["roofline"] = roofline_pass()
         imitator.generator.precision = precision
 
+    # the reference's call pattern strictly: ONE batch of 8 per generator launch sequence (models/imitator.py:166-171 runs one
+    # forward per batch) -- with the two lanes, and on a single stream
+    strict = {}
+    if not args.no_strict:
+        keep = os.environ.get("LWG_FUSE")
+        os.environ["LWG_FUSE"] = "1"
+        try:
+            for key, nl in (("strict_batch8_fps", lanes), ("strict_batch8_one_lane_fps", 1)):
+                run_steps(0, args.warmup, lanes=nl)
+                w = []
+                for r in range(max(1, min(3, args.repeats))):
+                    sharding.barrier(dev)
+                    t0 = time.perf_counter()
+                    run_steps(args.warmup + r * args.steps, args.steps, lanes=nl)
+                    torch.cuda.synchronize(dev)
+                    sharding.barrier(dev)
+                    w.append(sharding.max_over_ranks(time.perf_counter() - t0, rdev))
+                strict[key] = round(world * BATCH * args.steps / sorted(w)[len(w) // 2], 1)
+        finally:
+            if keep is None:
+                os.environ.pop("LWG_FUSE", None)
+            else:
+                os.environ["LWG_FUSE"] = keep
+
     if rank == 0:
         frames = world * BATCH * args.steps
+        fuse = int(os.environ.get("LWG_FUSE", imitator.fuse))
         line = {
             "metric": "frames/sec (256x256 motion-imitation, batch=8)",
             "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if precision == "fp32" else "bf16x3", "data": "synthetic",
+            "config": {"workload": "Imitator inference 256x256 batch=8, random-init ImpersonatorGenerator + synthetic SMPL, 1 source",
+                       "gflop_per_frame": 105.58, "frames": args.frames, "batch_per_gpu": BATCH, "image_size": IMAGE_SIZE,
+                       "parallelism": "frame-sharded replicas x%d" % world, "grid_sample_align_corners": False,
+                       "lanes": lanes, "batches_per_launch_sequence": fuse, "frames_per_launch": fuse * BATCH,
+                       "precision": precision, **strict},
             "repeats": len(windows), "ms_per_step_min": round(min(windows) / args.steps * 1e3, 4),
             "ms_per_step_max": round(max(windows) / args.steps * 1e3, 4),
             "ms_per_step_windows": [round(w / args.steps * 1e3, 4) for w in windows],
-            "timing": "median of %d windows of %d steps, each bracketed by barrier + device synchronisation, MAX over ranks" % (len(windows), args.steps),
             "gpu_clocks": sampler.summary(),
-            "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if precision == "fp32" else "bf16x3", "data": "synthetic",
-            "config": {"workload": "Imitator inference 256x256 batch=8, random-init ImpersonatorGenerator (tsf ResUnet, "
-                                   "105.58 GFLOP/frame) + synthetic SMPL (6890 verts / 13776 faces), 1 source, "
-                                   "%d-frame synthetic reference sequence" % args.frames,
-                       "batch_per_gpu": BATCH, "image_size": IMAGE_SIZE, "parallelism": "frame-sharded replicas x%d" % world,
-                       "grid_sample_align_corners": False,
-                       "streams": "%d generator lane(s) + 1 geometry stream per GPU; %s consecutive batches of %d per generator "
-                                  "launch sequence (frames of one source are independent: bit-identical to one batch at a time)"
-                                  % (lanes, os.environ.get("LWG_FUSE", str(imitator.fuse)), BATCH),
-                       "precision": precision + (" (fp32 operands carried as 2 bf16 terms, 3 MFMA products, fp32 "
-                                                 "accumulate; 8e-5 L-inf on the image vs fp32, bound 1e-3)"
-                                                 if precision == "bf16x3" else " (exact fp32 MFMA)")},
+            "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4),
         }
         if rccl is not None:
             # N > 1 (or LWG_FORCE_DIST=1 at N = 1): the process group behind the timing barrier -- backend 'nccl' IS RCCL on
@@ -799,18 +792,36 @@ def main():
             line["ranks"] = ranks_block   # (distinct_devices is reported, not enforced: device identifiers are the runtime's to define)
         if fp32_mode is not None:
             line["exact_fp32_mode"] = fp32_mode
-        if roofline is not None:
-            line["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], kept = cpu_baseline()
             # self-check of the timed pipeline against the oracle, after and outside the timed region
             line["parity"] = parity_block(imitator, src_img, bg_img, smpls, lanes, kept)
             if not line["parity"]["ok"]:
                 line["invalid"] = "the timed pipeline's output failed the parity check against the oracle (see `parity`)"
+        if roofline is not None:
+            # the like-for-like (exact fp32) result and the parity numbers as flat fields of `roofline`, next to the bf16x3 figures
+            if fp32_mode is not None:
+                r32 = fp32_mode.get("roofline") or {}
+                roofline.update({"exact_fp32_fps": fp32_mode["value"], "exact_fp32_ms_per_step": fp32_mode["ms_per_step"],
+                                 "exact_fp32_frac": r32.get("frac"), "exact_fp32_all_conv_frac": r32.get("all_conv_frac_pipe")})
+            if "parity" in line:
+                pb = line["parity"]
+                roofline.update({"parity_ok": pb["ok"], "parity_linf": pb["linf"], "fim_mismatch": pb["fim_mismatch"],
+                                 "theta_chain_linf_all": pb["theta_linf_all"],
+                                 "theta_chain_fim_mismatch_pixels": pb["theta_fim_mismatch_pixels"]})
+            line["roofline"] = roofline
         if world == 1 and not args.no_secondary:
-            # other workloads of BASELINE.json, measured after (and outside) the timed region
+            # other workloads of BASELINE.json, measured after (and outside) the timed region (field definitions: DESIGN.md 5.3)
             line["secondary"] = {"swap": secondary_swap(dev), "latency": secondary_latency(dev),
                                  "personalize": secondary_personalize(dev), "train": secondary_train()}
+        # the numbers a truncated record must still show, once more at the very end of the line
+        line["summary"] = {"fps": line["value"], "ms_per_step": line["ms_per_step"], "dtype": line["dtype"],
+                           "exact_fp32_fps": fp32_mode["value"] if fp32_mode else None,
+                           "frac": roofline["frac"] if roofline else None, "frac_pipe": roofline["frac_pipe"] if roofline else None,
+                           "all_conv_frac_pipe": roofline["all_conv_frac_pipe"] if roofline else None,
+                           "parity_linf": line.get("parity", {}).get("linf"), "fim_mismatch": line.get("parity", {}).get("fim_mismatch"),
+                           "theta_chain_linf_all": line.get("parity", {}).get("theta_linf_all"),
+                           "cpu_fps": line.get("cpu_baseline", {}).get("value"), **strict}
         print(json.dumps(line))
         if line.get("invalid"):
             sys.exit(1)

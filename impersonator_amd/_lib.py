@@ -40,6 +40,7 @@ _PROTOS = {
                                 _vp, _vp, _vp, _vp, _sz, _vp]),
     "lwg_smpl_swap": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lwg_smpl_project_joints": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "lwg_rotate_translate": (_i, [_vp, _c.c_long, _vp, _vp, _vp, _vp]),
     "lwg_smpl_workspace_bytes": (_sz, [_i]),
     "lwg_smpl_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lwg_smpl_forward_f64": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -270,6 +270,18 @@ __global__ void smpl_j2d_kernel(const float *__restrict__ j3d, const float *__re
     j2d[i] = cam[f * 3] * (j3d[((size_t)f * nj + j) * 3 + c] + cam[f * 3 + 1 + c]);
 }
 
+// Viewer.rotate_trans (models/viewer.py:240-247): out = X @ R + t for every vertex, R row-major (3,3).  The rotation and the
+// translation travel as kernel arguments (a dozen floats: no upload, nothing for a graph replay to re-read from the host).
+struct RigidArgs { float R[9]; float t[3]; };
+__global__ void rotate_translate_kernel(const float *__restrict__ x, long n, RigidArgs a, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[3 * i + j] = fmaf(x2, a.R[6 + j], fmaf(x1, a.R[3 + j], x0 * a.R[j])) + a.t[j];
+}
+
 }  // namespace
 }  // namespace lwg
 
@@ -297,6 +309,17 @@ int lwg_smpl_project_joints(const float *j3d, const float *cam, int bs, int num_
     LWG_REQUIRE(j3d && cam && j2d && bs > 0 && num_joints > 0, "smpl_project_joints: bad arguments");
     smpl_j2d_kernel<<<ceil_div((long)bs * num_joints * 2, 256), 256, 0, as_stream(stream)>>>(j3d, cam, bs, num_joints, j2d);
     LWG_LAUNCH_CHECK("smpl_j2d_kernel");
+    return LWG_OK;
+}
+
+int lwg_rotate_translate(const float *x, long n, const float *R9, const float *t3, float *out, lwg_stream_t stream)
+{
+    LWG_REQUIRE(x && R9 && t3 && out && n > 0, "rotate_translate: bad arguments");
+    RigidArgs a;
+    for (int i = 0; i < 9; ++i) a.R[i] = R9[i];
+    for (int i = 0; i < 3; ++i) a.t[i] = t3[i];
+    rotate_translate_kernel<<<ceil_div(n, 256), 256, 0, as_stream(stream)>>>(x, n, a, out);
+    LWG_LAUNCH_CHECK("rotate_translate_kernel");
     return LWG_OK;
 }
 

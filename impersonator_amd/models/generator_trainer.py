@@ -240,11 +240,13 @@ class GeneratorTrainer(object):
         if self._buckets is not None:
             self._buckets.checkpoint()
 
-    def _begin_buckets(self):
+    def _begin_buckets(self, all_reduce=True):
         """Data-parallel job: the gradient all-reduce runs bucket by bucket on a side stream while the backward pass goes on
-        (env LWG_GRAD_BUCKETS=0: one blocking all-reduce of the whole buffer after it; LWG_BUCKET_MB: bucket size, default 64)."""
+        (env LWG_GRAD_BUCKETS=0: one blocking all-reduce of the whole buffer after it; LWG_BUCKET_MB: bucket size, default 64).
+        `all_reduce=False` (a caller that wants this rank's raw gradients): no bucket is ever launched in this pass."""
         import os
-        if sharding.collectives_active() and os.environ.get("LWG_GRAD_BUCKETS", "1") != "0":
+        self._join_buckets()      # a previous pass whose step() was never called: its reductions are over before flat_g is rewritten
+        if all_reduce and sharding.collectives_active() and os.environ.get("LWG_GRAD_BUCKETS", "1") != "0":
             mb = os.environ.get("LWG_BUCKET_MB", "64")
             if self._buckets is None or self._bucket_mb != mb:
                 self._bucket_mb = mb
@@ -253,6 +255,12 @@ class GeneratorTrainer(object):
             self._buckets.begin()
         else:
             self._buckets = None
+
+    def _join_buckets(self):
+        """Every bucket of the current pass averaged, and the compute stream behind the side stream: whoever reads `flat_g` next
+        (Adam, gradients(), a new backward pass) sees either all of it averaged or -- without buckets -- none of it."""
+        if self._buckets is not None and not self._buckets.joined:
+            self._buckets.finish()
 
     # ------------------------------------------------------------------ parameters
     def state_dict(self):
@@ -264,6 +272,7 @@ class GeneratorTrainer(object):
         return out
 
     def gradients(self):
+        self._join_buckets()
         out = {}
         for key, _, parts in self.spec:
             for sk, rows, cin in parts:
@@ -317,11 +326,13 @@ class GeneratorTrainer(object):
 
     # ------------------------------------------------------------------ losses + backward (:368-394, :355-356)
     @torch.no_grad()
-    def backward(self):
+    def backward(self, all_reduce=True):
+        """`all_reduce` is decided HERE, before the first gradient is written: in a data-parallel job the buckets go on the wire
+        underneath this pass (sharding.GradientBuckets).  backward(all_reduce=False) leaves this rank's own gradients in flat_g."""
         b, lam = self.b, self.lam
+        self._begin_buckets(all_reduce)
         self.flat_g.zero_()
         self._untouched = set(self.G)
-        self._begin_buckets()
         to_nhwc = lambda t: t.permute(0, 2, 3, 1)
         src_img, src_mask, tsf_img, tsf_mask = self.src.img, self.src.mask, self.tsf.img, self.tsf.mask
         n = src_img.shape[0]
@@ -418,8 +429,14 @@ class GeneratorTrainer(object):
 
     @torch.no_grad()
     def step(self, all_reduce=True):
-        if all_reduce and self._buckets is not None:
-            self._buckets.finish()          # most buckets were averaged underneath the backward pass; wait for the rest
+        """Adam on the flat buffers.  With buckets (backward(all_reduce=True) in a data-parallel job) the averaging already ran
+        underneath the backward pass and is joined here whatever `all_reduce` says -- half-averaged gradients are never stepped
+        on; without them `all_reduce` selects one blocking all-reduce of the whole buffer."""
+        if self._buckets is not None:
+            if not all_reduce and not self._buckets.joined:
+                raise RuntimeError("step(all_reduce=False) after backward(all_reduce=True): the buckets of this pass are already "
+                                   "on the wire; decide in backward(all_reduce=False)")
+            self._join_buckets()            # most buckets were averaged underneath the backward pass; wait for the rest
         elif all_reduce:
             sharding.average_gradients(self.flat_g)
         self.t += 1
@@ -440,6 +457,6 @@ class GeneratorTrainer(object):
     def optimize_G(self, batch):
         """forward + losses + backward + Adam: the generator half of optimize_parameters (impersonator_trainer.py:350-357)."""
         fake = self.forward(batch)
-        terms = self.backward()
-        self.step()
+        terms = self.backward(all_reduce=True)
+        self.step(all_reduce=True)
         return terms, fake

@@ -15,10 +15,19 @@ class Viewer(Imitator):
         self.T = None
 
     def rotate_trans(self, rt, t, X):
-        """viewer.py:240-247: X @ R + t with R = euler2matrix(rt)."""
-        R = torch.as_tensor(cv_utils.euler2matrix(rt), dtype=torch.float32, device=X.device)[None]
-        t = torch.as_tensor(t, dtype=torch.float32, device=X.device)[None, None, :]
-        return torch.bmm(X, R.expand(X.shape[0], -1, -1)) + t
+        """viewer.py:240-247: X @ R + t with R = euler2matrix(rt) -- one liblwg launch (lwg_rotate_translate): the rotation and
+        the translation are twelve host floats handed to the kernel by value."""
+        import numpy as np
+        from .. import _lib
+        if not X.is_cuda:
+            raise RuntimeError("Viewer.rotate_trans: the mesh must be a CUDA tensor (no CPU path)")
+        R = np.ascontiguousarray(np.asarray(cv_utils.euler2matrix(rt), dtype=np.float32).reshape(3, 3))
+        tv = np.ascontiguousarray(np.asarray(t, dtype=np.float32).reshape(3))
+        x = X.float().contiguous()
+        out = torch.empty_like(x)
+        _lib.check(_lib.load().lwg_rotate_translate(_lib.ptr(x), x.numel() // 3, R.ctypes.data, tv.ctypes.data, _lib.ptr(out),
+                                                    _lib.stream_ptr()))
+        return out
 
     @torch.no_grad()
     def view(self, rt, t, visualizer=None, name='1'):

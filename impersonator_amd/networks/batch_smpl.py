@@ -257,12 +257,11 @@ class HumanModelRecovery(nn.Module):
         if theta.is_cuda:
             # the slicing and the keypoint projection as liblwg launches too (same values as the tensor expressions below)
             return self.get_details_swapped(theta, None, None, None, 'as_is')
+        # CPU tensors: the tensor-op statement of the same function (SMPL.forward_ops) -- what the CPU tests of the host logic and
+        # tests/test_oracle_vs_reference.py pin to the reference; the product path (CUDA tensors) returned above
         cam = theta[:, 0:3].contiguous()
         pose = theta[:, 3:75].contiguous()
         shape = theta[:, 75:].contiguous()
-        if theta.is_cuda:
-            verts, j3d, _ = self.smpl.forward_theta(theta)
-        else:
-            verts, j3d, _ = self.smpl(beta=shape, theta=pose, get_skin=True)
+        verts, j3d, _ = self.smpl(beta=shape, theta=pose, get_skin=True)
         return {'theta': theta, 'cam': cam, 'pose': pose, 'shape': shape, 'verts': verts,
                 'j2d': batch_orth_proj_idrot(j3d, cam), 'j3d': j3d}

@@ -208,6 +208,7 @@ class GradientBuckets(object):
         self.left = [len(b[2]) for b in self.buckets]
         self.ready, self.done = [], [False] * len(self.buckets)
         self.launched_log = []
+        self.joined = False        # finish() ran for this pass: every bucket averaged, the compute stream waits for the side stream
 
     def written(self, key):
         i = self.of_key[key]
@@ -242,6 +243,7 @@ class GradientBuckets(object):
                 self._launch(i)
         if self.stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        self.joined = True
 
 
 def collective_info(device=None):

@@ -122,6 +122,9 @@ LWG_API int lwg_smpl_swap(const float *tgt_smpl, int bs, int num_betas, int stra
                           const float *src_shape, const float *first_cam, float *theta, float *cam, float *pose, float *shape,
                           lwg_stream_t stream);
 LWG_API int lwg_smpl_project_joints(const float *j3d, const float *cam, int bs, int num_joints, float *j2d, lwg_stream_t stream);
+/* Viewer.rotate_trans (models/viewer.py:240-247), `torch.bmm(X, R) + t` of the novel-view path: out (n,3) = x (n,3) @ R + t.
+ * R9 (row-major 3x3) and t3 are HOST pointers (twelve floats, passed to the kernel by value); x / out device pointers. */
+LWG_API int lwg_rotate_translate(const float *x, long n, const float *R9, const float *t3, float *out, lwg_stream_t stream);
 LWG_API size_t lwg_smpl_workspace_bytes(int bs);
 LWG_API int lwg_smpl_forward(const float *theta, int bs, int num_betas, int nv, int num_out_joints,
                              const float *v_template, const float *shapedirs, const float *posedirs,

@@ -13,7 +13,8 @@ Two passes per variant:
     (the reference's fp32 SMPL.forward on 8 CPU threads, one frame per call).  The images are compared on the frames whose
     face-index maps agree, with the bounds the reference sets itself: its own SMPL run with another thread count or batch size
     moves T by 5e-4 and the image by 2.7e-3 and flips up to 2 face-index pixels (profiles/r04_theta_chain_reference_self.md);
-    the bounds here are twice that.  (Against the correctly rounded SMPL the default `compensated` device mode has no such
+    the bounds here are twice what the DEVICE shows against the golden (<= 1 flipped pixel, T 4.9e-4, image 6.4e-4), and the all-pixel
+    figure with nothing excluded is printed beside them.  (Against the correctly rounded SMPL the default `compensated` device mode has no such
     slack: tests/test_gpu_bench_config.py::test_theta_to_image_chain_with_the_oracles_own_smpl.)"""
 import numpy as np
 import pytest
@@ -145,8 +146,16 @@ def test_imitator_methods_match_the_reference_golden(name):
     src_diff = int((imitator.src_info["fim"].cpu().numpy() != g[k + "src_fim"]).sum())
     same = [i for i in range(4) if diff[i] == 0] if src_diff == 0 else []
     eT, eP = _compare_images(v, g, k, info["T"].numpy(), preds, same)
-    print("%s device SMPL: face-index pixels differing per frame %s (source %d); on the %d identical frames T %.2g, image %.3g"
-          % (name, diff.tolist(), src_diff, len(same), eT, eP))
-    assert diff.max() <= 2 and src_diff <= 2
-    assert eT <= 1.3e-3 and eP <= 6e-3, (eT, eP)
+    # ... and over ALL pixels of ALL frames, excluding nothing (reported: a flipped face-index pixel is another face's flow at that
+    # pixel, so where one flips the all-pixel figure is whatever the two faces' colours differ by -- there is no bound to assert)
+    eT_all, eP_all = _compare_images(v, g, k, info["T"].numpy(), preds, range(4))
+    print("%s device SMPL: face-index pixels differing per frame %s (source %d); on the %d identical frames T %.2g, image %.3g; "
+          "all pixels of all 4 frames, none excluded: T %.3g, image %.3g"
+          % (name, diff.tolist(), src_diff, len(same), eT, eP, eT_all, eP_all))
+    # observed on MI355X (profiles/r04_theta_chain_gpu_tests.log, unchanged since): at most ONE flipped pixel in one frame, T <= 4.9e-4,
+    # image <= 6.4e-4 -- asserted at twice that (the reference against itself, 1 thread vs 8: 5e-4 / 2.7e-3 / 2 pixels)
+    assert diff.max() <= 1 and src_diff == 0, (diff.tolist(), src_diff)
+    assert eT <= 1e-3 and eP <= 1.5e-3, (eT, eP)
+    if diff.max() == 0:
+        assert eT_all == eT and eP_all == eP
     imitator.generator.release()

@@ -76,7 +76,7 @@ def test_bench_two_ranks_bare_command_starts_its_own_ranks():
     """`python bench.py --gpus 2` WITHOUT torchrun (the way the driver starts --gpus 1): bench.py re-executes itself under
     torch.distributed.run with two ranks (gloo hook: they share the one GPU) and the line says n_gpus 2 -- never a silent n_gpus 1."""
     p = _bare(["bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline", "--no-fp32-mode",
-               "--no-secondary"], {"LWG_DIST_BACKEND": "gloo"})
+               "--no-secondary", "--no-strict"], {"LWG_DIST_BACKEND": "gloo"})
     assert p.returncode == 0, "bare bench.py --gpus 2 failed (%d)\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines          # rank 0 only
@@ -100,7 +100,7 @@ def test_bench_refuses_more_ranks_than_gpus():
 
 def test_bench_two_ranks_under_torchrun():
     lines = _torchrun(["bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline",
-                       "--no-fp32-mode", "--no-secondary"])
+                       "--no-fp32-mode", "--no-secondary", "--no-strict"])
     assert len(lines) == 1, lines          # rank 0 only
     _check_two_rank_line(json.loads(lines[0]))
 
