@@ -4,7 +4,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_C", "liblwg.so")
+# LWG_LIB=exp: the measurement build (python -m impersonator_amd.build --experiments; knock-out switches, tools/ only)
+LIB_PATH = os.path.join(_HERE, "_C", "liblwg_exp.so" if os.environ.get("LWG_LIB") == "exp" else "liblwg.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lwg.h")
 
 LWG_OK = 0
@@ -137,7 +138,7 @@ def load():
     # (loading liblwg first binds a second runtime that sees no device context: "no ROCm-capable device").
     import torch  # noqa: F401
     # a library older than the kernel sources next to it must not run silently (the build stamps what it compiled)
-    stamp = os.path.join(_HERE, "_C", "liblwg.sha256")
+    stamp = os.path.join(_HERE, "_C", "liblwg_exp.sha256" if os.environ.get("LWG_LIB") == "exp" else "liblwg.sha256")
     if os.path.isdir(os.path.join(_HERE, "csrc")) and os.path.exists(stamp) and not os.environ.get("LWG_ALLOW_STALE_LIB"):
         from . import build as _build
         if open(stamp).read().strip() != _build._digest():

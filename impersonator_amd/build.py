@@ -57,18 +57,21 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, experiments=False):
+    """experiments=True: the measurement build (-DLWG_EXPERIMENTS: knock-out switches and ablation variants, WRONG RESULTS on
+    request) as _C/liblwg_exp.so, loaded instead of liblwg.so only when LWG_LIB=exp is set; the product library is untouched."""
     os.makedirs(OUT_DIR, exist_ok=True)
-    stamp = os.path.join(OUT_DIR, "liblwg.sha256")
+    lib = os.path.join(OUT_DIR, "liblwg_exp.so") if experiments else LIB
+    stamp = os.path.join(OUT_DIR, "liblwg_exp.sha256" if experiments else "liblwg.sha256")
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
-        return LIB
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return lib
     hipcc = _hipcc()
     objs = []
     procs = []
     for src, extra in SOURCES:
-        obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(OUT_DIR, src.replace(".hip", ".exp.o" if experiments else ".o"))
+        cmd = [hipcc] + COMMON + extra + (["-DLWG_EXPERIMENTS"] if experiments else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -79,12 +82,12 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
     subprocess.check_call(cmd)
     with open(stamp, "w") as fh:
         fh.write(dig + "\n")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

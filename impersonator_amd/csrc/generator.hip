@@ -326,6 +326,23 @@ int missing_in(const StreamNet &s, bool with_decoder)
     return m;
 }
 
+// Knock-out switches for timing experiments (builds with -DLWG_EXPERIMENTS only: `python -m impersonator_amd.build --experiments`
+// writes _C/liblwg_exp.so; never in the shipped library).  LWG_KO = bit mask of launches to SKIP from the third pass of a handle on
+// (buffers keep the previous pass's values, so the arithmetic downstream stays representative; RESULTS ARE WRONG): what a launch
+// costs inside the two-lane pipeline = the bound on what optimising it can return.
+//   1 in_finalize, 2 stem apply, 4 encoder 1-3 applies, 8 trunk applies, 16 heads, 32 stem conv, 64 skipper.2, 128 convT.2,
+//   256 all other applies
+#ifdef LWG_EXPERIMENTS
+static int g_ko_passes = 0;
+static bool ko(int bit)
+{
+    static const int mask = getenv("LWG_KO") ? atoi(getenv("LWG_KO")) : 0;
+    return (mask & bit) && g_ko_passes >= 6;
+}
+#else
+static constexpr bool ko(int) { return false; }
+#endif
+
 // ---- profiling helpers
 int prof_begin(lwg_generator *g, hipStream_t st, hipEvent_t *e1)
 {
@@ -468,7 +485,7 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
         g->prof_launches[variant] += 1;
         g->ev_variant.push_back(variant);
     }
-    if (L.has_norm) {
+    if (L.has_norm && !ko(1)) {
         rc = launch_in_finalize(g->partials, L.nphase, a.mtiles, N, L.cout, L.gamma, L.beta, kInEps, g->ss, st);
         if (rc != LWG_OK) return rc;
     }
@@ -525,9 +542,10 @@ int run_encoder(lwg_generator *g, const StreamNet &s, int lvl, const float *x, i
 {
     const Layer &L = s.enc[lvl];
     const int Hin = lvl == 0 ? g->is : g->is >> (lvl - 1);
-    int rc = run_conv(g, L, x, ldx, N, Hin, Hin, g->raw, st);
+    int rc = (lvl == 0 && &s == &g->tsf && ko(32)) ? LWG_OK : run_conv(g, L, x, ldx, N, Hin, Hin, g->raw, st);
     if (rc != LWG_OK) return rc;
     const int Ho = g->is >> lvl;
+    if (&s == &g->tsf && ko(lvl == 0 ? 2 : 4)) return LWG_OK;
     return run_apply(g, N, Ho, Ho, L.cout, true, dst, ld_dst, nullptr, 0, warps, nwarp, align, st);
 }
 
@@ -546,6 +564,7 @@ int run_resblock(lwg_generator *g, const StreamNet &s, int i, const float *xin, 
         if ((rc = run_apply(g, N, h, h, C, true, g->trunk[2], C, nullptr, 0, nullptr, 0, align, st)) != LWG_OK) return rc;
         if ((rc = run_conv(g, s.res[2 * i + 1], g->trunk[2], C, N, h, h, g->raw, st)) != LWG_OK) return rc;
     }
+    if (&s == &g->tsf && ko(8)) return LWG_OK;
     return run_apply(g, N, h, h, C, false, xout, C, xin, C, warps, nwarp, align, st);
 }
 
@@ -613,7 +632,8 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
         // loads its halo (ConvArgs::raw_in): the producer writes its raw output straight into the consumer's input buffer and
         // no apply pass runs in between.  Transposed conv -> second half of cat[level]:
         const bool skip_takes_raw = takes_raw_input(g, s.skip[i], g->cat[lvl], 2 * oC, bs, oH, oH, oC);
-        if ((rc = run_conv(g, s.dec[i], d, dC, bs, dH, dH, skip_takes_raw ? g->cat[lvl] + oC : g->raw, st, skip_takes_raw ? 2 * oC : 0,
+        if (!(last && ko(128)) &&
+            (rc = run_conv(g, s.dec[i], d, dC, bs, dH, dH, skip_takes_raw ? g->cat[lvl] + oC : g->raw, st, skip_takes_raw ? 2 * oC : 0,
                            d_raw ? 0 : -1)) != LWG_OK)
             return rc;
         if (!skip_takes_raw &&
@@ -621,7 +641,8 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
             return rc;
         // skipper conv over the whole cat buffer -> the next level's input (the last one's raw output feeds the heads)
         const bool next_takes_raw = !last && takes_raw_input(g, s.dec[i + 1], g->sk[i], oC, bs, oH, oH, 0);
-        if ((rc = run_conv(g, s.skip[i], g->cat[lvl], 2 * oC, bs, oH, oH, next_takes_raw ? g->sk[i] : g->raw, st, 0,
+        if (!(last && ko(64)) &&
+            (rc = run_conv(g, s.skip[i], g->cat[lvl], 2 * oC, bs, oH, oH, next_takes_raw ? g->sk[i] : g->raw, st, 0,
                            skip_takes_raw ? oC : -1)) != LWG_OK)
             return rc;
         if (!last) {
@@ -647,6 +668,10 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
     h.bg = bg;
     h.bg_bs = bg_bs;
     h.pred = pred;
+#ifdef LWG_EXPERIMENTS
+    ++g_ko_passes;
+#endif
+    if (ko(16)) return LWG_OK;
     if (!g->split) return launch_heads(h, st);   // exact fp32 on the vector ALU
     if (g->tsf.heads_frag_stale) {
         if ((rc = launch_heads_pack(s.heads_w, s.heads_frag, st)) != LWG_OK) return rc;
