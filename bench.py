@@ -102,8 +102,9 @@ def parse():
     p.add_argument("--frames", type=int, default=1024, help="length of the synthetic reference sequence")
     p.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle timing (profiling runs)")
     p.add_argument("--no-roofline", action="store_true", help="skip the HIP-event pass over the conv kernel")
-    p.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
-                   help="conv arithmetic of the per-frame stream (default: the library default, bf16x3)")
+    p.add_argument("--precision", choices=["auto", "bf16x3", "fp32"], default=None,
+                   help="conv arithmetic of the per-frame stream (default: the library default, auto = bf16x3 unless the probe at "
+                        "personalize sends the weights to fp32)")
     p.add_argument("--no-fp32-mode", action="store_true", help="skip the extra timed pass in exact-fp32 mode")
     p.add_argument("--no-strict", action="store_true", help="skip the strict one-batch-per-launch-sequence windows")
     p.add_argument("--no-secondary", action="store_true",
@@ -569,8 +570,9 @@ def main():
     imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=BATCH, seed=0, image_size=IMAGE_SIZE)
     if args.precision:
         imitator.generator.precision = args.precision
-    precision = imitator.generator.precision
     imitator.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+    policy, auto_report = imitator.generator.precision_policy, imitator.generator.auto_report
+    precision = imitator.generator.precision          # what the pass runs in (policy auto: what the probe chose)
     smpls = torch.from_numpy(demo.synthetic_smpls(args.frames, seed=0)).to(dev)
     imitator.first_cam = smpls[0:1, 0:3].clone()
     blocks = sharding.shard_blocks(args.frames, BATCH, rank, world)
@@ -774,7 +776,8 @@ def main():
                        "gflop_per_frame": 105.58, "frames": args.frames, "batch_per_gpu": BATCH, "image_size": IMAGE_SIZE,
                        "parallelism": "frame-sharded replicas x%d" % world, "grid_sample_align_corners": False,
                        "lanes": lanes, "batches_per_launch_sequence": fuse, "frames_per_launch": fuse * BATCH,
-                       "precision": precision, **strict},
+                       "precision": precision, "precision_policy": policy,
+                       "auto_probe_linf_vs_fp32": None if not auto_report else round(auto_report["linf_bf16x3_vs_fp32"], 7), **strict},
             "repeats": len(windows), "ms_per_step_min": round(min(windows) / args.steps * 1e3, 4),
             "ms_per_step_max": round(max(windows) / args.steps * 1e3, 4),
             "ms_per_step_windows": [round(w / args.steps * 1e3, 4) for w in windows],

@@ -91,6 +91,7 @@ _PROTOS = {
     "lwg_mask_faces": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "lwg_swap_compose": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lwg_clamp": (_i, [_vp, _c.c_size_t, _c.c_float, _c.c_float, _vp]),
+    "lwg_max_abs_diff": (_i, [_vp, _vp, _c.c_size_t, _vp, _vp]),
     "lwg_grid_sample_plan_bytes": (_c.c_size_t, [_i, _i, _i, _i, _i, _i]),
     "lwg_grid_sample_plan": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _c.c_size_t, _vp]),
     "lwg_grid_sample_backward_planned": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _c.c_size_t, _vp, _vp]),

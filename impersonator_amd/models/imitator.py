@@ -161,6 +161,11 @@ class Imitator(BaseModel):
         if bg_done is not None:
             torch.cuda.current_stream().wait_event(bg_done)     # the background is complete for whoever uses src_info next
         self.src_info = src_info
+        if getattr(self.generator, 'precision_policy', None) == 'auto' and self.generator.auto_pending():
+            # conv arithmetic by probe (ImpersonatorGenerator.auto_probe; once per weight set): the source's own posed mesh as the
+            # target frame (no second SMPL evaluation, `tsf_info` untouched), through both arithmetics
+            probe = self.render.transfer(src_info['cam'], src_info['verts'], p2verts_c, img)
+            self.generator.auto_probe(src_info['feats'][0], src_info['feats'][1], probe['tsf_inputs'], probe['T'], src_info['bg'])
 
         if visualizer is not None:
             visualizer.vis_named_img('src', img)

@@ -145,11 +145,12 @@ class ImpersonatorGenerator(NetworkBase):
         # meant True, torch >= 1.3 means False.  False is the parity target; True serves 2019 checkpoints.
         self.align_corners = bool(align_corners)
         # conv arithmetic (extension): "bf16x3" = fp32 operands split into two bf16 terms, three MFMA products, fp32
-        # accumulate (8e-5 L-inf on the final image, ~2.2x faster); "fp32" = exact fp32 MFMA.  Env LWG_PRECISION overrides.
+        # accumulate (8e-5 L-inf on the final image, ~3x faster); "fp32" = exact fp32 MFMA, the reference's own arithmetic;
+        # "auto" (default) = bf16x3 unless a probe pass in both arithmetics says the weights need fp32 (see `auto_probe`).
+        # Env LWG_PRECISION overrides the default.
         import os
-        self.precision = precision or os.environ.get("LWG_PRECISION", "bf16x3")
-        if self.precision not in self.PRECISIONS:
-            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+        self._policy, self._precision, self.auto_report = "auto", "bf16x3", None
+        self.precision = precision or os.environ.get("LWG_PRECISION", "auto")
         self.bg_dim = bg_dim
         self.bg_model = ResNetGenerator(conv_dim=conv_dim, c_dim=bg_dim, repeat_num=repeat_num, k_size=3, n_down=N_DOWN)
         import weakref
@@ -158,6 +159,61 @@ class ImpersonatorGenerator(NetworkBase):
         self.tsf_model = ResUnetGenerator(conv_dim=conv_dim, c_dim=tsf_dim, repeat_num=repeat_num, k_size=3, n_down=N_DOWN)
         self._handle = None
         self._uploaded_version = None
+
+    # ------------------------------------------------------------------ conv arithmetic
+    AUTO_BOUND = 2.5e-4   # bf16x3 serves a weight set if its probe image is within this of the exact-fp32 one (bound: 1e-3)
+
+    @property
+    def precision(self):
+        """The arithmetic the per-frame stream runs in: "bf16x3" or "fp32" (under the "auto" policy: what the probe chose, bf16x3
+        before any probe)."""
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value == "auto":
+            self._policy, self.auto_report = "auto", None
+            self._precision = "bf16x3"
+            return
+        if value not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % (sorted(self.PRECISIONS) + ["auto"]))
+        self._policy = self._precision = value
+
+    @property
+    def precision_policy(self):
+        return self._policy
+
+    def auto_pending(self):
+        """True while the "auto" policy has not probed the current weights (a probe is due at the next personalize)."""
+        if self._policy != "auto":
+            return False
+        ver = self._weights_version() + (bool(self.align_corners), int(self.image_size))
+        return self.auto_report is None or self.auto_report.get("weights") != ver
+
+    @torch.no_grad()
+    def auto_probe(self, src_encoder_outs, src_resnet_outs, tsf_inputs, T, bg_img):
+        """Policy "auto": decides the arithmetic for the CURRENT weights, once per weight set.  The reference computes
+        networks/generator.py:80-133 in fp32; bf16x3 differs from it by ~2^-17 per product, which random-init and trained weights
+        turn into 1e-5..1e-4 on the image but extreme weight sets (conv weights 5x wider than the initialisation, InstanceNorm
+        gains spread over two decades: tests/test_gpu_weight_sets.py) into 5e-4..8e-4.  So: one probe frame through BOTH
+        arithmetics; bf16x3 is kept when image, colour and mask agree with the fp32 pass within AUTO_BOUND, else this weight set
+        is served in fp32.  Costs one bf16x3 + one fp32 frame and a 4-byte read-back; nothing once the weights are known.
+        Returns the report (also in self.auto_report)."""
+        if not self.auto_pending():
+            return self.auto_report
+        ver = self._weights_version() + (bool(self.align_corners), int(self.image_size))
+        lib, outs = _lib.load(), {}
+        for mode in ("bf16x3", "fp32"):
+            self._precision = mode
+            outs[mode] = self.inference(src_encoder_outs, src_resnet_outs, tsf_inputs, T, bg_img=bg_img)
+        worst = torch.empty(3, device=tsf_inputs.device, dtype=torch.float32)   # (lwg_max_abs_diff zeroes its word itself)
+        for k, (a, b) in enumerate(zip(outs["bf16x3"], outs["fp32"])):
+            _lib.check(lib.lwg_max_abs_diff(_lib.ptr(a), _lib.ptr(b), a.numel(), ctypes.c_void_p(worst.data_ptr() + 4 * k),
+                                            _lib.stream_ptr()))
+        linf = float(max(worst.tolist()))
+        self._precision = "bf16x3" if linf <= self.AUTO_BOUND else "fp32"
+        self.auto_report = {"weights": ver, "linf_bf16x3_vs_fp32": linf, "bound": self.AUTO_BOUND, "chosen": self._precision}
+        return self.auto_report
 
     # ------------------------------------------------------------------ handle / weights
     def _weights_version(self):
@@ -208,7 +264,7 @@ class ImpersonatorGenerator(NetworkBase):
         other's.  Precision and align_corners follow the original at every use (see Imitator._lanes)."""
         r = ImpersonatorGenerator(self.bg_dim, self.src_dim, self.tsf_dim, conv_dim=self.conv_dim,
                                   repeat_num=self.repeat_num, image_size=self.image_size, max_batch=self.max_batch,
-                                  align_corners=self.align_corners, precision=self.precision)
+                                  align_corners=self.align_corners, precision=self.precision)   # (the resolved arithmetic)
         r.bg_model, r.src_model, r.tsf_model = self.bg_model, self.src_model, self.tsf_model   # shared Parameters
         return r
 

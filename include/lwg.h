@@ -157,6 +157,11 @@ LWG_API int lwg_mask_faces(const float *f2pts, const unsigned char *drop, int nf
 LWG_API int lwg_swap_compose(const float *tsf21, const float *tsf11, const float *part_mask, const float *left_mask, const float *cond,
                              int nc, int H, int W, float *out, lwg_stream_t stream);
 LWG_API int lwg_clamp(float *x, size_t n, float lo, float hi, lwg_stream_t stream);
+/* *out (device) = max |a[i] - b[i]| over n floats; a NaN difference reports +inf.  The comparison behind the generator's
+ * `precision="auto"` (impersonator_amd/networks/generator.py): the reference computes networks/generator.py:80-133 in fp32
+ * throughout, the library's bf16x3 arithmetic is narrower -- one probe pass in both arithmetics per weight set decides which one
+ * serves it, and this is its `(a - b).abs().max()` without a framework kernel. */
+LWG_API int lwg_max_abs_diff(const float *a, const float *b, size_t n, float *out, lwg_stream_t stream);
 /* ---- Once-per-source glue of Imitator.personalize (models/imitator.py:82-155), so that `personalize` launches no
  * framework kernel.
  * morph: utils/util.py:73-89 -- erode (mode 0: pad with 1, count == ks*ks) / dilate (mode 1: pad with 0, count >= 1) of a

@@ -18,12 +18,8 @@ import tempfile
 LLVM = "/opt/rocm/lib/llvm/bin/"
 
 
-def main():
-    lib = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] not in ("", "-") else None
-    if lib is None:
-        import torch
-        lib = os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_hip.so")
-    out = sys.argv[2] if len(sys.argv) > 2 else None
+def scan(lib):
+    """-> dict(bundles, symbols, pk, bad, kernels={kernel: [instructions]}) for every gfx950 code object embedded in `lib`."""
     fh = open(lib, "rb")
     mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
     pos = nblob = npk = nbad = nkern = 0
@@ -63,10 +59,31 @@ def main():
                     os.remove(co)
             nblob += 1
             pos = i + total
+    return {"bundles": nblob, "symbols": nkern, "pk": npk, "bad": nbad, "kernels": bad}
+
+
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 24), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] not in ("", "-") else None
+    if lib is None:
+        import torch
+        lib = os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_hip.so")
+    out = sys.argv[2] if len(sys.argv) > 2 else None
+    r = scan(lib)
+    nblob, nkern, npk, nbad, bad = r["bundles"], r["symbols"], r["pk"], r["bad"], r["kernels"]
     names = list(bad)
     dem = subprocess.run(["c++filt"], input="\n".join(names) + "\n", stdout=subprocess.PIPE, text=True).stdout.splitlines() if names else []
     fam = collections.Counter(re.sub(r"^void ", "", re.sub(r"[<(].*", "", d))[:80] for d in dem)
     lines = ["# Packed-fp32 instructions with op_sel[src1] = 1 in %s (tools/pk_opsel_scan_library.py)\n" % os.path.basename(lib),
+             "`%s`, sha256 `%s`.\n" % (lib, file_sha256(lib)),
              "%d compressed offload bundles, %d gfx950 symbols disassembled, %d packed-fp32 instructions, **%d with op_sel set for src1 in %d kernels**. "
              "That is the form that returns wrong values on a CU shared with liblwg's bf16x3 conv kernels (DESIGN.md section 5.1, "
              "`profiles/r03_coresidency.md`).  It is harmless as long as these kernels do not run on another stream beside those conv "
