@@ -136,18 +136,21 @@ class Imitator(BaseModel):
             # workgroups: it runs on a side stream UNDERNEATH the source-stream encoder below (equally small launches) instead of in
             # front of it -- same kernels, same values; the streams meet again before personalize returns
             main = torch.cuda.current_stream()
-            if getattr(self, '_bg_stream', None) is None:
-                self._bg_stream = torch.cuda.Stream()
-            fork = torch.cuda.Event()
-            fork.record(main)
-            with torch.cuda.stream(self._bg_stream):
-                self._bg_stream.wait_event(fork)
+            if os.environ.get("LWG_BG_SIDE_STREAM", "1") == "0":      # A/B switch: the inpaintor in front of the encoder, one stream
                 src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)
-                bg_done = torch.cuda.Event()
-                bg_done.record(self._bg_stream)
-            for t in (img, body_mask):
-                t.record_stream(self._bg_stream)
-            src_info['bg'].record_stream(main)
+            else:
+                if getattr(self, '_bg_stream', None) is None:
+                    self._bg_stream = torch.cuda.Stream()
+                fork = torch.cuda.Event()
+                fork.record(main)
+                with torch.cuda.stream(self._bg_stream):
+                    self._bg_stream.wait_event(fork)
+                    src_info['bg'] = self.bgnet(img, masks=body_mask, only_x=True)
+                    bg_done = torch.cuda.Event()
+                    bg_done.record(self._bg_stream)
+                for t in (img, body_mask):
+                    t.record_stream(self._bg_stream)
+                src_info['bg'].record_stream(main)
         else:
             # imitator.py:126-132: BGNet on the masked image + mask
             bg_mask = util.morph(bg_cond, ks=opt.bg_ks, mode='erode')

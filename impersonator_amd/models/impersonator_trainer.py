@@ -298,16 +298,34 @@ class Impersonator(BaseModel):
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     terms, (_, _, fake_tsf_imgs, _) = tr.optimize_G(batch)
                     terms = dict(terms, d_loss=self._optimize_D(fake_tsf_imgs))
-            except Exception as e:   # noqa: BLE001 -- whatever broke the capture, training must go on eagerly
+                failed = None
+            except RuntimeError as e:
+                # what a capture can legitimately trip over is reported as RuntimeError (HIP / torch "operation not permitted when
+                # stream is capturing", an allocation inside the capture, LwgError is one too); anything else -- a bug -- propagates
+                failed = e
+            if os.environ.get("LWG_GRAPH_STRICT") == "1" and failed is not None:
+                raise failed
+            # The fall-back is ONE decision for the whole job: a rank that replays a graph with captured collectives while another
+            # issues them eagerly would hang both.  (The flag travels on the compute stream after the capture has ended.)
+            if sharding.collectives_active():
+                flag = torch.tensor([1.0 if failed is not None else 0.0], device=self._T.device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                any_failed = bool(flag.item() > 0)
+            else:
+                any_failed = failed is not None
+            if any_failed:
                 import warnings
-                warnings.warn("optimize_parameters_graphed: capture failed (%s: %s); continuing with eager iterations"
-                              % (type(e).__name__, e))
+                warnings.warn("optimize_parameters_graphed: capture failed (%s); continuing with eager iterations"
+                              % ("%s: %s" % (type(failed).__name__, failed) if failed is not None else "on another rank"))
                 self._graph = self._graph_terms = None
                 self._graph_failed = True
                 torch.cuda.synchronize()
                 for k, v in caller.items():
                     setattr(self, k, v)
                 self._device_steps(False)
+                # the aborted capture advanced the generator trainer's pass state on the host (bucket counters, `untouched` keys):
+                # the eager iteration below starts its own pass from scratch (backward() re-begins both)
+                tr._buckets = None
                 return self.optimize_parameters()
             self._graph, self._graph_terms = graph, terms
             self._graph_lrs = (float(self._current_lr_D), float(tr.lr))

@@ -117,23 +117,37 @@ class SMPL(nn.Module):
         self.parents = np.asarray(params['kintree_table'][0]).astype(np.int32)
         self.register_buffer('weights', f32(params['weights']))
         self.register_buffer('joint_regressor', f32(np.asarray(params['cocoplus_regressor']).T))
-        # device path (liblwg, smpl.hip): the joint regression is linear in the shape, fold it once in float64
-        jreg = np.asarray(params['J_regressor'], np.float64)                       # (24, nv)
-        vt = np.asarray(params['v_template'], np.float64)                          # (nv, 3)
-        sdirs = np.asarray(params['shapedirs'], np.float64)                        # (nv, 3, nb)
-        self.register_buffer('J_template', f32(jreg @ vt))                         # (24, 3)
-        self.register_buffer('J_shapedirs', f32(np.einsum('jv,vck->kjc', jreg, sdirs).reshape(self.num_betas, -1)))
-        self.register_buffer('parents_t', torch.from_numpy(self.parents.astype(np.int32)))
-        # "compensated" mode (lwg_smpl_forward_f64): the same folding, in fp64, of the fp32 tensors the model actually holds
-        jreg32 = self.J_regressor.double().numpy().T                               # (24, nv), the fp32 values
-        # non-persistent: derived from the fp32 buffers, so checkpoints keep the reference's keys (strict load_state_dict works)
-        self.register_buffer('J_template_d', torch.from_numpy(jreg32 @ self.v_template.double().numpy()).contiguous(),
-                             persistent=False)
-        sd32 = self.shapedirs.double().numpy().reshape(self.num_betas, -1, 3)      # (nb, nv, 3)
-        self.register_buffer('J_shapedirs_d', torch.from_numpy(
-            np.einsum('jv,kvc->kjc', jreg32, sd32).reshape(self.num_betas, -1)).contiguous(), persistent=False)
+        self.register_buffer('parents_t', torch.from_numpy(self.parents.astype(np.int32)), persistent=False)
+        # Derived buffers of the device path (liblwg, smpl.hip) -- the joint regression is linear in the shape and is folded once.
+        # All NON-persistent: a state_dict holds exactly the reference's six keys (networks/batch_smpl.py:251-283: v_template,
+        # shapedirs, J_regressor, posedirs, weights, joint_regressor), a strict load of a reference checkpoint works, and
+        # _refresh_derived() rebuilds them whenever load_state_dict has replaced the tensors they are functions of.
+        self._refresh_derived()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._after_load(incompatible))
         self.precision = os.environ.get("LWG_SMPL_PRECISION", self.precision)
         self._ws = None
+
+    def _refresh_derived(self):
+        """J_template (24,3) / J_shapedirs (nb,72): J_regressor^T applied to v_template / shapedirs, folded in float64 and rounded
+        (the fp32 kernels' operands); J_template_d / J_shapedirs_d: the same products kept in fp64 (the `compensated` kernels')."""
+        dev = self.v_template.device
+        jreg = self.J_regressor.detach().double().cpu().t()                                       # (24, nv), the fp32 values
+        jt = jreg @ self.v_template.detach().double().cpu()                                        # (24, 3)
+        js = torch.einsum('jv,kvc->kjc', jreg, self.shapedirs.detach().double().cpu().reshape(self.num_betas, -1, 3)) \
+            .reshape(self.num_betas, -1)                                                           # (nb, 72)
+        for name, val in (('J_template', jt.float()), ('J_shapedirs', js.float()), ('J_template_d', jt), ('J_shapedirs_d', js)):
+            val = val.contiguous().to(dev)
+            if name in self._buffers:
+                self._buffers[name] = val
+            else:
+                self.register_buffer(name, val, persistent=False)
+
+    def _after_load(self, incompatible):
+        """load_state_dict post-hook: checkpoints written by earlier rounds of this repo carried the derived buffers as keys --
+        they are accepted and ignored (never an `unexpected key` error) -- and the derived buffers follow the loaded tensors."""
+        legacy = {'J_template', 'J_shapedirs', 'parents_t', 'J_template_d', 'J_shapedirs_d'}
+        incompatible.unexpected_keys[:] = [k for k in incompatible.unexpected_keys if k.split('.')[-1] not in legacy]
+        self._refresh_derived()
 
     def forward(self, beta, theta, get_skin=False):
         """networks/batch_smpl.py:285-375.  CUDA tensors run the fused HIP kernels of liblwg (smpl.hip);

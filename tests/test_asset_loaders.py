@@ -59,6 +59,26 @@ def test_smpl_pickle_loader(assets):
         SMPL(pkl_path=str(d / "missing.pkl"))
 
 
+def test_smpl_state_dict_has_the_reference_keys_and_derived_buffers_follow_a_load(assets):
+    """The SMPL module's state_dict is exactly the reference's six buffers (networks/batch_smpl.py:251-283): a strict load of a
+    reference-keyed checkpoint works, a checkpoint of an earlier round (derived buffers as extra keys) still loads, and the derived
+    buffers of the device kernels are rebuilt from what was loaded."""
+    from impersonator_amd.networks.batch_smpl import SMPL, synthetic_smpl_params
+    a, b = SMPL(params=synthetic_smpl_params(0)), SMPL(params=synthetic_smpl_params(1))
+    assert sorted(a.state_dict()) == ["J_regressor", "joint_regressor", "posedirs", "shapedirs", "v_template", "weights"]
+    assert not torch.equal(a.J_shapedirs_d, b.J_shapedirs_d)
+    res = b.load_state_dict(a.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for name in ("J_template", "J_shapedirs", "J_template_d", "J_shapedirs_d"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert b.J_template_d.dtype == torch.float64 and b.J_template.dtype == torch.float32
+    legacy = dict(a.state_dict(), J_template=a.J_template.clone(), J_shapedirs=a.J_shapedirs.clone(), parents_t=a.parents_t.clone(),
+                  J_template_d=a.J_template_d.clone(), J_shapedirs_d=a.J_shapedirs_d.clone())
+    c = SMPL(params=synthetic_smpl_params(2))
+    c.load_state_dict(legacy, strict=True)       # the extra keys of an old checkpoint are tolerated, not loaded
+    assert torch.equal(c.J_shapedirs_d, a.J_shapedirs_d)
+
+
 def test_mapping_tables(assets):
     from impersonator_amd.utils import mesh
     d, _ = assets

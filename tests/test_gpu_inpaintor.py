@@ -68,6 +68,20 @@ def test_imitator_personalize_with_inpaintor():
         bg_mask = torch_ref.morph(si["cond"][:, -1:].cpu(), imitator._opt.bg_ks, "erode")
         _, ox, _ = torch_ref.inpaint_forward(sd, torch.from_numpy(src_img)[None], 1 - bg_mask)
     assert float((si["bg"].cpu() - ox).abs().max()) <= 1e-3
+    # the inpaintor runs on a side stream underneath the source-stream encoder (both bf16x3 / fp32 MFMA launches of 64-128
+    # workgroups): the same call with everything in sequence on one stream must give the same bits, five times over
+    import os
+    keep = {k: si[k].clone() for k in ("bg",)}
+    feats = [f.clone() for f in si["feats"][0] + si["feats"][1]]
+    for rep in range(5):
+        os.environ["LWG_BG_SIDE_STREAM"] = "0" if rep % 2 == 0 else "1"
+        try:
+            imitator.personalize(src_img, src_smpl=src_smpl)
+        finally:
+            os.environ.pop("LWG_BG_SIDE_STREAM", None)
+        assert torch.equal(imitator.src_info["bg"], keep["bg"]), rep
+        for a, b in zip(imitator.src_info["feats"][0] + imitator.src_info["feats"][1], feats):
+            assert torch.equal(a, b), rep
 
 
 def test_mfma_attention_equals_the_vector_alu_attention(tmp_path):
