@@ -86,9 +86,10 @@ struct ConvArgs {
 int conv_trace_set(void *device_buffer, size_t bytes);
 int conv_trace_launch(int idx, long long *v10);
 
-// bn = 64 or 128 output channels per workgroup tile.  *variant (optional) receives which kernel instantiation ran:
+// bn = 64 or 128 output channels per workgroup tile (exact-fp32 DMA path also 32: twice the workgroups for launches that leave
+// most of the chip idle -- one source, one frame).  *variant (optional) receives which kernel instantiation ran:
 enum { kIgemmReg64 = 0, kIgemmReg128 = 1, kIgemmSmallCin = 2, kIgemmDma64 = 3, kIgemmDma128 = 4, kIgemmBf16x3_64 = 5,
-       kIgemmBf16x3_128 = 6, kDirectStemBf16x3 = 7, kHaloBf16x3_128 = 8, kHaloBf16x3_64 = 9, kIgemmVariants = 10 };
+       kIgemmBf16x3_128 = 6, kDirectStemBf16x3 = 7, kHaloBf16x3_128 = 8, kHaloBf16x3_64 = 9, kIgemmDma32 = 10, kIgemmVariants = 11 };
 extern const char *const kIgemmVariantNames[kIgemmVariants];
 int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant = nullptr);
 // true when launch_conv_igemm(a, bn) would run a kernel that honours a.raw_in (the halo-resident 3x3 / transposed kernels)

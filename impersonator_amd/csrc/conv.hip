@@ -605,11 +605,18 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    // piece p rides behind chain p; where a stage has more pieces than chains (the 32-channel tile: 5 pieces, 4
+                    // chains) the last chain takes the rest -- in order: the last piece advances the (tap, channel) walk
+                    constexpr int CHAINS = (BK / 8) * WM * WN;
                     const int piece = k8 * (WM * WN) + i * WN + j;
-                    if (decltype(do_dma)::value && piece < LPS && !(DBG & 1)) {
-                        __builtin_amdgcn_sched_barrier(0);   // keep the piece where it is: behind this MFMA chain
-                        dma_piece(piece, kt + (NS - 1), slot2);
-                        __builtin_amdgcn_sched_barrier(0);
+                    if (decltype(do_dma)::value && !(DBG & 1)) {
+#pragma unroll
+                        for (int pp = piece; pp < LPS; ++pp) {
+                            if (pp != piece && piece != CHAINS - 1) break;
+                            __builtin_amdgcn_sched_barrier(0);   // keep the piece where it is: behind this MFMA chain
+                            dma_piece(pp, kt + (NS - 1), slot2);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             if (k8 + 1 < BK / 8 && !(DBG & 8)) {
@@ -631,7 +638,7 @@ __device__ __forceinline__ void igemm_dma_body(const ConvArgs &a)
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
-    static_assert(LPS <= (BK / 8) * WM * WN, "not enough MFMA chains to hide the DMA pieces of a stage");
+    static_assert(LPS <= 2 * (BK / 8) * WM * WN, "not enough MFMA chains to hide the DMA pieces of a stage");
 
     const int nk = ph.Kpad / BK;
     // prologue: NS-1 stages in flight, the first one must have landed
@@ -1804,7 +1811,7 @@ const char *const kIgemmVariantNames[kIgemmVariants] = {
     "conv_igemm_dma_f32<64, 1, 2, 0, 3>", "conv_igemm_dma_f32<128, 2, 2, 0, 3>",
     // kernels that run as several instantiations (ring depth / tile height) are named by the prefix rocprofv3 prints
     "conv_igemm_bf16x3<64, 1, 2, 3, 0>", "conv_igemm_bf16x3<128, 2, 2", "stem_bf16x3_kernel",
-    "conv3x3_halo_bf16x3<128, 2, 2", "conv3x3_halo_bf16x3<64, 1, 2"};
+    "conv3x3_halo_bf16x3<128, 2, 2", "conv3x3_halo_bf16x3<64, 1, 2", "conv_igemm_dma_f32<32, 1, 1, 0, 3>"};
 
 // ---- measurement hook: per-wave cycle accounting of the 128-wide bf16x3 kernel (lwg_conv_trace, tools/conv_trace.py)
 constexpr int kTraceMaxLaunches = 4096;
@@ -1870,7 +1877,9 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
 {
     ConvArgs a = a_in;   // (the halo launches attach a trace block)
     a.trace = nullptr;   // only this function hands out trace blocks (lwg_conv_trace); never a caller's uninitialised field
-    if (a.Cout % bn != 0 || (bn != 64 && bn != 128))
+    // (32-channel tiles: the exact-fp32 DMA-fed kernel only)
+    const bool bn32_ok = bn == 32 && a.precision == 0 && !a.general && a.Cin >= BK && a.zeros;
+    if (a.Cout % bn != 0 || (bn != 64 && bn != 128 && !bn32_ok))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: Cout=%d not a multiple of the %d-channel tile", a.Cout, bn);
     if (!a.general && ((a.Hm * a.Wm) % BM != 0 || a.mtiles * BM != a.N * a.Hm * a.Wm))
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: %dx%d output grid per image is not a multiple of %d pixels", a.Hm, a.Wm, BM);
@@ -2136,7 +2145,7 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
     // same order, so the choice never changes a result bit.
     const int ncu = device_cu_count();
     const long nblocks = (long)grid.x * grid.y * grid.z;
-    const bool use_dma = !small_cin && a.zeros && (bn == 64 || nblocks <= ncu);
+    const bool use_dma = !small_cin && a.zeros && (bn <= 64 || nblocks <= ncu);
     if (a.fuse_phases && !use_dma) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: fused phases need the DMA-fed kernel (Cin >= 32, 64-channel tile)");
     if (use_dma) {
         // DMA-fed 3-stage ring: (BM + bn) * 32 floats per stage
@@ -2151,12 +2160,22 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
         }
         for (int p = 0; p < a.nphase; ++p)
             if (a.ph[p].ntaps > 32) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: more than 32 taps on the DMA path");
-        if (bn == 64) {
+        if (bn == 32) {
+            // 128 pixels x 32 channels, one 32 x 32 MFMA tile per wave: a launch of 64 of the 64-channel tiles (one source's
+            // 512 -> 512 layer on a 32 x 32 map) becomes 128 workgroups.  Same products in the same order per output: same bits.
+            static DeviceOnce dma32_opt_in;
+            if (!dma32_opt_in.done()) {
+                LWG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_dma_f32<32, 1, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM + 32) * BK * (int)sizeof(float)));
+                dma32_opt_in.mark();
+            }
+            conv_igemm_dma_f32<32, 1, 1><<<grid, 256, lds_dma, st>>>(a);
+        } else if (bn == 64) {
             conv_igemm_dma_f32<64, 1, 2><<<grid, 256, lds_dma, st>>>(a);
         } else {
             conv_igemm_dma_f32<128, 2, 2><<<grid, 256, lds_dma, st>>>(a);
         }
-        if (variant) *variant = bn == 64 ? kIgemmDma64 : kIgemmDma128;
+        if (variant) *variant = bn == 32 ? kIgemmDma32 : (bn == 64 ? kIgemmDma64 : kIgemmDma128);
         LWG_LAUNCH_CHECK("conv_igemm_dma_f32");
         return LWG_OK;
     }

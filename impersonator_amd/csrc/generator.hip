@@ -423,6 +423,12 @@ int conv_args(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, 
     // phases walked inside the workgroup (equal work per workgroup).
     const long tiles128 = (long)a.mtiles * (L.cout / 128) * L.nphase;
     bn = (L.cout % 128 == 0 && tiles128 >= 256) ? 128 : 64;
+    // exact fp32 with few tiles (one source's encoder, one frame per call): 32-channel tiles while the launch stays under one
+    // workgroup per CU -- the 512 -> 512 layer on a 32 x 32 map is 64 workgroups of the 64-channel tile (env LWG_F32_BN32=0: off)
+    static const char *bn32_env = getenv("LWG_F32_BN32");
+    if (bn == 64 && a.precision == 0 && !L.transposed && L.cin_pad >= kConvBK && L.cout % 32 == 0 &&
+        (long)a.mtiles * (L.cout / 64) * L.nphase * 2 <= 256 && !(bn32_env && bn32_env[0] == '0'))
+        bn = 32;
     if (L.transposed) {
         if (a.precision == 1 && L.cout % 128 == 0) {
             // bf16x3: the 128-channel tile is ~1.4x faster than the 64-channel one; phases become separate workgroups,

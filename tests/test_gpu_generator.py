@@ -239,6 +239,53 @@ def test_fused_instance_norm_apply_is_bit_identical_to_the_apply_kernel():
     assert fused == unfused, (fused, unfused)
 
 
+_BN32_PROBE = (
+    "import hashlib, torch\n"
+    "from impersonator_amd.networks.generator import ImpersonatorGenerator\n"
+    "from oracle import torch_ref\n"
+    "from tests import helpers\n"
+    "def run():\n"
+    "    G = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=6, image_size=256, max_batch=2, precision='fp32')\n"
+    "    G.load_state_dict(torch_ref.state_dict_from_numpy(helpers.generator_state_dict(seed=0, affine='random')))\n"
+    "    G = G.cuda()\n"
+    "    g = torch.Generator().manual_seed(55)\n"
+    "    h = hashlib.sha256()\n"
+    "    src = torch.rand(1, 6, 256, 256, generator=g) * 2 - 1\n"
+    "    enc, res = G.encode_src(src.cuda())\n"
+    "    for f in enc + res:\n"
+    "        h.update(f.cpu().numpy().tobytes())\n"
+    "    h.update(G.infer_bg((torch.rand(1, 4, 256, 256, generator=g) * 2 - 1).cuda()).cpu().numpy().tobytes())\n"
+    "    for bs in (1, 2):\n"
+    "        x = torch.rand(bs, 6, 256, 256, generator=g) * 2 - 1\n"
+    "        T = torch.rand(bs, 256, 256, 2, generator=g) * 2.4 - 1.2\n"
+    "        bg = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1\n"
+    "        for t in G.inference(enc, res, x.cuda(), T.cuda(), bg_img=bg.cuda()):\n"
+    "            h.update(t.cpu().numpy().tobytes())\n"
+    "    G.release()\n"
+    "    return h.hexdigest()\n")
+
+
+def test_fp32_32_channel_tiles_are_bit_identical_to_the_64_channel_ones():
+    """conv_igemm_dma_f32<32, 1, 1> (128 pixels x 32 channels per workgroup: what the exact-fp32 launches of ONE source / ONE frame
+    take while they leave most of the chip idle -- the once-per-source encoder, the BGNet, one frame per call in fp32) against the
+    64-channel tiles (LWG_F32_BN32=0, a subprocess): every output adds the same products in the same order, the statistics are
+    combined per 32-row tile in the same order -- source features, background and frames must agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    assert os.environ.get("LWG_F32_BN32", "1") != "0", "this process must run the 32-channel tiles"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ns = {}
+    exec(_BN32_PROBE, ns)
+    narrow = ns["run"]()
+    p = subprocess.run([sys.executable, "-c", _BN32_PROBE + "print('HASH', run())\n"], cwd=root,
+                       env=dict(os.environ, LWG_F32_BN32="0", PYTHONPATH=root), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    wide = [l for l in p.stdout.splitlines() if l.startswith("HASH")][0].split()[1]
+    assert narrow == wide, (narrow, wide)
+
+
 @pytest.mark.parametrize("size,bs", [(512, 2), (384, 1)])
 def test_generator_at_other_image_sizes(size, bs):
     """The bf16x3 per-frame stream away from 256x256: 512 (sixteen 32-column tiles per row at the last level, the trunk on 64x64
