@@ -69,7 +69,7 @@ IMAGE_SIZE = 256
 TRAFFIC_FILE = "r06_traffic.json"
 # speed of the CPU port (oracle/) relative to the reference's own modules on the same cores, same inputs, bit-identical outputs:
 # tools/port_vs_reference.py, measured where /root/reference exists (profiles/r06_port_vs_reference.md)
-PORT_VS_REFERENCE = 0.90
+PORT_VS_REFERENCE = 0.97
 
 
 # sources of the kernels the timed step launches (the training and inpainting kernels are not among them)
