@@ -4,8 +4,10 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LWG_LIB=exp: the measurement build (python -m impersonator_amd.build --experiments; knock-out switches, tools/ only)
-LIB_PATH = os.path.join(_HERE, "_C", "liblwg_exp.so" if os.environ.get("LWG_LIB") == "exp" else "liblwg.so")
+# LWG_LIB=exp: the measurement build (python -m impersonator_amd.build --experiments; knock-out switches, tools/ only);
+# LWG_LIB=<tag>: _C/liblwg_<tag>.so, e.g. a copy of the previous build kept for an A/B on one box (with LWG_ALLOW_STALE_LIB=1)
+_LIB_TAG = re.sub(r"[^A-Za-z0-9]", "", os.environ.get("LWG_LIB", ""))
+LIB_PATH = os.path.join(_HERE, "_C", "liblwg_%s.so" % _LIB_TAG if _LIB_TAG else "liblwg.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lwg.h")
 
 LWG_OK = 0
@@ -139,7 +141,7 @@ def load():
     # (loading liblwg first binds a second runtime that sees no device context: "no ROCm-capable device").
     import torch  # noqa: F401
     # a library older than the kernel sources next to it must not run silently (the build stamps what it compiled)
-    stamp = os.path.join(_HERE, "_C", "liblwg_exp.sha256" if os.environ.get("LWG_LIB") == "exp" else "liblwg.sha256")
+    stamp = os.path.join(_HERE, "_C", "liblwg_%s.sha256" % _LIB_TAG if _LIB_TAG else "liblwg.sha256")
     if os.path.isdir(os.path.join(_HERE, "csrc")) and os.path.exists(stamp) and not os.environ.get("LWG_ALLOW_STALE_LIB"):
         from . import build as _build
         if open(stamp).read().strip() != _build._digest():

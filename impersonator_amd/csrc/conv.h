@@ -95,17 +95,19 @@ int launch_conv_igemm(const ConvArgs &a, int bn, hipStream_t st, int *variant = 
 // true when launch_conv_igemm(a, bn) would run a kernel that honours a.raw_in (the halo-resident 3x3 / transposed kernels)
 bool conv_raw_input_supported(const ConvArgs &a, int bn);
 
-// The 7x7 stem (Cin 6 in an NHWC8 fp32 tensor -> 64 channels) as an LDS-resident direct convolution on the bf16x3
+// The 7x7 stem (Cin <= 6 in an NHWC8 fp32 tensor -> 64 channels) as an LDS-resident direct convolution on the bf16x3
 // path (direct.hip).  `w` is the filter bank packed by stem_pack_weights; output and partials as launch_conv_igemm.
-constexpr int kStemWPitch = 57 * 16;               // bytes per output channel and plane: 7 rows x 8 taps x 16 B + 16 pad
+constexpr int kStemKRow = 48;                      // reduction entries per kernel row: 7 taps x 6 channels = 42, padded to three k-steps
+constexpr int kStemWPitch = 7 * kStemKRow * 2 + 16; // bytes per output channel and plane: 7 rows x 96 B + 16 pad (43 x 16: odd)
 constexpr int kStemWBytes = 2 * 64 * kStemWPitch;  // hi plane, lo plane
 struct StemArgs {
     const float *x; int N, H, W;    // NHWC8 fp32
     const void *w;                  // device, kStemWBytes
     float *y;                       // raw output NHWC (N,H,W,64)
     float2 *partials;               // [N*H*W/128][64] or null
+    int dbg;                        // measurement builds only (LWG_STEM_DBG)
 };
-bool stem_bf16x3_supported(int H, int W, int cin_pad, int cout, int k, int stride, int pad);
+bool stem_bf16x3_supported(int H, int W, int cin, int cin_pad, int cout, int k, int stride, int pad);
 void stem_pack_weights(const float *w_oihw, int cin, std::vector<unsigned char> &out);
 int launch_stem_bf16x3(const StemArgs &a, hipStream_t st);
 

@@ -162,7 +162,7 @@ int alloc_layer(Layer &L)
     if (L.cin_pad >= kConvBK) {
         LWG_HIP(hipMalloc(reinterpret_cast<void **>(&L.w_split), L.w_floats * sizeof(float)));
         LWG_HIP(hipMemset(L.w_split, 0, L.w_floats * sizeof(float)));
-    } else if (!L.transposed && stem_bf16x3_supported(kConvBM, kConvBM, L.cin_pad, L.cout, L.k, L.stride, L.pad)) {
+    } else if (!L.transposed && stem_bf16x3_supported(kConvBM, kConvBM, L.cin, L.cin_pad, L.cout, L.k, L.stride, L.pad)) {
         LWG_HIP(hipMalloc(&L.w_stem, kStemWBytes));
         LWG_HIP(hipMemset(L.w_stem, 0, kStemWBytes));
     }
@@ -471,7 +471,7 @@ int run_conv(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, i
     }
     int variant = 0;
     int rc;
-    if (g->split && L.w_stem && ldx == 8 && stem_bf16x3_supported(H, W, L.cin_pad, L.cout, L.k, L.stride, L.pad)) {
+    if (g->split && L.w_stem && ldx == 8 && stem_bf16x3_supported(H, W, L.cin, L.cin_pad, L.cout, L.k, L.stride, L.pad)) {
         StemArgs s = {};
         s.x = x; s.N = N; s.H = H; s.W = W;
         s.w = L.w_stem;
