@@ -2145,7 +2145,9 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
     // same order, so the choice never changes a result bit.
     const int ncu = device_cu_count();
     const long nblocks = (long)grid.x * grid.y * grid.z;
-    const bool use_dma = !small_cin && a.zeros && (bn <= 64 || nblocks <= ncu);
+    bool few_taps = true;   // the DMA ring keeps a 32-bit tap mask per row: a 7x7 stem on 32 padded channels is register-staged
+    for (int p = 0; p < a.nphase; ++p) few_taps = few_taps && a.ph[p].ntaps <= 32;
+    const bool use_dma = !small_cin && a.zeros && few_taps && (bn <= 64 || nblocks <= ncu);
     if (a.fuse_phases && !use_dma) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: fused phases need the DMA-fed kernel (Cin >= 32, 64-channel tile)");
     if (use_dma) {
         // DMA-fed 3-stage ring: (BM + bn) * 32 floats per stage
@@ -2179,6 +2181,7 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
         LWG_LAUNCH_CHECK("conv_igemm_dma_f32");
         return LWG_OK;
     }
+    if (bn != 64 && bn != 128) LWG_FAIL(LWG_ERR_UNSUPPORTED, "conv: the register-staged fp32 kernel has 64- and 128-channel tiles, not %d", bn);
     if (variant) *variant = small_cin ? kIgemmSmallCin : (bn == 64 ? kIgemmReg64 : kIgemmReg128);
     if (small_cin) {
         conv_igemm_f32<64, 1, 2, true><<<grid, 256, lds, st>>>(a);

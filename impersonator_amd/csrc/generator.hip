@@ -65,7 +65,8 @@ struct lwg_generator {
     int ignored_keys = 0;
 
     // scratch (sized for max_batch)
-    float *x0 = nullptr;              // (bs,is,is,8) packed input
+    float *x0 = nullptr;              // (bs,is,is,x0_c) packed input
+    int x0_c = 8;                     // widest padded stem input of the streams (8 for the default 6- / 4-channel inputs)
     float *raw = nullptr;             // largest raw conv output
     float *cat[kNDown] = {};          // cat[l]: (bs, is>>l, is>>l, 2*cd<<l): [skip | decoder]
     float *trunk[3] = {};             // (bs, is/8, is/8, 8cd) ping/pong/mid
@@ -111,7 +112,9 @@ int act_alloc(float **p, size_t floats)
 void init_conv(Layer &L, int cin, int cout, int k, int stride, int pad)
 {
     L.cin = cin;
-    L.cin_pad = cin < 8 ? 8 : cin;
+    // input channels padded to what the kernels address: 8 (NHWC8: the default condition maps), 16 or 32 for the wide condition
+    // maps of utils/mesh.py:446-473 ('par': 3 + 11, 'binary': 3 + 15); inner layers have powers of two >= 64
+    L.cin_pad = cin <= 8 ? 8 : cin <= 16 ? 16 : cin <= 32 ? 32 : cin;
     L.cout = cout;
     L.k = k;
     L.stride = stride;
@@ -159,7 +162,8 @@ int alloc_layer(Layer &L)
     int rc = dev_alloc(&L.w, L.w_floats);
     if (rc != LWG_OK) return rc;
     LWG_HIP(hipMemset(L.w, 0, L.w_floats * sizeof(float)));
-    if (L.cin_pad >= kConvBK) {
+    // (a 7x7 stem with 32 padded input channels has 49 taps: more than the bf16x3 ring walks -- it stays on the exact-fp32 kernel)
+    if (L.cin_pad >= kConvBK && L.k * L.k <= 32) {
         LWG_HIP(hipMalloc(reinterpret_cast<void **>(&L.w_split), L.w_floats * sizeof(float)));
         LWG_HIP(hipMemset(L.w_split, 0, L.w_floats * sizeof(float)));
     } else if (!L.transposed && stem_bf16x3_supported(kConvBM, kConvBM, L.cin, L.cin_pad, L.cout, L.k, L.stride, L.pad)) {
@@ -426,7 +430,7 @@ int conv_args(lwg_generator *g, const Layer &L, const float *x, int ldx, int N, 
     // exact fp32 with few tiles (one source's encoder, one frame per call): 32-channel tiles while the launch stays under one
     // workgroup per CU -- the 512 -> 512 layer on a 32 x 32 map is 64 workgroups of the 64-channel tile (env LWG_F32_BN32=0: off)
     static const char *bn32_env = getenv("LWG_F32_BN32");
-    if (bn == 64 && a.precision == 0 && !L.transposed && L.cin_pad >= kConvBK && L.cout % 32 == 0 &&
+    if (bn == 64 && a.precision == 0 && !L.transposed && L.cin_pad >= kConvBK && L.k * L.k <= 32 && L.cout % 32 == 0 &&
         (long)a.mtiles * (L.cout / 64) * L.nphase * 2 <= 256 && !(bn32_env && bn32_env[0] == '0'))
         bn = 32;
     if (L.transposed) {
@@ -530,14 +534,17 @@ int run_apply(lwg_generator *g, int N, int H, int W, int C, bool relu, float *ds
     return launch_apply(a, st);
 }
 
-int pack_input(lwg_generator *g, const float *x, int layout, int N, int C, hipStream_t st, const float **out)
+// cpad = the consuming stem's padded input channels (Layer::cin_pad)
+int pack_input(lwg_generator *g, const float *x, int layout, int N, int C, int cpad, hipStream_t st, const float **out)
 {
     if (layout == 1) {
+        if (cpad != 8) LWG_FAIL(LWG_ERR_INVALID_ARG, "layout 1 (NHWC8) needs an input of at most 8 channels, this stream has %d", C);
         *out = x;
         return LWG_OK;
     }
     if (layout != 0) LWG_FAIL(LWG_ERR_INVALID_ARG, "layout must be 0 (NCHW) or 1 (NHWC8)");
-    const int rc = lwg_pack_nhwc(x, N, C, g->is, g->is, 8, g->x0, st);
+    if (cpad > g->x0_c) LWG_FAIL(LWG_ERR_STATE, "packed-input buffer holds %d channels, %d needed", g->x0_c, cpad);
+    const int rc = lwg_pack_nhwc(x, N, C, g->is, g->is, cpad, g->x0, st);
     *out = g->x0;
     return rc;
 }
@@ -597,10 +604,10 @@ int run_tsf(lwg_generator *g, const float *tsf_inputs, int layout, const float *
             if ((rc = lwg_resize_flow(T[k], bs, is, is, is >> l, is >> l, g->tscale[k][l - 1], st)) != LWG_OK) return rc;
 
     const float *x0 = nullptr;
-    if ((rc = pack_input(g, tsf_inputs, layout, bs, g->tsf_dim, st, &x0)) != LWG_OK) return rc;
+    if ((rc = pack_input(g, tsf_inputs, layout, bs, g->tsf_dim, s.enc[0].cin_pad, st, &x0)) != LWG_OK) return rc;
 
     // encoders: level l output lives in the first half of cat[l] (the decoder's skip operand), level 3 in the trunk
-    if ((rc = run_encoder(g, s, 0, x0, 8, bs, g->cat[0], 2 * cd, nullptr, 0, align, st)) != LWG_OK) return rc;
+    if ((rc = run_encoder(g, s, 0, x0, s.enc[0].cin_pad, bs, g->cat[0], 2 * cd, nullptr, 0, align, st)) != LWG_OK) return rc;
     for (int l = 1; l <= kNDown; ++l) {
         Warp w[2];
         for (int k = 0; k < nsets; ++k) {
@@ -696,7 +703,7 @@ int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, int conv
 {
     LWG_REQUIRE(out, "generator_create: NULL out");
     *out = nullptr;
-    LWG_REQUIRE(src_dim > 0 && src_dim <= 8 && tsf_dim > 0 && tsf_dim <= 8, "generator_create: input dims must be 1..8");
+    LWG_REQUIRE(src_dim > 0 && src_dim <= 32 && tsf_dim > 0 && tsf_dim <= 32, "generator_create: input dims must be 1..32");
     LWG_REQUIRE(repeat_num > 0 && max_batch > 0, "generator_create: repeat_num/max_batch must be positive");
     if (conv_dim != 64)
         LWG_FAIL(LWG_ERR_UNSUPPORTED, "generator_create: conv_dim=%d (the kernels are built for the reference's 64)", conv_dim);
@@ -719,7 +726,10 @@ int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, int conv
 
     const size_t B = (size_t)max_batch, P = (size_t)image_size * image_size;
     const int cd = conv_dim;
-    if (rc == LWG_OK) rc = dev_alloc(&g->x0, B * P * 8);
+    if (rc == LWG_OK) {
+        g->x0_c = g->src.enc[0].cin_pad > g->tsf.enc[0].cin_pad ? g->src.enc[0].cin_pad : g->tsf.enc[0].cin_pad;
+        rc = dev_alloc(&g->x0, B * P * g->x0_c);
+    }
     if (rc == LWG_OK) rc = dev_alloc(&g->raw, B * P * cd);
     for (int l = 0; l < kNDown && rc == LWG_OK; ++l) rc = act_alloc(&g->cat[l], g->cat_floats[l] = B * (P >> (2 * l)) * (size_t)(2 * (cd << l)));
     for (int i = 0; i < 3 && rc == LWG_OK; ++i) rc = act_alloc(&g->trunk[i], g->trunk_floats = B * (P >> (2 * kNDown)) * (size_t)(cd << kNDown));
@@ -894,9 +904,9 @@ int lwg_generator_encode_src_n(lwg_generator *g, const float *src_inputs_nchw, i
     // once per source, and its outputs are fp32 tensors handed to the caller (the LWB gathers read them): always fp32
     g->split = false;
     const float *x0 = nullptr;
-    if ((rc = pack_input(g, src_inputs_nchw, 0, bs, g->src_dim, st, &x0)) != LWG_OK) return rc;
+    if ((rc = pack_input(g, src_inputs_nchw, 0, bs, g->src_dim, g->src.enc[0].cin_pad, st, &x0)) != LWG_OK) return rc;
     const float *x = x0;
-    int ldx = 8;
+    int ldx = g->src.enc[0].cin_pad;
     for (int l = 0; l <= kNDown; ++l) {
         const int C = g->cd << l;
         if ((rc = run_encoder(g, g->src, l, x, ldx, bs, feats_nhwc[l], C, nullptr, 0, 0, st)) != LWG_OK) return rc;
@@ -987,8 +997,8 @@ int lwg_generator_bg_forward(lwg_generator *g, const float *bg_inputs_nchw, int 
     g->split = false;
     int rc;
     const float *x = nullptr;
-    if ((rc = pack_input(g, bg_inputs_nchw, 0, bs, g->bg_dim, st, &x)) != LWG_OK) return rc;
-    int ldx = 8;
+    if ((rc = pack_input(g, bg_inputs_nchw, 0, bs, g->bg_dim, s.enc[0].cin_pad, st, &x)) != LWG_OK) return rc;
+    int ldx = s.enc[0].cin_pad;
     for (int l = 0; l <= kNDown; ++l) {
         float *dst = l < kNDown ? g->cat[l] : g->trunk[0];
         const int C = cd << l;

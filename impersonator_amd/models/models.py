@@ -30,8 +30,8 @@ class BaseModel(object):
     @staticmethod
     def _cond_nc(map_name):
         # models/models.py:85-94 -> utils/mesh.py:446-473 (get_map_fn_dim): channel count of the face->condition table.
-        # (The generator handle takes up to 8 input channels, i.e. 3 + cond_nc <= 8: 'par' and 'binary' keep the
-        # reference's dims here and are rejected by lwg_generator_create with its own message.)
+        # (3 + cond_nc <= 8 takes the fused NHWC8 input path; 'par' and 'binary' run through the NCHW input and the
+        # 16- / 32-channel padded stem, lwg_generator_create.)
         dims = {'seg': 1, 'uv': 2, 'uv_seg': 3, 'par': 11, 'ids': 1, 'binary': 15}
         if map_name not in dims:
             raise ValueError('map name error {}'.format(map_name))

@@ -93,7 +93,14 @@ def create_mapping(map_name, mapping_path='assets/pretrains/mapper.txt',
         map_fn = np.zeros((nf, 1), np.float32)
         map_fn[faces] = 1.0
         bg = np.zeros((1, 1), np.float32)
+    elif map_name == 'binary':
+        # utils/mesh.py:271-279: the face index in binary, most significant bit first; background = -1 everywhere
+        width = len(np.binary_repr(nf))
+        idx = np.arange(nf, dtype=np.int64)[:, None]
+        map_fn = ((idx >> np.arange(width - 1, -1, -1, dtype=np.int64)[None, :]) & 1).astype(np.float32)
+        bg = np.zeros((1, width), np.float32) - 1.0
     else:
+        # ('ids' cannot be built with contain_bg in the reference either: its table is 1-D, utils/mesh.py:282-285)
         raise ValueError('map name error {}'.format(map_name))
     if contain_bg:
         map_fn = np.concatenate([map_fn, bg], axis=0)

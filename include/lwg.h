@@ -197,7 +197,10 @@ LWG_API int lwg_unpack_nchw(const float *x_nhwc, int n, int C, int H, int W, int
 typedef struct lwg_generator lwg_generator;
 
 /* ImpersonatorGenerator(bg_dim, src_dim, tsf_dim, conv_dim=64, repeat_num=6), n_down = 3
- * (generator.py:189-202).  Allocates weights + scratch for batches up to max_batch. */
+ * (generator.py:189-202).  Allocates weights + scratch for batches up to max_batch.  src_dim / tsf_dim = 3 + the condition
+ * map's channels (models/models.py:85-94, utils/mesh.py:446-473): 1..32, i.e. every map_name of the reference ('uv_seg' 6,
+ * 'par' 14, 'binary' 18).  Inputs of at most 8 channels take the NHWC8 path (layout 1 of lwg_generator_inference) and, under
+ * precision 1, the LDS-resident bf16x3 stem; wider ones are NCHW only and their 7x7 stem runs on the exact-fp32 kernel. */
 LWG_API int lwg_generator_create(lwg_generator **out, int src_dim, int tsf_dim, int conv_dim, int repeat_num,
                                  int image_size, int max_batch);
 LWG_API void lwg_generator_destroy(lwg_generator *g);

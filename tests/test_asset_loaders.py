@@ -92,6 +92,8 @@ def test_mapping_tables(assets):
     assert mesh.create_mapping("back", **kw).sum() == 11
     fb = mesh.create_mapping("par", fill_back=True, **kw)
     assert fb.shape == (121, 6) and (fb[:60] == fb[60:120]).all()
+    binary = mesh.create_mapping("binary", **kw)      # 60 faces -> 6 bits, most significant first; background row of -1
+    assert binary.shape == (61, 6) and (binary[-1] == -1).all() and (binary[37] == [1, 0, 0, 1, 0, 1]).all()
     ids = mesh.get_part_face_ids("par", mapping_path=kw["mapping_path"], part_info=kw["part_info"])
     assert sorted(sum(ids.values(), [])) == list(range(60))
     with pytest.raises(FileNotFoundError):
@@ -107,7 +109,7 @@ def test_mapping_tables_equal_the_reference_loaders(assets):
     d, _ = assets
     kw = dict(mapping_path=str(d / "mapper.txt"), part_info=str(d / "smpl_part_info.json"),
               front_info=str(d / "front_facial.json"), head_info=str(d / "head.json"))
-    for name in ("uv", "seg", "uv_seg", "par", "front", "head", "back"):
+    for name in ("uv", "seg", "uv_seg", "par", "front", "head", "back", "binary"):
         for fill_back in (False, True):
             if name == "par" and fill_back:
                 continue   # the reference drops fill_back on this branch (utils/mesh.py:404) and trips its own assert

@@ -1,0 +1,75 @@
+"""The condition maps wider than 'uv_seg' (utils/mesh.py:446-473: 'par' = 10 part labels + background, 'binary' = the face index in
+binary): 3 + cond_nc = 14 / 17 input channels for both streams of ImpersonatorGenerator (models/models.py:85-94,
+models/imitator.py:68-70).  Such inputs arrive NCHW (SMPLRenderer.transfer packs NHWC8 only for three condition channels) and the 7x7
+stems run on the 16- / 32-channel padded kernels; everything behind the stem is the default path.  Parity against the CPU oracle on
+the whole chain: renderer -> cond -> T -> generator -> blend, both arithmetic modes, 1e-3 on the image (north-star bound)."""
+import numpy as np
+import pytest
+import torch
+
+from impersonator_amd.utils import mesh, synthetic
+from oracle import torch_ref
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+TOL_IMAGE = 1e-3
+
+
+def _binary_table(nf):
+    """create_mapping('binary') needs the reference's mapper.txt for the face count only: the same table from nf."""
+    width = len(np.binary_repr(nf))
+    idx = np.arange(nf, dtype=np.int64)[:, None]
+    tab = ((idx >> np.arange(width - 1, -1, -1, dtype=np.int64)[None, :]) & 1).astype(np.float32)
+    return np.concatenate([tab, np.zeros((1, width), np.float32) - 1.0], axis=0)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("map_name", ["par", "binary"])
+def test_wide_condition_map_chain_matches_oracle(map_name, precision):
+    from impersonator_amd.networks.generator import ImpersonatorGenerator
+    from impersonator_amd.utils.nmr import SMPLRenderer
+    s = helpers.scene()
+    rest, faces = s["rest"], s["faces"]
+    map_fn = synthetic.part_map_fn(rest, faces)[0] if map_name == "par" else _binary_table(faces.shape[0])
+    nc = map_fn.shape[1]
+    assert nc == {"par": 11, "binary": len(np.binary_repr(faces.shape[0]))}[map_name] and 3 + nc > 8
+    G = ImpersonatorGenerator(bg_dim=4, src_dim=3 + nc, tsf_dim=3 + nc, repeat_num=6, max_batch=2, precision=precision)
+    shapes = [(k, tuple(v.shape)) for k, v in G.state_dict().items()]
+    sd = torch_ref.state_dict_from_numpy(synthetic.random_state_dict(shapes, seed=3, affine="random"))
+    G.load_state_dict(sd)
+    G = G.cuda()
+    r = SMPLRenderer(image_size=256, faces=faces, map_fn=map_fn).cuda()
+    try:
+        faces_t, map_t = helpers.t(faces), helpers.t(map_fn)
+        src_img, bg_img = helpers.t(s["src_img"]), helpers.t(s["bg_img"])
+        # oracle: source side (models/imitator.py:95-143) and two target frames (:250-260)
+        sf2v, sfim, _ = torch_ref.render_fim_wim(helpers.t(s["src_cam"]), helpers.t(s["src_verts"]), faces_t)
+        scond = torch_ref.encode_fim(sfim, map_t)
+        p2v = torch_ref.source_p2verts(sf2v)
+        src_inputs = torch.cat([src_img, scond], dim=1)
+        fr = torch_ref.transfer_frame(src_img, p2v, helpers.t(s["tgt_cam"]), helpers.t(s["tgt_verts"]), faces_t, map_t)
+        with torch.no_grad():
+            o_enc, o_res = torch_ref.encode_src(sd, src_inputs)
+            o_pred, o_color, o_mask = torch_ref.imitator_forward(sd, o_enc, o_res, bg_img, fr["tsf_inputs"], fr["T"])
+        # device: the renderer's transfer (cond has nc channels: no NHWC8 buffer, tsf_inputs is a plain NCHW cat)
+        out = r.transfer(helpers.t(s["tgt_cam"]).cuda(), helpers.t(s["tgt_verts"]).cuda(), p2v.cuda(), src_img.cuda())
+        assert tuple(out["tsf_inputs"].shape) == (2, 3 + nc, 256, 256) and out["tsf_inputs"].is_contiguous()
+        assert torch.equal(out["fim"].cpu(), fr["fim"].to(torch.int32)) and torch.equal(out["cond"].cpu(), fr["cond"])
+        assert helpers.maxdiff(out["T"], fr["T"])[0] <= 2e-6
+        enc, res = G.encode_src(src_inputs.cuda())
+        tol_f = {"fp32": 2e-4, "bf16x3": 6e-4}[precision]
+        for i, (a, b) in enumerate(zip(enc + res, o_enc + o_res)):
+            d, where = helpers.maxdiff(a, b)
+            assert d <= tol_f * max(1.0, float(b.abs().max())), ("source feature %d" % i, d, where)
+        pred, color, mask = G.inference(enc, res, out["tsf_inputs"], out["T"], bg_img=bg_img.cuda())
+        for name, a, b in (("color", color, o_color), ("mask", mask, o_mask), ("pred", pred, o_pred)):
+            d, where = helpers.maxdiff(a, b)
+            print("%s %s %s: L-inf %.3g" % (map_name, precision, name, d))
+            assert d <= TOL_IMAGE, (name, d, where)
+        # the NHWC8 fast path refuses a stream that is wider than eight channels instead of misreading it
+        from impersonator_amd import _lib
+        x8 = torch.zeros((2, 256, 256, 8), device="cuda").permute(0, 3, 1, 2)
+        with pytest.raises((ValueError, _lib.LwgError)):
+            G.inference(enc, res, x8, out["T"])
+    finally:
+        G.release()
