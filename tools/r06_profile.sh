@@ -61,20 +61,6 @@ try:
 except Exception as e:
     print("bench parse failed", e); print(open("$O/bench.err").read()[-1500:])
 PY
-import json
-try:
-    d = json.load(open("$O/bench.json")); r = d.get("roofline") or {}
-    print("fps", d["value"], "ms", d["ms_per_step"], d.get("ms_per_step_windows"), "fp32", d.get("exact_fp32_mode", {}).get("value"),
-          r.get("kernel"), r.get("achieved"), r.get("frac_pipe"), (r.get("all_conv_kernels") or {}).get("frac_pipe"))
-    print("clocks", d.get("gpu_clocks"))
-    print("parity", json.dumps(d.get("parity"))[:500])
-    print("cpu", json.dumps(d.get("cpu_baseline"))[:200])
-    s = d.get("secondary", {})
-    for k in ("latency", "personalize", "swap", "train"):
-        print(k, json.dumps(s.get(k))[:1400])
-except Exception as e:
-    print("bench parse failed", e); print(open("$O/bench.err").read()[-1500:])
-PY
 sed -n 1,40p $O/r06_roofline.md | cut -c1-200; sed -n '/HBM-side/,$p' $O/r06_roofline.md | cut -c1-200 | head -30
 grep -A12 "By kernel" $O/r06_fp32_roofline.md | cut -c1-200; tail -8 $O/r06_pmc_mfma.md
 sed -n 8,30p $O/r06_train_kernel_stats.md | cut -c1-150
