@@ -12,8 +12,9 @@
 //                does not matter, only the order inside it); texels with more than kHeavy contributions are queued
 //     3. fill  : every pixel appends key = pixel * 4 + tap to its texels' lists (order: whatever the atomics give)
 //     4. sort  : one thread per texel sorts its (short) list by key and stores the bilinear weight beside every key
-//     5. heavy : a queued texel's list is rebuilt IN KEY ORDER by a dense scan over the pixels of its image with a block-wide
-//                ordered compaction (a degenerate flow may send a whole image to one texel: no quadratic sort)
+//     5. heavy : a queued texel's list of up to 4096 keys is sorted in LDS by its workgroup (bitonic); a longer one is rebuilt IN KEY
+//                ORDER by a dense scan over the pixels of its image with a block-wide ordered compaction (a degenerate flow may
+//                send a whole image to one texel: no quadratic sort, and at most 4P / 4096 texels can be that long)
 //   apply (per warp) : one thread per (texel, 4 channels) walks the list in key order: acc = fma(w_k, dy[pixel_k], acc); dx += acc.
 // Same contributions as the atomic kernel (w * dy per tap, zeros padding), summed in a fixed order: bit-reproducible.
 #include "common.h"
@@ -168,12 +169,19 @@ __global__ __launch_bounds__(256) void gs_plan_sort_kernel(const float *__restri
     }
 }
 
-// one workgroup per queued texel (strided over the queue): the list rebuilt in key order by scanning the pixels of the texel's
-// image in order, 256 at a time, with a block-wide ordered compaction.  A pixel's four taps are four different texels, so a
-// pixel contributes at most once.
+// one workgroup per queued texel (strided over the queue).
+//   * up to kSortMax contributions (a minifying flow: every texel of the sampled region collects (Ho/H)^2-ish pixels -- up to
+//     4P/33 texels can be queued): the keys the fill pass left in arrival order are sorted in LDS (bitonic, padded with INT_MAX)
+//     and the weights looked up from the sorted keys: O(c log^2 c) per texel, O(P log^2) per plan whatever the flow;
+//   * longer lists (a degenerate flow sending a whole image to a few texels; at most 4P / kSortMax of them): the list rebuilt in key
+//     order by scanning the pixels of the texel's image in order, 256 at a time, with a block-wide ordered compaction.  A pixel's
+//     four taps are four different texels, so a pixel contributes at most once.
+// (Round 5 rescanned the image for EVERY queued texel: O(#heavy x pixels), ~1e9-1e10 tap evaluations for a strongly minifying flow.)
+constexpr int kSortMax = 4096;
 __global__ __launch_bounds__(256) void gs_plan_heavy_kernel(const float *__restrict__ grid, PlanDims d, PlanView v)
 {
     __shared__ int wave_cnt[4];
+    __shared__ int skeys[kSortMax];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nheavy = *v.heavy_count;
     if (nheavy > v.heavy_cap) nheavy = (int)v.heavy_cap;
@@ -182,6 +190,32 @@ __global__ __launch_bounds__(256) void gs_plan_heavy_kernel(const float *__restr
         const long tex = v.heavy[q];
         int *keys = v.keys + v.offset[tex];
         float *wts = v.weights + v.offset[tex];
+        const int cnt = v.count[tex];
+        if (cnt <= kSortMax) {
+            int n2 = 64;
+            while (n2 < cnt) n2 <<= 1;
+            for (int i = tid; i < n2; i += 256) skeys[i] = i < cnt ? keys[i] : 0x7fffffff;
+            __syncthreads();
+            for (int k = 2; k <= n2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < n2; i += 256) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const int a0 = skeys[i], b0 = skeys[l];
+                            const bool up = (i & k) == 0;
+                            if ((a0 > b0) == up) { skeys[i] = b0; skeys[l] = a0; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = tid; i < cnt; i += 256) {
+                const int key = skeys[i];
+                keys[i] = key;
+                wts[i] = pixel_taps(grid, key >> 2, d).w[key & 3];
+            }
+            __syncthreads();   // skeys is reused by this workgroup's next texel
+            continue;
+        }
         // pixels that can reach this texel: those of its own image (xn == n) or of every image (xn == 1: one shared source)
         const long p0 = d.xn > 1 ? (tex / hw_i) * hw_o : 0, p1 = d.xn > 1 ? p0 + hw_o : d.P;
         int written = 0;
@@ -287,7 +321,7 @@ int lwg_grid_sample_plan(const float *grid, int xn, int H, int W, int n, int Ho,
     LWG_LAUNCH_CHECK("gs_plan_fill_kernel");
     gs_plan_sort_kernel<<<tb, 256, 0, st>>>(grid, d, v);
     LWG_LAUNCH_CHECK("gs_plan_sort_kernel");
-    gs_plan_heavy_kernel<<<256, 256, 0, st>>>(grid, d, v);
+    gs_plan_heavy_kernel<<<1024, 256, 0, st>>>(grid, d, v);   // strided over the queue; workgroups without a texel leave at once
     LWG_LAUNCH_CHECK("gs_plan_heavy_kernel");
     return LWG_OK;
 }

@@ -283,6 +283,40 @@ def test_grid_sample_backward_is_bit_reproducible_also_on_crowded_texels(shared)
         ops.grid_sample_backward(dyd, gd, (x.shape[0], H + 1, H, C), False, plan=plan)
 
 
+def test_grid_sample_backward_minifying_flow_takes_the_sorted_lists_and_stays_fast():
+    """A strongly minifying flow (256 x 256 output pixels sampling a 16 x 16-texel region: hundreds of contributions per texel,
+    thousands of queued texels) sorts each list in LDS instead of rescanning the image per texel (the rescan was
+    O(#heavy x pixels)); one image sends all its 9216 pixels to one location (> 4096: the dense-scan path).  Values against float64
+    autograd, bit-reproducible, and the plan of the training step's size is built in milliseconds."""
+    import time
+    from impersonator_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, C, H, Ho = 3, 8, 64, 96
+    x = torch.randn(n, C, H, H, generator=g)
+    grid = (torch.rand(n, Ho, Ho, 2, generator=g) * 2 - 1) * 0.12            # ~8 x 8 texels collect 96 x 96 pixels: ~500 per texel
+    grid[1] = torch.tensor([-0.313, 0.207])                                   # 9216 contributions per tap texel: dense scan
+    dy = torch.randn(n, C, Ho, Ho, generator=g)
+    xr = x.double().clone().requires_grad_(True)
+    F.grid_sample(xr, grid.double(), align_corners=False).backward(dy.double())
+    dyd, gd = dy.permute(0, 2, 3, 1).contiguous().cuda(), grid.cuda()
+    shape = (n, H, H, C)
+    runs = [ops.grid_sample_backward(dyd, gd, shape, False) for _ in range(3)]
+    assert all(torch.equal(r, runs[0]) for r in runs[1:])
+    # fp32 sums of 500 - 9216 terms in a fixed order: 3e-6 of the tensor's scale (the atomic kernel, any order: the same)
+    assert _rel(runs[0].cpu().permute(0, 3, 1, 2).double(), xr.grad) < 1e-5
+    # the training step's largest level: 4 images of 256 x 256 pixels sampling a 32 x 32-texel window of a 256 x 256 source
+    big = ((torch.rand(4, 256, 256, 2, generator=g) * 2 - 1) * 0.125).cuda()
+    ops.GridSamplePlan(big, (4, 256, 256, 8), False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ops.GridSamplePlan(big, (4, 256, 256, 8), False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    print("plan of a 64x-minifying flow, 4 x 256 x 256 pixels: %.2f ms" % ms)
+    assert ms < 60.0, ms   # (round 5, rescanning the image per queued texel: see profiles/r06_gs_plan.md)
+
+
 def test_adam_update():
     from impersonator_amd import ops
     g = torch.Generator().manual_seed(13)
