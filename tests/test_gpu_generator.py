@@ -13,8 +13,10 @@ pytestmark = pytest.mark.gpu
 
 TOL_IMAGE = 1e-3     # BASELINE.json north_star: per-pixel L-inf vs the reference
 # intermediate activations (O(1) magnitude after InstanceNorm), per conv arithmetic: exact fp32 MFMA, and the
-# default split-bf16 three-product mode (16 mantissa bits per operand; same 1e-3 bound on the image)
-TOL_FEATURES = {"fp32": 2e-4, "bf16x3": 6e-4}
+# default split-bf16 three-product mode (16 mantissa bits per operand; same 1e-3 bound on the image).  Relative to the tensor's
+# scale; 3x what is observed (round 6, printed by the tests: fp32 <= 6.1e-6 on every checkpoint, bf16x3 <= 1.2e-5 incl. the trunk
+# output after 18 layers) -- ONE wrong tap among a trunk layer's 4608 reduction entries moves a feature by ~1.5e-2 of its scale.
+TOL_FEATURES = {"fp32": 2e-5, "bf16x3": 4e-5}
 _ORACLE = {}
 
 
@@ -65,6 +67,7 @@ def test_encode_src_every_level(ctx):
     for i, (a, b) in enumerate(zip(enc + res, ctx["o_enc"] + ctx["o_res"])):
         assert tuple(a.shape) == tuple(b.shape)
         d, where = helpers.maxdiff(a, b)
+        print("OBSERVED %s source feature %d: %.3g of the tensor's scale" % (ctx["precision"], i, d / max(1.0, float(b.abs().max()))))
         assert d <= ctx["tol_feature"] * max(1.0, float(b.abs().max())), ("feature %d" % i, d, where)
     g = helpers.golden("frame_golden.npz")
     for a, st in zip(enc, g["src_enc_stat"]):
@@ -119,10 +122,12 @@ def test_trunk_and_decoder_checkpoints(ctx):
         c = 64 << l
         cat = G.peek(l, (bs, 256 >> l, 256 >> l, 2 * c))
         d, where = helpers.maxdiff(cat[..., :c].permute(0, 3, 1, 2), encs[l])
+        print("OBSERVED %s tsf encoder %d: %.3g of the tensor's scale" % (ctx["precision"], l, d / max(1.0, float(encs[l].abs().max()))))
         assert d <= ctx["tol_feature"] * max(1.0, float(encs[l].abs().max())), ("tsf encoder", l, d, where)
     trunk = G.peek(3, (bs, 32, 32, 512)).permute(0, 3, 1, 2)
     d, where = helpers.maxdiff(trunk, x)
-    assert d <= 5 * ctx["tol_feature"] * max(1.0, float(x.abs().max())), ("trunk", d, where)
+    print("OBSERVED %s trunk output: %.3g of the tensor's scale" % (ctx["precision"], d / max(1.0, float(x.abs().max()))))
+    assert d <= ctx["tol_feature"] * max(1.0, float(x.abs().max())), ("trunk", d, where)
 
 
 def test_batch_composition_is_independent(ctx):

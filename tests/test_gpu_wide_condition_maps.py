@@ -57,7 +57,7 @@ def test_wide_condition_map_chain_matches_oracle(map_name, precision):
         assert torch.equal(out["fim"].cpu(), fr["fim"].to(torch.int32)) and torch.equal(out["cond"].cpu(), fr["cond"])
         assert helpers.maxdiff(out["T"], fr["T"])[0] <= 2e-6
         enc, res = G.encode_src(src_inputs.cuda())
-        tol_f = {"fp32": 2e-4, "bf16x3": 6e-4}[precision]
+        tol_f = {"fp32": 2e-5, "bf16x3": 4e-5}[precision]   # as tests/test_gpu_generator.py (the source stream is exact fp32 in both modes)
         for i, (a, b) in enumerate(zip(enc + res, o_enc + o_res)):
             d, where = helpers.maxdiff(a, b)
             assert d <= tol_f * max(1.0, float(b.abs().max())), ("source feature %d" % i, d, where)
