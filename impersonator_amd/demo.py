@@ -34,6 +34,22 @@ def synthetic_smpls(num_frames, seed=0):
     return np.concatenate([cam, pose, shape], 1).astype(np.float32)
 
 
+def synthetic_map_fn(map_name, rest, faces):
+    """The face -> condition table of `--map_name` (utils/mesh.py:368-421) on the synthetic body mesh, background row included:
+    'uv_seg' (3 channels, the default), 'par' (10 part labels + background = 11), 'binary' (the face index in binary, background -1)."""
+    if map_name == 'uv_seg':
+        return synthetic.uv_seg_map_fn(rest, faces)
+    if map_name == 'par':
+        return synthetic.part_map_fn(rest, faces)[0]
+    if map_name == 'binary':
+        nf = faces.shape[0]
+        width = len(np.binary_repr(nf))
+        idx = np.arange(nf, dtype=np.int64)[:, None]
+        tab = ((idx >> np.arange(width - 1, -1, -1, dtype=np.int64)[None, :]) & 1).astype(np.float32)
+        return np.concatenate([tab, np.zeros((1, width), np.float32) - 1.0], axis=0)
+    raise ValueError('map name error {}'.format(map_name))
+
+
 def build_synthetic_imitator(batch_size=8, seed=0, image_size=256, affine="identity", opt=None, model="imitator"):
     """Returns (imitator, src_smpl (85,), src_img (3,H,W) in [-1,1], bg_img (3,H,W))."""
     from .models.imitator import Imitator
@@ -45,10 +61,12 @@ def build_synthetic_imitator(batch_size=8, seed=0, image_size=256, affine="ident
 
     opt = opt or default_opt(batch_size=batch_size, image_size=image_size)
     rest, faces = synthetic.body_mesh()
-    render = SMPLRenderer(image_size=image_size, faces=faces, map_fn=synthetic.uv_seg_map_fn(rest, faces),
+    map_fn = synthetic_map_fn(getattr(opt, 'map_name', 'uv_seg'), rest, faces)
+    dim = 3 + map_fn.shape[1]                       # models/imitator.py:68-70: src_dim = tsf_dim = 3 + cond_nc
+    render = SMPLRenderer(image_size=image_size, faces=faces, map_fn=map_fn,
                           front_map_fn=synthetic.front_map_fn(rest, faces), has_front=True,
                           align_corners=opt.align_corners)
-    gen = ImpersonatorGenerator(bg_dim=4, src_dim=6, tsf_dim=6, repeat_num=opt.repeat_num, image_size=image_size,
+    gen = ImpersonatorGenerator(bg_dim=4, src_dim=dim, tsf_dim=dim, repeat_num=opt.repeat_num, image_size=image_size,
                                 max_batch=batch_size, align_corners=opt.align_corners)
     shapes = [(k, tuple(v.shape)) for k, v in gen.state_dict().items()]
     sd = synthetic.random_state_dict(shapes, seed=seed, affine=affine)

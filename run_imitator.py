@@ -50,7 +50,8 @@ def main():
         imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(
             batch_size=opt.batch_size, image_size=opt.image_size,
             opt=demo.default_opt(batch_size=opt.batch_size, image_size=opt.image_size, front_warp=opt.front_warp,
-                                 only_vis=opt.only_vis, align_corners=opt.align_corners))
+                                 only_vis=opt.only_vis, align_corners=opt.align_corners,
+                                 map_name=getattr(opt, 'map_name', 'uv_seg')))
         imitator.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
         tgt_smpls = demo.synthetic_smpls(opt.num_frames, seed=0)
         tgt_paths = None

@@ -73,3 +73,42 @@ def test_wide_condition_map_chain_matches_oracle(map_name, precision):
             G.inference(enc, res, x8, out["T"])
     finally:
         G.release()
+
+
+def test_imitator_with_the_par_condition_map_matches_the_oracle():
+    """The reference's own API on `--map_name par` (models/models.py:85-94: src_dim = tsf_dim = 3 + 11): Imitator.personalize ->
+    transfer_params_by_smpl -> forward for four frames against the oracle's chain on the same posed vertices, and the two-lane
+    pipeline against the sequential calls, bit for bit."""
+    from impersonator_amd import demo
+    B = 4
+    opt = demo.default_opt(batch_size=B, image_size=256, map_name="par")
+    imitator, src_smpl, src_img, bg_img = demo.build_synthetic_imitator(batch_size=B, seed=0, image_size=256, affine="random", opt=opt)
+    assert imitator.generator.src_dim == 14 and imitator.render.map_fn.shape[1] == 11
+    imitator.personalize(src_img, src_smpl=src_smpl, bg_img=bg_img)
+    smpls = torch.from_numpy(demo.synthetic_smpls(64, seed=0))[8:8 + 2 * B].cuda()
+    imitator.first_cam = smpls[0:1, 0:3].clone()
+    chunks = [(smpls[s:s + B], 8 + s) for s in range(0, 2 * B, B)]
+    seq, infos = [], []
+    for chunk, t in chunks:
+        x = imitator.transfer_params_by_smpl(chunk, "smooth", t=t)
+        info = imitator.tsf_info
+        assert tuple(x.shape) == (B, 14, 256, 256)
+        seq.append(imitator.forward(x, info["T"]).clone())
+        infos.append({k: info[k].clone() for k in ("verts", "cam", "fim", "T", "cond")})
+    piped = [p.clone() for _, p in imitator.predict_batches(iter(chunks), "smooth", lanes=2)]
+    torch.cuda.synchronize()
+    for a, b in zip(seq, piped):
+        assert torch.equal(a, b)
+    sd = {k: v.detach().cpu() for k, v in imitator.generator.state_dict().items()}
+    faces_t, map_fn, si = imitator.render.faces.cpu(), imitator.render.map_fn.cpu(), imitator.src_info
+    src_t, bg_t = torch.from_numpy(src_img)[None], torch.from_numpy(bg_img)[None]
+    verts, cam = torch.cat([i["verts"] for i in infos]).cpu(), torch.cat([i["cam"] for i in infos]).cpu()
+    with torch.no_grad():
+        src = torch_ref.personalize(sd, src_t, si["cam"].cpu(), si["verts"].cpu(), faces_t, map_fn, ft_ks=imitator._opt.ft_ks)
+        fr, pred = torch_ref.imitator_frames(sd, src, src_t, bg_t, cam, verts, faces_t, map_fn)
+    assert torch.equal(src["fim"], imitator.src_info["fim"].cpu())
+    assert torch.equal(torch.cat([i["fim"] for i in infos]).cpu(), fr["fim"])
+    assert torch.equal(torch.cat([i["cond"] for i in infos]).cpu(), fr["cond"])
+    err = float((torch.cat(seq).cpu() - pred).abs().max())
+    print("Imitator, map_name par: L-inf over %d frames = %.3g" % (2 * B, err))
+    assert err <= TOL_IMAGE
