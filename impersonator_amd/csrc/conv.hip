@@ -2019,7 +2019,9 @@ int launch_conv_igemm(const ConvArgs &a_in, int bn, hipStream_t st, int *variant
         }
         // ConvTranspose2d(k3, s2, p1, op1) given as its four phases: one launch of the halo kernel (CT = 1)
         if (!(halo_env && halo_env[0] == '0') && haloCT_shape(a)) {
-            const bool wide = a.Cout % 128 == 0 && (long)a.mtiles * (a.Cout / 128) >= device_cu_count();
+            static const char *ct_wide_env = getenv("LWG_CT_WIDE");   // "0": the 64-channel tile (two workgroups per CU) everywhere (A/B switch)
+            const bool wide = a.Cout % 128 == 0 && (long)a.mtiles * (a.Cout / 128) >= device_cu_count() &&
+                              !(ct_wide_env && ct_wide_env[0] == '0');
             const int cbn = wide ? 128 : 64, ns = wide ? 4 : 3;
             const int nch = ((4 + 1) * (32 + 1) + 7) / 8;
             const size_t bytes = ((size_t)2 * nch * 8 * BK + (size_t)ns * cbn * BK) * sizeof(float) +
