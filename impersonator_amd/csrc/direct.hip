@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256 * ST_GROUPS) void stem_bf16x3_kernel(const Stem
     const int group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
     unsigned char *halo = lds + 2 * ST_WPLANE + group * ST_GLDS;   // [2 planes][ST_HH][ST_HW] x 12 B
     float2 *red = reinterpret_cast<float2 *>(halo + 2 * ST_HPLANE);
-    unsigned *gctr = reinterpret_cast<unsigned *>(lds + 2 * ST_WPLANE + ST_GROUPS * ST_GLDS) + group;
+    unsigned *gctr_all = reinterpret_cast<unsigned *>(lds + 2 * ST_WPLANE + ST_GROUPS * ST_GLDS);   // one barrier counter per group
+    unsigned *gctr = gctr_all + group;
     unsigned gtarget = 0;
 
     const int tid = threadIdx.x & 255, lane = tid & 63;   // thread within its group
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256 * ST_GROUPS) void stem_bf16x3_kernel(const Stem
     // filter bank: staged once per workgroup, already in LDS layout
     for (int i = threadIdx.x; i < 2 * ST_WPLANE / 16; i += 256 * ST_GROUPS)
         reinterpret_cast<float4 *>(wts)[i] = reinterpret_cast<const float4 *>(a.w)[i];
-    if (threadIdx.x < ST_GROUPS) gctr[threadIdx.x - group] = 0;   // (group is 0 for these threads)
+    if (threadIdx.x < ST_GROUPS) gctr_all[threadIdx.x] = 0;
 
     // lane bases (bytes).  A: run of pixel (wrow, whalf*64 + i*32 + (lane&31)), k half lane>>5 (relative to a halo plane);
     // B: weight row of channel j*32 + (lane&31), k half lane>>5 (relative to a weight plane)
