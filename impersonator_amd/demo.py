@@ -42,11 +42,8 @@ def synthetic_map_fn(map_name, rest, faces):
     if map_name == 'par':
         return synthetic.part_map_fn(rest, faces)[0]
     if map_name == 'binary':
-        nf = faces.shape[0]
-        width = len(np.binary_repr(nf))
-        idx = np.arange(nf, dtype=np.int64)[:, None]
-        tab = ((idx >> np.arange(width - 1, -1, -1, dtype=np.int64)[None, :]) & 1).astype(np.float32)
-        return np.concatenate([tab, np.zeros((1, width), np.float32) - 1.0], axis=0)
+        from .utils import mesh
+        return np.concatenate(mesh.binary_mapping(faces.shape[0]), axis=0)
     raise ValueError('map name error {}'.format(map_name))
 
 

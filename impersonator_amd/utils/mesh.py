@@ -50,6 +50,15 @@ def _face_list(path, nf, fill_back):
     return faces
 
 
+def binary_mapping(nf):
+    """utils/mesh.py:271-279: the face index in binary, most significant bit first, len(binary_repr(nf)) channels; background = -1
+    everywhere.  Returns (table (nf, width), background row (1, width))."""
+    width = len(np.binary_repr(nf))
+    idx = np.arange(nf, dtype=np.int64)[:, None]
+    map_fn = ((idx >> np.arange(width - 1, -1, -1, dtype=np.int64)[None, :]) & 1).astype(np.float32)
+    return map_fn, np.zeros((1, width), np.float32) - 1.0
+
+
 def create_mapping(map_name, mapping_path='assets/pretrains/mapper.txt',
                    part_info='assets/pretrains/smpl_part_info.json',
                    front_info='assets/pretrains/front_facial.json',
@@ -94,11 +103,7 @@ def create_mapping(map_name, mapping_path='assets/pretrains/mapper.txt',
         map_fn[faces] = 1.0
         bg = np.zeros((1, 1), np.float32)
     elif map_name == 'binary':
-        # utils/mesh.py:271-279: the face index in binary, most significant bit first; background = -1 everywhere
-        width = len(np.binary_repr(nf))
-        idx = np.arange(nf, dtype=np.int64)[:, None]
-        map_fn = ((idx >> np.arange(width - 1, -1, -1, dtype=np.int64)[None, :]) & 1).astype(np.float32)
-        bg = np.zeros((1, width), np.float32) - 1.0
+        map_fn, bg = binary_mapping(nf)
     else:
         # ('ids' cannot be built with contain_bg in the reference either: its table is 1-D, utils/mesh.py:282-285)
         raise ValueError('map name error {}'.format(map_name))

@@ -16,11 +16,8 @@ TOL_IMAGE = 1e-3
 
 
 def _binary_table(nf):
-    """create_mapping('binary') needs the reference's mapper.txt for the face count only: the same table from nf."""
-    width = len(np.binary_repr(nf))
-    idx = np.arange(nf, dtype=np.int64)[:, None]
-    tab = ((idx >> np.arange(width - 1, -1, -1, dtype=np.int64)[None, :]) & 1).astype(np.float32)
-    return np.concatenate([tab, np.zeros((1, width), np.float32) - 1.0], axis=0)
+    """create_mapping('binary') reads the reference's mapper.txt for the face count only: the same table from nf."""
+    return np.concatenate(mesh.binary_mapping(nf), axis=0)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
